@@ -1,0 +1,139 @@
+"""ctypes loader for oracle/libposeidon_oracle.so (the C restatement)  --  TEST INFRASTRUCTURE ONLY.
+
+Used by tests/ (bulk comparator), __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import poseidon_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libposeidon_oracle.so")
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [
+        ("t", ctypes.c_uint32), ("rate", ctypes.c_uint32), ("capacity", ctypes.c_uint32),
+        ("full_rounds", ctypes.c_uint32), ("partial_rounds", ctypes.c_uint32), ("pad_", ctypes.c_uint32),
+        ("alpha", ctypes.c_uint64), ("modulus", ctypes.c_uint64 * 4), ("inv", ctypes.c_uint64),
+        ("ark", ctypes.c_void_p), ("mds", ctypes.c_void_p),
+    ]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "poseidon_ref.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-B", "all"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.pref_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def elems_to_limbs(vals, p: int, mont: bool = True) -> np.ndarray:
+    """canonical ints (any nesting flattened by the caller) -> [n][4] u64 (Montgomery by default)."""
+    out = np.empty((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        if mont:
+            v = O.to_mont(v, p)
+        out[i] = O.to_limbs(v)
+    return out
+
+
+def limbs_to_elems(arr: np.ndarray, p: int, mont: bool = True):
+    arr = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 4)
+    out = []
+    for row in arr:
+        v = O.from_limbs([int(x) for x in row])
+        out.append(O.from_mont(v, p) if mont else v)
+    return out
+
+
+class CRef:
+    """One PoseidonConfig loaded into the C restatement."""
+
+    def __init__(self, cfg: O.PoseidonConfig):
+        self.cfg = cfg
+        p = cfg.p
+        self._ark = np.ascontiguousarray(
+            elems_to_limbs([v for row in cfg.ark for v in row], p).reshape(-1))
+        self._mds = np.ascontiguousarray(
+            elems_to_limbs([v for row in cfg.mds for v in row], p).reshape(-1))
+        c = _Config()
+        c.t, c.rate, c.capacity = cfg.t, cfg.rate, cfg.capacity
+        c.full_rounds, c.partial_rounds, c.alpha = cfg.full_rounds, cfg.partial_rounds, cfg.alpha
+        for i, l in enumerate(O.to_limbs(p)):
+            c.modulus[i] = l
+        c.inv = O.mont_constants(p)["inv"]
+        c.ark = self._ark.ctypes.data
+        c.mds = self._mds.ctypes.data
+        self._c = c
+
+    @staticmethod
+    def _ptr(a: np.ndarray):
+        assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+        return ctypes.c_void_p(a.ctypes.data)
+
+    def permute_batch(self, states: np.ndarray, threads: int = 1) -> np.ndarray:
+        """states [n][t][4] Montgomery limbs -> permuted copy."""
+        out = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        n = out.size // (self.cfg.t * 4)
+        rc = lib().pref_permute_batch(ctypes.byref(self._c), self._ptr(out), ctypes.c_size_t(n),
+                                      ctypes.c_int(threads))
+        assert rc == 0
+        return out
+
+    def hash_batch(self, msgs: np.ndarray, L: int, k: int, threads: int = 1) -> np.ndarray:
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint64)
+        n = msgs.size // (L * 4) if L else msgs.shape[0]
+        out = np.zeros((n, k, 4), dtype=np.uint64)
+        rc = lib().pref_hash_batch(ctypes.byref(self._c), self._ptr(msgs), ctypes.c_size_t(L),
+                                   self._ptr(out), ctypes.c_size_t(k), ctypes.c_size_t(n),
+                                   ctypes.c_int(threads))
+        assert rc == 0
+        return out
+
+    def merkle(self, leaves: np.ndarray, threads: int = 1) -> np.ndarray:
+        """leaves [m][4] -> nodes [2m-1][4] (leaves, then each level, root last)."""
+        leaves = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4)
+        m = leaves.shape[0]
+        nodes = np.zeros((2 * m - 1, 4), dtype=np.uint64)
+        nodes[:m] = leaves
+        rc = lib().pref_merkle_2to1(ctypes.byref(self._c), self._ptr(nodes), ctypes.c_size_t(m),
+                                    ctypes.c_int(threads))
+        assert rc == 0
+        return nodes
+
+    def sponge_absorb(self, state: np.ndarray, mode: int, index: int, elems: np.ndarray):
+        state = np.ascontiguousarray(state, dtype=np.uint64).copy()
+        elems = np.ascontiguousarray(elems, dtype=np.uint64).reshape(-1, 4)
+        m, i = ctypes.c_uint32(mode), ctypes.c_uint32(index)
+        lib().pref_sponge_absorb(ctypes.byref(self._c), self._ptr(state), ctypes.byref(m),
+                                 ctypes.byref(i), self._ptr(elems), ctypes.c_size_t(elems.shape[0]))
+        return state, m.value, i.value
+
+    def sponge_squeeze(self, state: np.ndarray, mode: int, index: int, n: int):
+        state = np.ascontiguousarray(state, dtype=np.uint64).copy()
+        out = np.zeros((n, 4), dtype=np.uint64)
+        m, i = ctypes.c_uint32(mode), ctypes.c_uint32(index)
+        lib().pref_sponge_squeeze(ctypes.byref(self._c), self._ptr(state), ctypes.byref(m),
+                                  ctypes.byref(i), self._ptr(out), ctypes.c_size_t(n))
+        return state, m.value, i.value, out
+
+
+def max_threads() -> int:
+    return int(lib().pref_max_threads())
