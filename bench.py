@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched Poseidon permutation on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path (pmx_permute_batch_dev: PoseidonSponge::permute on every state,
+reference src/poseidon/mod.rs:95-118) over one device-resident batch of synthetic random states.
+Workload at N=1: BASELINE.json configs[1] -- 2^20 independent states, BLS12-381 Fr, t=3, alpha=5, 8+31
+rounds.  For N>1 (launched by torch.distributed.run, one rank per GPU) every rank permutes its own
+2^20-state shard (weak scaling, no data-path collective) and the permuted shards are all-gathered over
+RCCL, double-buffered so the gather of step k overlaps the permutation of step k+1 ("final gather").
+
+Rank 0 prints ONE JSON line.  `value` = permutations per second over all ranks, inputs already in HBM.
+`roofline` prices the permutation kernel against HBM (algorithmic 2*t*32 bytes per permutation);
+`cpu_baseline` times the C restatement of the reference algorithm (oracle/, kind "port") on the host
+cores for a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (field, rate, alpha, RF, RP, log2 states per GPU, seed, description)
+    "c2": ("bls12_381_fr", 2, 5, 8, 31, 20, 0x5EED0002, "bls12_381_fr t=3 alpha=5 RF=8 RP=31, 2^20 states/GPU"),
+    "c3": ("bn254_fr", 8, 5, 8, 57, 18, 0x5EED0003, "bn254_fr t=9 alpha=5 RF=8 RP=57, 2^18 states/GPU"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--states-per-gpu-log2", type=int, default=None)
+    ap.add_argument("--gather", default="overlap", choices=["overlap", "serial", "none"],
+                    help="N>1: all-gather of each step's output shard (RCCL)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(field_name, rate, alpha, rf, rp, seed, target_seconds):
+    """C restatement of the reference permutation (oracle/poseidon_ref.c) on all host cores."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    import sponge_amd as S
+    from sponge_amd import synth
+
+    p, bits = {"bls12_381_fr": (O.BLS12_381_FR, 255), "bn254_fr": (O.BN254_FR, 254)}[field_name]
+    ocfg = O.make_config(p, bits, rate, alpha, rf, rp)
+    cr = cref.CRef(ocfg)
+    t = rate + 1
+    threads = cref.max_threads()
+    field = S.FIELDS[field_name]
+    probe = synth.random_elements(field, 4096 * t, seed).reshape(4096, t, 4)
+    t0 = time.perf_counter()
+    cr.permute_batch(probe, threads=threads)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    n = int(min(1 << 22, max(4096, 4096 * target_seconds / dt)))
+    n = 1 << (n.bit_length() - 1)
+    batch = synth.random_elements(field, n * t, seed).reshape(n, t, 4)
+    t0 = time.perf_counter()
+    cr.permute_batch(batch, threads=threads)
+    dt = time.perf_counter() - t0
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": n / dt, "unit": "permutations/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} states of the same seeded batch, C restatement of mod.rs:63-118 "
+                      f"(dense MDS, square-and-multiply pow), OpenMP x{threads}, {dt:.2f} s, CPU: {model}"}
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the Poseidon path has no CPU fallback")
+
+    import torch.distributed as dist
+    import sponge_amd as S
+    from sponge_amd import synth
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    field_name, rate, alpha, rf, rp, log2n, seed, desc = WORKLOADS[args.workload]
+    if args.states_per_gpu_log2 is not None:
+        log2n = args.states_per_gpu_log2
+    n = 1 << log2n
+    t = rate + 1
+    field = S.FIELDS[field_name]
+    cfg = S.poseidon_config_from_lfsr(field, rate, alpha, rf, rp)
+    ctx = cfg.context(local_rank)
+
+    # this rank's shard of the global seeded batch [world*n][t][4]
+    host = synth.random_elements(field, n * t, seed, offset=rank * n * t)
+    n_buf = 2 if (world > 1 and args.gather == "overlap") else 1
+    bufs = [torch.from_numpy(host.view(np.int64).copy()).to(dev).reshape(n, t, 4) for _ in range(n_buf)]
+    gathered = [torch.empty((world * n, t, 4), dtype=torch.int64, device=dev) for _ in range(n_buf)] \
+        if (world > 1 and args.gather != "none") else None
+    pending = [None] * n_buf
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        b = i % n_buf
+        if pending[b] is not None:           # the gather that still reads this buffer
+            pending[b].wait()
+            pending[b] = None
+        ctx.permute_batch_dev(bufs[b].data_ptr(), n, stream.cuda_stream)
+        if gathered is not None:
+            work = dist.all_gather_into_tensor(gathered[b].view(-1), bufs[b].view(-1), async_op=True)
+            if args.gather == "serial":
+                work.wait()
+            else:
+                pending[b] = work
+
+    def drain():
+        for b in range(n_buf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    drain()
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
+
+    times = torch.tensor([elapsed, dev_ms / 1e3], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    elapsed, dev_s = float(times[0]), float(times[1])
+
+    if rank == 0:
+        perms = float(world) * n * args.steps
+        value = perms / elapsed
+        # dominant kernel: permute_kernel; its average launch duration from the HIP events of this rank's
+        # stream (at N=1 the timed region holds nothing but the K back-to-back launches)
+        kernel_s = dev_s / args.steps
+        algo_bytes = 2 * t * 32 * n                       # 2*t*32 B per permutation, n per launch
+        achieved = algo_bytes / kernel_s / 1e9
+        out = {
+            "metric": "Poseidon permutations/sec", "value": value, "unit": "permutations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32-limb Montgomery (256-bit modular integer)", "data": "synthetic",
+            "config": {"workload": desc, "states_per_gpu": n, "total_states": world * n,
+                       "gather": (args.gather if world > 1 else "n/a"), "sharding": f"contiguous x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
+                         "kernel": "pmx::permute_kernel", "kernel_ms": 1e3 * kernel_s,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "integer-VALU bound, not HBM bound: see DESIGN.md (v_mad_u64_u32 roofline)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(field_name, rate, alpha, rf, rp, seed, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        return json.load(open(path))[workload]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

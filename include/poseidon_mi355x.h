@@ -1,0 +1,139 @@
+/*
+ * poseidon_mi355x.h -- C ABI of the MI355X-native batched Poseidon permutation / duplex sponge.
+ *
+ * Drop-in boundary for the Poseidon hot path of arkworks-rs/sponge (ark-sponge).  The reference has
+ * no FFI seam of its own (src/lib.rs:10 forbids unsafe); the seam is its generic trait surface.  Each
+ * entry point below names the reference interface it replaces.  The Rust-side binding a maintainer
+ * adds is shown in INTEGRATION.md.
+ *
+ * Element representation (everywhere in this ABI): a field element is 4 little-endian uint64_t limbs
+ * holding the fully reduced Montgomery residue  x * 2^256 mod p  -- byte-identical to ark-ff's
+ * Fp<MontBackend<_,4>,4>, so a Rust &[Fr] / Vec<Fr> is passed as-is (src/poseidon/mod.rs:57 `state`).
+ * "Bit-exact" means limb-for-limb equality of these residues.
+ *
+ * State order inside one sponge state is the reference's: capacity elements first, then the rate
+ * elements (src/poseidon/mod.rs:128,143,159).
+ *
+ * All functions return PMX_OK (0) or a negative pmx_status; pmx_last_error() gives the message of the
+ * calling thread's last failure.  Nothing throws or aborts across the boundary (the reference panics:
+ * src/poseidon/mod.rs:196-203).  There is NO CPU fallback: without a usable HIP device every data-path
+ * call fails with PMX_ERR_HIP.
+ *
+ * Threading: a pmx_ctx is single-caller; distinct contexts are independent.
+ */
+#ifndef POSEIDON_MI355X_H
+#define POSEIDON_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_ABI_VERSION 1
+#define PMX_LIMBS 4        /* uint64_t limbs per field element */
+#define PMX_MAX_WIDTH 16   /* largest rate+capacity accepted (reference default table uses 3..9) */
+
+typedef enum pmx_status {
+    PMX_OK = 0,
+    PMX_ERR_CONFIG = -1,      /* violates the asserts of PoseidonConfig::new (src/poseidon/mod.rs:196-203) or a limit of this build */
+    PMX_ERR_ARG = -2,         /* null pointer / bad size / bad mode word */
+    PMX_ERR_HIP = -3,         /* HIP runtime failure or no device */
+    PMX_ERR_UNSUPPORTED = -4  /* width without a compiled kernel */
+} pmx_status;
+
+/* DuplexSpongeMode (src/lib.rs:198-210) as two words per sponge: tag + index. */
+#define PMX_MODE_ABSORBING 0u /* index = next_absorb_index  in [0, rate] */
+#define PMX_MODE_SQUEEZING 1u /* index = next_squeeze_index in [0, rate] */
+
+/*
+ * PoseidonConfig<F> (src/poseidon/mod.rs:23-42) plus the prime.  ark / mds are borrowed for the
+ * duration of pmx_ctx_create only.
+ */
+typedef struct pmx_config {
+    uint32_t full_rounds;            /* PoseidonConfig::full_rounds (even; RF/2 before and after the partial rounds) */
+    uint32_t partial_rounds;         /* PoseidonConfig::partial_rounds */
+    uint64_t alpha;                  /* PoseidonConfig::alpha, S-box exponent */
+    uint32_t rate;                   /* PoseidonConfig::rate */
+    uint32_t capacity;               /* PoseidonConfig::capacity */
+    uint64_t modulus[PMX_LIMBS];     /* p, canonical little-endian limbs (odd, < 2^256) */
+    const uint64_t *ark;             /* [full_rounds+partial_rounds][rate+capacity][4]  ark[round][i] */
+    const uint64_t *mds;             /* [rate+capacity][rate+capacity][4]               mds[i][j], row-major */
+} pmx_config;
+
+typedef struct pmx_ctx pmx_ctx;
+
+/* ---- library / error ------------------------------------------------------------------------- */
+int pmx_abi_version(void);
+const char *pmx_last_error(void);
+/* Number of HIP devices visible (0 when none; never fails). */
+int pmx_device_count(void);
+
+/* ---- parameters (host only) -------------------------------------------------------------------
+ * find_poseidon_ark_and_mds (src/poseidon/traits.rs:105-146) with PoseidonGrainLFSR
+ * (src/poseidon/grain_lfsr.rs:15-189): width = rate+1.  Writes Montgomery residues:
+ * ark_out [(full_rounds+partial_rounds)*(rate+1)*4], mds_out [(rate+1)*(rate+1)*4]. */
+int pmx_find_poseidon_ark_and_mds(const uint64_t modulus[PMX_LIMBS], uint64_t prime_bits, uint32_t rate,
+                                  uint32_t full_rounds, uint32_t partial_rounds, uint32_t skip_matrices,
+                                  uint64_t *ark_out, uint64_t *mds_out);
+
+/* Montgomery constants of a modulus: inv = -p^-1 mod 2^64, r = 2^256 mod p, r2 = 2^512 mod p. */
+int pmx_mont_constants(const uint64_t modulus[PMX_LIMBS], uint64_t *inv, uint64_t r[PMX_LIMBS],
+                       uint64_t r2[PMX_LIMBS]);
+/* canonical -> Montgomery / Montgomery -> canonical, in place over n elements (ark-ff from_bigint / into_bigint). */
+int pmx_to_mont(const uint64_t modulus[PMX_LIMBS], uint64_t *elems, size_t n);
+int pmx_from_mont(const uint64_t modulus[PMX_LIMBS], uint64_t *elems, size_t n);
+
+/* ---- context ----------------------------------------------------------------------------------
+ * CryptographicSponge::new's parameter clone (src/poseidon/mod.rs:219-230) happens once here: the
+ * config is validated like PoseidonConfig::new (src/poseidon/mod.rs:187-213) and its constants are
+ * uploaded to `device`.  */
+int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out);
+int pmx_ctx_destroy(pmx_ctx *ctx);
+/* width t = rate + capacity of the context's config */
+int pmx_ctx_width(const pmx_ctx *ctx);
+
+/* ---- permutation ------------------------------------------------------------------------------
+ * PoseidonSponge::permute (src/poseidon/mod.rs:95-118 with apply_ark :76-80, apply_s_box :63-74,
+ * apply_mds :82-93) applied independently to n states, in place.  states: [n][t][4].
+ * The host variant copies in, runs the kernel, copies out.  The _dev variant takes a device pointer
+ * and a hipStream_t (NULL = default stream) and only enqueues.  */
+int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n);
+int pmx_permute_batch_dev(pmx_ctx *ctx, uint64_t *d_states, size_t n, void *stream);
+
+/* ---- fixed-shape hash driver ------------------------------------------------------------------
+ * Per row: PoseidonSponge::new; absorb(in_len native elements); squeeze_native_field_elements(out_len)
+ * (src/poseidon/mod.rs:219-254, 321-341).  in: [n][in_len][4], out: [n][out_len][4].  in_len may be 0
+ * (absorb of an empty input is a no-op, mod.rs:234-236). */
+int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n);
+int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64_t *d_out, size_t out_len,
+                       size_t n, void *stream);
+
+/* ---- duplex sponge driver on explicit (state, mode) ---------------------------------------------
+ * n mid-stream sponges as moved out by SpongeExt::into_state (src/lib.rs:188-195,
+ * src/poseidon/mod.rs:344-367): states [n][t][4], mode_tag [n], mode_index [n]; all updated in place.
+ * absorb: CryptographicSponge::absorb for in_len native elements per sponge (mod.rs:232-254, 121-150).
+ * squeeze: FieldBasedCryptographicSponge::squeeze_native_field_elements(out_len) (mod.rs:321-341,
+ * 153-182, including the `!= rate` test of :175).  Sponges in one call may be in different modes. */
+int pmx_sponge_absorb_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
+                            const uint64_t *in, size_t in_len, size_t n);
+int pmx_sponge_squeeze_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
+                             uint64_t *out, size_t out_len, size_t n);
+int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_mode_tag, uint32_t *d_mode_index,
+                                const uint64_t *d_in, size_t in_len, size_t n, void *stream);
+int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_mode_tag, uint32_t *d_mode_index,
+                                 uint64_t *d_out, size_t out_len, size_t n, void *stream);
+
+/* ---- 2-to-1 Merkle compression ------------------------------------------------------------------
+ * parent = (new; absorb([left, right]); squeeze_native(1))[0]  (needs rate >= 2), level by level.
+ * leaves: [n_leaves][4], n_leaves a power of two.  nodes (may be NULL): [2*n_leaves-1][4] receives the
+ * leaves, then every level, root last.  root (may be NULL): [4]. */
+int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint64_t *nodes, uint64_t *root);
+/* Device variant: d_nodes [2*n_leaves-1][4] must already hold the leaves in its first n_leaves rows. */
+int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_leaves, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEIDON_MI355X_H */

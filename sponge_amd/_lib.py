@@ -1,0 +1,92 @@
+"""ctypes binding of libposeidon_mi355x.so (the C ABI declared in include/poseidon_mi355x.h).
+
+There is deliberately no fallback: if the shared library is missing, import fails; if no HIP device is
+usable, context creation raises PmxError (PMX_ERR_HIP).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libposeidon_mi355x.so")
+
+PMX_OK = 0
+PMX_ERR_CONFIG = -1
+PMX_ERR_ARG = -2
+PMX_ERR_HIP = -3
+PMX_ERR_UNSUPPORTED = -4
+
+MODE_ABSORBING = 0
+MODE_SQUEEZING = 1
+
+
+class PmxError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"pmx error {code}: {message}")
+        self.code = code
+
+
+class PmxConfig(ctypes.Structure):
+    _fields_ = [
+        ("full_rounds", ctypes.c_uint32), ("partial_rounds", ctypes.c_uint32),
+        ("alpha", ctypes.c_uint64),
+        ("rate", ctypes.c_uint32), ("capacity", ctypes.c_uint32),
+        ("modulus", ctypes.c_uint64 * 4),
+        ("ark", ctypes.c_void_p), ("mds", ctypes.c_void_p),
+    ]
+
+
+_u64p = ctypes.c_void_p
+_u32p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); one entry per function declared in include/poseidon_mi355x.h
+SIGNATURES = {
+    "pmx_abi_version": (ctypes.c_int, []),
+    "pmx_last_error": (ctypes.c_char_p, []),
+    "pmx_device_count": (ctypes.c_int, []),
+    "pmx_find_poseidon_ark_and_mds": (ctypes.c_int, [_u64p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                                     ctypes.c_uint32, ctypes.c_uint32, _u64p, _u64p]),
+    "pmx_mont_constants": (ctypes.c_int, [_u64p, _u64p, _u64p, _u64p]),
+    "pmx_to_mont": (ctypes.c_int, [_u64p, _u64p, _sz]),
+    "pmx_from_mont": (ctypes.c_int, [_u64p, _u64p, _sz]),
+    "pmx_ctx_create": (ctypes.c_int, [ctypes.POINTER(PmxConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_ctx_width": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_permute_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz]),
+    "pmx_permute_batch_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, ctypes.c_void_p]),
+    "pmx_hash_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p, _sz, _sz]),
+    "pmx_hash_batch_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p, _sz, _sz, ctypes.c_void_p]),
+    "pmx_sponge_absorb_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u32p, _u32p, _u64p, _sz, _sz]),
+    "pmx_sponge_squeeze_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u32p, _u32p, _u64p, _sz, _sz]),
+    "pmx_sponge_absorb_batch_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u32p, _u32p, _u64p, _sz, _sz,
+                                                   ctypes.c_void_p]),
+    "pmx_sponge_squeeze_batch_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u32p, _u32p, _u64p, _sz, _sz,
+                                                    ctypes.c_void_p]),
+    "pmx_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p, _u64p]),
+    "pmx_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C sponge_amd/csrc` "
+                "(or __graft_entry__.build()). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != PMX_OK:
+        raise PmxError(rc, lib().pmx_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,322 @@
+// C ABI of libposeidon_mi355x.so: contexts, validation, host<->device staging, kernel dispatch.
+// See include/poseidon_mi355x.h for the contract and the reference interfaces each entry replaces.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/poseidon_mi355x.h"
+#include "pmx_host_field.hpp"
+#include "pmx_internal.hpp"
+#include "pmx_launch.hpp"
+
+namespace pmx {
+
+static thread_local char g_error[512] = "";
+
+int set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what) {
+    return set_error(PMX_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define PMX_HIP(expr)                                        \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);    \
+    } while (0)
+
+}  // namespace pmx
+
+using namespace pmx;
+
+struct pmx_ctx {
+    int device;
+    uint32_t t;
+    DevConfig dev;           // kernel-argument block (points at d_consts)
+    uint32_t *d_consts;      // device: ark | mds as u32 limbs
+    hipStream_t stream;      // used by the host-buffer entry points
+    void *scratch[4];        // grow-only device staging for the host-buffer entry points
+    size_t scratch_bytes[4];
+};
+
+static int ctx_bind(pmx_ctx *ctx) {
+    PMX_HIP(hipSetDevice(ctx->device));
+    return PMX_OK;
+}
+
+static int ctx_scratch(pmx_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) PMX_HIP(hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr;
+        ctx->scratch_bytes[slot] = 0;
+        PMX_HIP(hipMalloc(&ctx->scratch[slot], bytes));
+        ctx->scratch_bytes[slot] = bytes;
+    }
+    *out = ctx->scratch[slot];
+    return PMX_OK;
+}
+
+extern "C" int pmx_abi_version(void) { return PMX_ABI_VERSION; }
+
+extern "C" const char *pmx_last_error(void) { return g_error; }
+
+extern "C" int pmx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) {
+    if (!cfg || !out) return set_error(PMX_ERR_ARG, "pmx_ctx_create: null pointer");
+    *out = nullptr;
+    if (!cfg->ark || !cfg->mds) return set_error(PMX_ERR_ARG, "pmx_ctx_create: null ark/mds");
+    const uint64_t t64 = (uint64_t)cfg->rate + cfg->capacity;
+    if (cfg->rate == 0) return set_error(PMX_ERR_CONFIG, "rate must be >= 1");
+    if (t64 > PMX_MAX_WIDTH) return set_error(PMX_ERR_UNSUPPORTED, "width %llu > PMX_MAX_WIDTH %d", (unsigned long long)t64, PMX_MAX_WIDTH);
+    if (cfg->full_rounds % 2) return set_error(PMX_ERR_CONFIG, "full_rounds must be even (RF/2 rounds on each side, mod.rs:96)");
+    const uint64_t rounds = (uint64_t)cfg->full_rounds + cfg->partial_rounds;
+    if (rounds == 0 || rounds > 4096) return set_error(PMX_ERR_CONFIG, "round count %llu out of range", (unsigned long long)rounds);
+    HostField f;
+    if (!f.init(cfg->modulus)) return set_error(PMX_ERR_CONFIG, "modulus must be odd and > 2");
+    const uint32_t t = (uint32_t)t64;
+    const size_t n_ark = (size_t)rounds * t, n_mds = (size_t)t * t;
+    // every constant must be a reduced residue (ark-ff's invariant for Fp values)
+    for (size_t k = 0; k < n_ark + n_mds; ++k) {
+        const uint64_t *src = k < n_ark ? cfg->ark + 4 * k : cfg->mds + 4 * (k - n_ark);
+        U256 v;
+        std::memcpy(v.l, src, sizeof v.l);
+        if (u256_geq(v, f.p)) return set_error(PMX_ERR_CONFIG, "%s constant %zu is not reduced", k < n_ark ? "ark" : "mds", k < n_ark ? k : k - n_ark);
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return set_error(PMX_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+
+    pmx_ctx *ctx = new (std::nothrow) pmx_ctx();
+    if (!ctx) return set_error(PMX_ERR_ARG, "out of host memory");
+    std::memset(ctx, 0, sizeof *ctx);
+    ctx->device = device;
+    ctx->t = t;
+    int rc = ctx_bind(ctx);
+    if (rc) { delete ctx; return rc; }
+
+    const size_t words = (n_ark + n_mds) * 8;
+    std::vector<uint32_t> h(words);
+    std::memcpy(h.data(), cfg->ark, n_ark * 32);
+    std::memcpy(h.data() + n_ark * 8, cfg->mds, n_mds * 32);
+    e = hipMalloc((void **)&ctx->d_consts, words * 4);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_consts, h.data(), words * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        if (ctx->d_consts) (void)hipFree(ctx->d_consts);
+        delete ctx;
+        return hip_fail(e, "pmx_ctx_create: device setup");
+    }
+
+    DevConfig &d = ctx->dev;
+    d.consts = ctx->d_consts;
+    d.n_const_words = (uint32_t)words;
+    d.rate = cfg->rate;
+    d.capacity = cfg->capacity;
+    d.half_full = cfg->full_rounds / 2;
+    d.partial_rounds = cfg->partial_rounds;
+    d.total_rounds = (uint32_t)rounds;
+    d.alpha_lo = (uint32_t)cfg->alpha;
+    d.alpha_hi = (uint32_t)(cfg->alpha >> 32);
+    std::memcpy(d.p, f.p.l, 32);
+    d.inv32 = (uint32_t)f.inv;
+    std::memcpy(d.one, f.r.l, 32);
+    *out = ctx;
+    return PMX_OK;
+}
+
+extern "C" int pmx_ctx_destroy(pmx_ctx *ctx) {
+    if (!ctx) return PMX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    for (int i = 0; i < 4; ++i)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->d_consts) (void)hipFree(ctx->d_consts);
+    delete ctx;
+    return PMX_OK;
+}
+
+extern "C" int pmx_ctx_width(const pmx_ctx *ctx) { return ctx ? (int)ctx->t : 0; }
+
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+// ---- permutation ---------------------------------------------------------------------------------
+extern "C" int pmx_permute_batch_dev(pmx_ctx *ctx, uint64_t *d_states, size_t n, void *stream) {
+    if (!ctx || (!d_states && n)) return set_error(PMX_ERR_ARG, "pmx_permute_batch_dev: null pointer");
+    if (n == 0) return PMX_OK;
+    if (!aligned16(d_states)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
+    int rc = ctx_bind(ctx);
+    if (rc) return rc;
+    PMX_HIP(launch_permute(ctx->dev, ctx->t, d_states, n, (hipStream_t)stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n) {
+    if (!ctx || (!states && n)) return set_error(PMX_ERR_ARG, "pmx_permute_batch: null pointer");
+    if (n == 0) return PMX_OK;
+    int rc = ctx_bind(ctx);
+    if (rc) return rc;
+    const size_t bytes = n * ctx->t * 32;
+    void *d = nullptr;
+    if ((rc = ctx_scratch(ctx, 0, bytes, &d))) return rc;
+    PMX_HIP(hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pmx_permute_batch_dev(ctx, (uint64_t *)d, n, ctx->stream))) return rc;
+    PMX_HIP(hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+// ---- hash ----------------------------------------------------------------------------------------
+extern "C" int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64_t *d_out, size_t out_len,
+                                  size_t n, void *stream) {
+    if (!ctx || (!d_in && n && in_len) || (!d_out && n && out_len)) return set_error(PMX_ERR_ARG, "pmx_hash_batch_dev: null pointer");
+    if (n == 0) return PMX_OK;
+    if (!aligned16(d_in) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    int rc = ctx_bind(ctx);
+    if (rc) return rc;
+    PMX_HIP(launch_hash(ctx->dev, ctx->t, d_in, in_len, d_out, out_len, n, (hipStream_t)stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n) {
+    if (!ctx || (!in && n && in_len) || (!out && n && out_len)) return set_error(PMX_ERR_ARG, "pmx_hash_batch: null pointer");
+    if (n == 0) return PMX_OK;
+    int rc = ctx_bind(ctx);
+    if (rc) return rc;
+    const size_t in_bytes = n * in_len * 32, out_bytes = n * out_len * 32;
+    void *d_in = nullptr, *d_out = nullptr;
+    if ((rc = ctx_scratch(ctx, 0, in_bytes, &d_in))) return rc;
+    if ((rc = ctx_scratch(ctx, 1, out_bytes, &d_out))) return rc;
+    if (in_bytes) PMX_HIP(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pmx_hash_batch_dev(ctx, (const uint64_t *)d_in, in_len, (uint64_t *)d_out, out_len, n, ctx->stream))) return rc;
+    if (out_bytes) PMX_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+// ---- duplex sponge driver ------------------------------------------------------------------------
+extern "C" int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_tag, uint32_t *d_index,
+                                           const uint64_t *d_in, size_t in_len, size_t n, void *stream) {
+    if (!ctx || ((!d_states || !d_tag || !d_index) && n) || (!d_in && n && in_len))
+        return set_error(PMX_ERR_ARG, "pmx_sponge_absorb_batch_dev: null pointer");
+    if (n == 0 || in_len == 0) return PMX_OK;  // absorbing an empty input changes nothing (mod.rs:234-236)
+    if (!aligned16(d_states) || !aligned16(d_in)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    int rc = ctx_bind(ctx);
+    if (rc) return rc;
+    PMX_HIP(launch_absorb(ctx->dev, ctx->t, d_states, d_tag, d_index, d_in, in_len, n, (hipStream_t)stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_tag, uint32_t *d_index,
+                                            uint64_t *d_out, size_t out_len, size_t n, void *stream) {
+    if (!ctx || ((!d_states || !d_tag || !d_index) && n) || (!d_out && n && out_len))
+        return set_error(PMX_ERR_ARG, "pmx_sponge_squeeze_batch_dev: null pointer");
+    if (n == 0) return PMX_OK;
+    if (!aligned16(d_states) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    int rc = ctx_bind(ctx);
+    if (rc) return rc;
+    PMX_HIP(launch_squeeze(ctx->dev, ctx->t, d_states, d_tag, d_index, d_out, out_len, n, (hipStream_t)stream));
+    return PMX_OK;
+}
+
+static int check_modes(const pmx_ctx *ctx, const uint32_t *tag, const uint32_t *index, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        if (tag[i] > PMX_MODE_SQUEEZING) return set_error(PMX_ERR_ARG, "sponge %zu: mode tag %u is neither Absorbing nor Squeezing", i, tag[i]);
+        if (index[i] > ctx->dev.rate) return set_error(PMX_ERR_ARG, "sponge %zu: mode index %u > rate %u", i, index[i], ctx->dev.rate);
+    }
+    return PMX_OK;
+}
+
+static int sponge_host(pmx_ctx *ctx, uint64_t *states, uint32_t *tag, uint32_t *index, const uint64_t *in, uint64_t *out,
+                       size_t len, size_t n, bool absorb) {
+    if (!ctx || ((!states || !tag || !index) && n)) return set_error(PMX_ERR_ARG, "pmx_sponge_*_batch: null pointer");
+    if (n == 0) return PMX_OK;
+    if (absorb && len == 0) return PMX_OK;
+    if ((absorb && !in) || (!absorb && !out && len)) return set_error(PMX_ERR_ARG, "pmx_sponge_*_batch: null data pointer");
+    int rc = check_modes(ctx, tag, index, n);
+    if (rc) return rc;
+    if ((rc = ctx_bind(ctx))) return rc;
+    const size_t st_bytes = n * ctx->t * 32, io_bytes = n * len * 32;
+    void *d_st = nullptr, *d_io = nullptr, *d_tag = nullptr, *d_idx = nullptr;
+    if ((rc = ctx_scratch(ctx, 0, st_bytes, &d_st))) return rc;
+    if ((rc = ctx_scratch(ctx, 1, io_bytes, &d_io))) return rc;
+    if ((rc = ctx_scratch(ctx, 2, n * 4, &d_tag))) return rc;
+    if ((rc = ctx_scratch(ctx, 3, n * 4, &d_idx))) return rc;
+    PMX_HIP(hipMemcpyAsync(d_st, states, st_bytes, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_tag, tag, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_idx, index, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (absorb) {
+        PMX_HIP(hipMemcpyAsync(d_io, in, io_bytes, hipMemcpyHostToDevice, ctx->stream));
+        rc = pmx_sponge_absorb_batch_dev(ctx, (uint64_t *)d_st, (uint32_t *)d_tag, (uint32_t *)d_idx, (const uint64_t *)d_io, len, n, ctx->stream);
+    } else {
+        rc = pmx_sponge_squeeze_batch_dev(ctx, (uint64_t *)d_st, (uint32_t *)d_tag, (uint32_t *)d_idx, (uint64_t *)d_io, len, n, ctx->stream);
+    }
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(states, d_st, st_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(tag, d_tag, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(index, d_idx, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!absorb && io_bytes) PMX_HIP(hipMemcpyAsync(out, d_io, io_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_sponge_absorb_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
+                                       const uint64_t *in, size_t in_len, size_t n) {
+    return sponge_host(ctx, states, mode_tag, mode_index, in, nullptr, in_len, n, true);
+}
+
+extern "C" int pmx_sponge_squeeze_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
+                                        uint64_t *out, size_t out_len, size_t n) {
+    return sponge_host(ctx, states, mode_tag, mode_index, nullptr, out, out_len, n, false);
+}
+
+// ---- Merkle 2-to-1 -------------------------------------------------------------------------------
+extern "C" int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_leaves, void *stream) {
+    if (!ctx || !d_nodes) return set_error(PMX_ERR_ARG, "pmx_merkle_2to1_dev: null pointer");
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two");
+    if (ctx->dev.rate < 2) return set_error(PMX_ERR_CONFIG, "2-to-1 compression needs rate >= 2");
+    size_t src = 0, width = n_leaves;
+    while (width > 1) {  // one level: parents[i] = H(children[2i], children[2i+1]); rows of 2 elements in, 1 out
+        int rc = pmx_hash_batch_dev(ctx, d_nodes + src * 4, 2, d_nodes + (src + width) * 4, 1, width / 2, stream);
+        if (rc) return rc;
+        src += width;
+        width /= 2;
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint64_t *nodes, uint64_t *root) {
+    if (!ctx || !leaves) return set_error(PMX_ERR_ARG, "pmx_merkle_2to1: null pointer");
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two");
+    int rc = ctx_bind(ctx);
+    if (rc) return rc;
+    const size_t n_nodes = 2 * n_leaves - 1;
+    void *d = nullptr;
+    if ((rc = ctx_scratch(ctx, 0, n_nodes * 32, &d))) return rc;
+    PMX_HIP(hipMemcpyAsync(d, leaves, n_leaves * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pmx_merkle_2to1_dev(ctx, (uint64_t *)d, n_leaves, ctx->stream))) return rc;
+    if (nodes) PMX_HIP(hipMemcpyAsync(nodes, d, n_nodes * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (root) PMX_HIP(hipMemcpyAsync(root, (uint64_t *)d + (n_nodes - 1) * 4, 32, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}

@@ -1,0 +1,113 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every declared symbol, and its
+host-only pieces (parameter generation, Montgomery conversion, validation) agree with the oracle.
+No kernel runs here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sponge_amd as S
+from sponge_amd import _lib, synth
+from oracle import kats as K
+from oracle import poseidon_oracle as O
+
+from helpers import golden, oracle_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "poseidon_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pmx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 20
+    lib = _lib.lib()
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.pmx_abi_version() == 1
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    if _lib.lib().pmx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg = S.poseidon_config_from_lfsr(S.BLS12_381_FR, 2, 5, 8, 31)
+    with pytest.raises(S.PmxError) as ei:
+        cfg.context(0)
+    assert ei.value.code == _lib.PMX_ERR_HIP
+    assert "no CPU fallback" in str(ei.value)
+
+
+@pytest.mark.parametrize("field,ofield", [(S.BLS12_381_FR, O.BLS12_381_FR), (S.BN254_FR, O.BN254_FR)])
+def test_montgomery_constants_and_conversion(field, ofield):
+    inv, r, r2 = field.mont_constants()
+    mc = O.mont_constants(ofield)
+    assert inv == mc["inv"]
+    assert [int(x) for x in r] == O.to_limbs(mc["r"])
+    assert [int(x) for x in r2] == O.to_limbs(mc["r2"])
+    vals = [0, 1, 2, ofield - 1, ofield // 3, 1 << 200]
+    m = field.from_ints(vals)
+    assert [O.from_limbs([int(x) for x in row]) for row in m] == [O.to_mont(v, ofield) for v in vals]
+    assert field.to_ints(m) == vals
+
+
+def test_unreduced_element_is_rejected():
+    f = S.BLS12_381_FR
+    bad = np.array([[0xFFFFFFFFFFFFFFFF] * 4], dtype=np.uint64)
+    with pytest.raises(S.PmxError):
+        f.to_ints(bad)
+
+
+def test_lfsr_reference_kats_through_the_library():
+    # src/poseidon/grain_lfsr.rs:197-213 and src/poseidon/traits.rs:163-358, via pmx_find_poseidon_ark_and_mds
+    f = S.BLS12_381_FR
+    for (rate, weights), (ark00, mds00) in K.DEFAULT_PARAMS_BLS12_381.items():
+        cfg = S.get_default_poseidon_parameters(f, rate, weights)
+        assert cfg.capacity == 1 and cfg.rate == rate
+        assert f.to_ints(cfg.ark[0, 0:1]) == [ark00]
+        assert f.to_ints(cfg.mds[0, 0:1]) == [mds00]
+    cfg = S.get_default_poseidon_parameters(f, 2, False)
+    assert f.to_ints(cfg.ark[0, 0:2]) == K.GRAIN_LFSR_255_3_8_31
+    assert (cfg.alpha, cfg.full_rounds, cfg.partial_rounds) == (17, 8, 31)
+    assert S.get_default_poseidon_parameters(f, 9, False) is None
+    assert S.get_default_poseidon_parameters(S.BN254_FR, 2, False) is None
+
+
+@pytest.mark.parametrize("name", sorted(golden("config_pins.json")))
+def test_generated_constants_equal_oracle(name):
+    pin = golden("config_pins.json")[name]
+    f = S.FIELDS[pin["field"]]
+    cfg = S.poseidon_config_from_lfsr(f, pin["rate"], pin["alpha"], pin["full_rounds"], pin["partial_rounds"])
+    ocfg = oracle_config(name)
+    assert f.to_ints(cfg.ark.reshape(-1, 4)) == [v for row in ocfg.ark for v in row]
+    assert f.to_ints(cfg.mds.reshape(-1, 4)) == [v for row in ocfg.mds for v in row]
+    assert f.to_ints(cfg.ark[0, 0:1]) == [int(pin["ark_first"], 16)]
+    assert f.to_ints(cfg.mds[-1, -1:]) == [int(pin["mds_last"], 16)]
+
+
+def test_parameter_errors():
+    f = S.BLS12_381_FR
+    with pytest.raises(S.PmxError):   # prime_bits must equal the modulus bit size (grain_lfsr.rs:112)
+        S.find_poseidon_ark_and_mds(f, 254, 2, 8, 31, 0)
+    with pytest.raises(AssertionError):   # PoseidonConfig::new asserts, mod.rs:196-203
+        S.PoseidonConfig(f, 8, 31, 5, np.zeros((3, 3, 4), np.uint64), np.zeros((38, 3, 4), np.uint64), 2, 1)
+    with pytest.raises(AssertionError):
+        S.PoseidonConfig(f, 8, 31, 5, np.zeros((3, 2, 4), np.uint64), np.zeros((39, 3, 4), np.uint64), 2, 1)
+
+
+def test_synthetic_batches_are_reduced_and_shardable():
+    for f in (S.BLS12_381_FR, S.BN254_FR):
+        a = synth.random_elements(f, 1000, seed=0x5EED0001)
+        vals = [O.from_limbs([int(x) for x in row]) for row in a]
+        assert all(v < f.modulus for v in vals)
+        assert len(set(vals)) == 1000
+        b = synth.random_elements(f, 400, seed=0x5EED0001, offset=600)
+        assert np.array_equal(a[600:], b)
+    # splitmix64 known answers (seed 0 stream: 0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4)
+    out = synth.splitmix64(np.array([0, 1], dtype=np.uint64))
+    assert [int(x) for x in out] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4]

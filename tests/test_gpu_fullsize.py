@@ -1,0 +1,88 @@
+"""BASELINE.json's full sizes on the GPU: the whole batch against the C restatement (all host cores) where
+that takes seconds, plus size-independent properties (position independence, 2-to-1 == permute of
+[0,l,r], subtree decomposition of the Merkle root)."""
+import numpy as np
+import pytest
+import torch
+
+import sponge_amd as S
+from sponge_amd import synth
+
+from gpu_helpers import c_oracle, product_config
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_tensor(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(a.view(np.int64)).to("cuda:0")
+
+
+def to_numpy(t: torch.Tensor) -> np.ndarray:
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_c2_full_batch_2e20_bls_t3_alpha5():
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    n = 1 << 20
+    states = synth.random_elements(cfg.field, n * 3, seed=0x5EED0002).reshape(n, 3, 4)
+    d = dev_tensor(states)
+    ctx = cfg.context()
+    ctx.permute_batch_dev(d.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = to_numpy(d).reshape(n, 3, 4)
+    want = c_oracle(name).permute_batch(states, threads=0)
+    assert np.array_equal(got, want)
+    # position independence: the reversed batch gives the reversed result
+    d2 = dev_tensor(np.ascontiguousarray(states[::-1]))
+    ctx.permute_batch_dev(d2.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_numpy(d2).reshape(n, 3, 4)[::-1], got)
+
+
+def test_c3_full_batch_2e18_bn254_t9_alpha5():
+    name = "bn254_t9_a5_8_57"
+    cfg = product_config(name)
+    n = 1 << 18
+    states = synth.random_elements(cfg.field, n * 9, seed=0x5EED0003).reshape(n, 9, 4)
+    d = dev_tensor(states)
+    cfg.context().permute_batch_dev(d.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = to_numpy(d).reshape(n, 9, 4)
+    # the restatement needs ~0.25 ms per t=9 permutation per core: check a strided 1/16 sample in full
+    idx = np.arange(0, n, 16)
+    want = c_oracle(name).permute_batch(np.ascontiguousarray(states[idx]), threads=0)
+    assert np.array_equal(got[idx], want)
+
+
+def test_c5_merkle_2e20_leaves_root_and_decomposition():
+    """Level-by-level tree on the GPU; root == root rebuilt from 8 subtree roots (the multi-GPU split);
+    lowest level == 2-to-1 compression == permute([0, l, r])[capacity] checked against the restatement."""
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    ctx = cfg.context()
+    m = 1 << 20
+    leaves = synth.random_elements(cfg.field, m, seed=0x5EED0005)
+    nodes = torch.zeros((2 * m - 1, 4), dtype=torch.int64, device="cuda:0")
+    nodes[:m] = dev_tensor(leaves)
+    ctx.merkle_2to1_dev(nodes.data_ptr(), m, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = to_numpy(nodes)
+    # first level against the restatement, in full
+    want_l1 = c_oracle(name).hash_batch(leaves.reshape(m // 2, 2, 4), 2, 1, threads=0).reshape(m // 2, 4)
+    assert np.array_equal(got[m:m + m // 2], want_l1)
+    # 2-to-1 == permute([0,l,r])[1] on a sample
+    st = np.zeros((1024, 3, 4), dtype=np.uint64)
+    st[:, 1:, :] = leaves[:2048].reshape(1024, 2, 4)
+    assert np.array_equal(ctx.permute_batch(st)[:, 1, :], got[m:m + 1024])
+    # subtree decomposition: 8 shards of 2^17 leaves -> 8 roots -> 3 more levels
+    sub_roots = []
+    for g in range(8):
+        _, r = ctx.merkle_2to1(leaves[g * (m // 8):(g + 1) * (m // 8)], want_nodes=False)
+        sub_roots.append(r)
+    _, top = ctx.merkle_2to1(np.stack(sub_roots), want_nodes=False)
+    assert np.array_equal(top, got[-1])
+    # upper 10 levels against the restatement (1023 compressions)
+    lvl10 = got[2 * m - 1 - 2047: 2 * m - 1 - 1023]      # the level with 1024 nodes
+    want_top = c_oracle(name).merkle(lvl10, threads=0)
+    assert np.array_equal(want_top[-1], got[-1])

@@ -1,0 +1,174 @@
+"""Parity of the HIP path (through the C ABI) with the oracle: golden fixtures, the reference's own KAT,
+seeded random batches against the C restatement, ragged sizes, mixed modes.  Bit-exact: every comparison
+is limb-for-limb equality of Montgomery residues."""
+import numpy as np
+import pytest
+
+import sponge_amd as S
+from sponge_amd import synth
+from oracle import kats as K
+
+from gpu_helpers import c_oracle, ints, product_config
+from helpers import golden, oracle_config
+
+pytestmark = pytest.mark.gpu
+
+ALL_CONFIGS = ["bls_t3_a5_8_31", "bls_t3_a17_8_31", "bls_t4_a5_8_56", "bls_t9_a5_8_57", "bls_t3_a257_8_13",
+               "bn254_t9_a5_8_57", "bn254_t3_a5_8_57", "reference_test_a17_8_29"]
+
+
+def test_poseidon_sponge_consistency():
+    """The reference's own KAT, src/poseidon/mod.rs:376-399, written the way the reference writes it."""
+    Fr = S.BLS12_381_FR
+    sponge_param = S.get_default_poseidon_parameters(Fr, 2, False)
+    sponge = S.PoseidonSponge.new(sponge_param)
+    sponge.absorb(Fr.from_ints([0, 1, 2]))
+    res = sponge.squeeze_native_field_elements(3)
+    assert Fr.to_ints(res) == K.SPONGE_CONSISTENCY_OUTPUT
+    assert sponge.mode == S.DuplexSpongeMode.Squeezing(1)
+
+
+@pytest.mark.parametrize("name", ALL_CONFIGS)
+def test_permute_golden_vectors(name):
+    cfg = product_config(name)
+    f = cfg.field
+    vecs = golden("permute_vectors.json")[name]
+    states = f.from_ints([x for v in vecs for x in ints(v["in"])]).reshape(len(vecs), cfg.t, 4)
+    out = cfg.context().permute_batch(states)
+    assert f.to_ints(out) == [x for v in vecs for x in ints(v["out"])]
+
+
+@pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31", "bn254_t9_a5_8_57", "bls_t4_a5_8_56"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000])
+def test_permute_ragged_batches_vs_c_oracle(name, n):
+    cfg = product_config(name)
+    states = synth.random_elements(cfg.field, n * cfg.t, seed=1234 + n).reshape(n, cfg.t, 4)
+    got = cfg.context().permute_batch(states)
+    want = c_oracle(name).permute_batch(states, threads=0)
+    assert np.array_equal(got, want)
+
+
+def test_permute_empty_batch_is_a_no_op():
+    cfg = product_config("bls_t3_a5_8_31")
+    out = cfg.context().permute_batch(np.zeros((0, 3, 4), dtype=np.uint64))
+    assert out.shape == (0, 3, 4)
+
+
+@pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31", "reference_test_a17_8_29", "bn254_t9_a5_8_57"])
+def test_sponge_traces(name):
+    """Every branch of absorb / squeeze incl. the mod.rs:175 quirk, via the PoseidonSponge mirror."""
+    cfg = product_config(name)
+    f = cfg.field
+    for tname, steps in golden("sponge_traces.json")[name].items():
+        sponge = S.PoseidonSponge.new(cfg)
+        for st in steps:
+            if st["op"] == "absorb":
+                sponge.absorb(f.from_ints(ints(st["in"])))
+            else:
+                out = sponge.squeeze_native_field_elements(st["n"])
+                assert f.to_ints(out) == ints(st["out"]), (name, tname)
+            assert f.to_ints(sponge.state) == ints(st["state"]), (name, tname)
+            assert [sponge.mode.tag, sponge.mode.index] == st["mode"], (name, tname)
+
+
+def test_hash_and_merkle_golden():
+    g = golden("hash_merkle_vectors.json")
+    for name, d in g.items():
+        cfg = product_config(name)
+        f = cfg.field
+        for row in d["hash"]:
+            msg = f.from_ints(ints(row["in"])).reshape(1, row["L"], 4)
+            out = cfg.context().hash_batch(msg, row["L"], row["k"], n=1)
+            assert f.to_ints(out) == ints(row["out"]), (name, row["L"], row["k"])
+    cfg = product_config("bls_t3_a5_8_31")
+    levels = g["bls_t3_a5_8_31"]["merkle16"]
+    nodes, root = cfg.context().merkle_2to1(cfg.field.from_ints(ints(levels[0])))
+    assert cfg.field.to_ints(nodes) == [x for lvl in levels for x in ints(lvl)]
+    assert cfg.field.to_ints(root.reshape(1, 4)) == ints(levels[-1])
+
+
+@pytest.mark.parametrize("name,L,k", [("bls_t3_a5_8_31", 2, 1), ("bls_t3_a5_8_31", 7, 5), ("bls_t3_a17_8_31", 3, 3),
+                                      ("bn254_t9_a5_8_57", 8, 1), ("bn254_t9_a5_8_57", 19, 10), ("bls_t4_a5_8_56", 4, 4)])
+def test_hash_batch_vs_c_oracle(name, L, k):
+    cfg = product_config(name)
+    n = 333
+    msgs = synth.random_elements(cfg.field, n * L, seed=99).reshape(n, L, 4)
+    got = cfg.context().hash_batch(msgs, L, k)
+    want = c_oracle(name).hash_batch(msgs, L, k, threads=0)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bn254_t9_a5_8_57"])
+def test_batch_sponge_with_mixed_modes_vs_c_oracle(name):
+    """n sponges in different modes and positions advance together; each is checked against the C
+    restatement run sponge by sponge."""
+    cfg = product_config(name)
+    cr = c_oracle(name)
+    n, r = 200, cfg.rate
+    rng = np.random.default_rng(5)
+    batch = S.BatchPoseidonSponge.new(cfg, n)
+    batch.state = synth.random_elements(cfg.field, n * cfg.t, seed=7).reshape(n, cfg.t, 4)
+    batch.mode_tag = rng.integers(0, 2, n).astype(np.uint32)
+    batch.mode_index = rng.integers(0, r + 1, n).astype(np.uint32)
+    ref = [(batch.state[i].copy(), int(batch.mode_tag[i]), int(batch.mode_index[i])) for i in range(n)]
+    for (op, length) in [("absorb", r + 1), ("squeeze", r), ("squeeze", 1), ("absorb", 1), ("squeeze", 2 * r + 1)]:
+        if op == "absorb":
+            elems = synth.random_elements(cfg.field, n * length, seed=length).reshape(n, length, 4)
+            batch.absorb(elems)
+            ref = [cr.sponge_absorb(s, m, i, elems[j]) for j, (s, m, i) in enumerate(ref)]
+        else:
+            out = batch.squeeze_native_field_elements(length)
+            nxt = []
+            for j, (s, m, i) in enumerate(ref):
+                s2, m2, i2, o = cr.sponge_squeeze(s, m, i, length)
+                assert np.array_equal(out[j], o), (op, length, j)
+                nxt.append((s2, m2, i2))
+            ref = nxt
+        for j, (s, m, i) in enumerate(ref):
+            assert np.array_equal(batch.state[j], s) and (batch.mode_tag[j], batch.mode_index[j]) == (m, i), (op, j)
+
+
+def test_squeeze_bytes_bits_and_state_roundtrip():
+    """src/poseidon/tests.rs:71-85 (native cast) and the SpongeExt round trip, plus byte/bit truncation."""
+    from oracle import poseidon_oracle as O
+    cfg = product_config("reference_test_a17_8_29")
+    f = cfg.field
+    sponge1 = S.PoseidonSponge.new(cfg)
+    sponge1.absorb(f.from_ints([123456789]))
+    sponge2 = sponge1.clone()
+    assert np.array_equal(sponge1.squeeze_native_field_elements(5), sponge2.squeeze_field_elements(5))
+    sponge3 = S.PoseidonSponge.from_state(sponge1.into_state(), cfg)
+    osp = O.PoseidonSponge(oracle_config("reference_test_a17_8_29"))
+    osp.absorb([123456789])
+    osp.squeeze_native_field_elements(5)
+    a, b = osp.clone(), osp.clone()
+    assert sponge3.squeeze_bytes(100) == a.squeeze_bytes(100, 255)
+    assert sponge1.squeeze_bits(600) == [bool(x) for x in b.squeeze_bits(600, 255)]
+
+
+def test_single_field_element_changes_the_output():
+    """src/poseidon/tests.rs:26-33 single_field_element / :35-43 list_with_constant_size_element."""
+    cfg = product_config("reference_test_a17_8_29")
+    f = cfg.field
+    lst1 = synth.random_elements(f, 1024 * 8, seed=42)
+    lst2 = lst1.copy()
+    lst2[3] = f.from_ints([f.to_ints(lst1[3:4])[0] + 1])[0]
+    out = cfg.context().hash_batch(np.stack([lst1, lst2]), 1024 * 8, 3)
+    assert not np.array_equal(out[0], out[1])
+    want = c_oracle("reference_test_a17_8_29").hash_batch(np.stack([lst1, lst2]), 1024 * 8, 3)
+    assert np.array_equal(out, want)
+
+
+def test_bad_arguments_fail_loudly():
+    cfg = product_config("bls_t3_a5_8_31")
+    ctx = cfg.context()
+    with pytest.raises(S.PmxError):      # not a power of two
+        ctx.merkle_2to1(np.zeros((3, 4), dtype=np.uint64))
+    b = S.BatchPoseidonSponge.new(cfg, 2)
+    b.mode_index[1] = 7                  # > rate
+    with pytest.raises(S.PmxError):
+        b.squeeze_native_field_elements(1)
+    b.mode_index[1] = 0
+    b.mode_tag[0] = 9
+    with pytest.raises(S.PmxError):
+        b.absorb(np.zeros((2, 1, 4), dtype=np.uint64))
