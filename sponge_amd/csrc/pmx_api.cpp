@@ -6,11 +6,12 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/poseidon_mi355x.h"
-#include "pmx_host_field.hpp"
 #include "pmx_internal.hpp"
+#include "pmx_prepare.hpp"
 #include "pmx_launch.hpp"
 
 namespace pmx {
@@ -81,23 +82,10 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     if (!cfg || !out) return set_error(PMX_ERR_ARG, "pmx_ctx_create: null pointer");
     *out = nullptr;
     if (!cfg->ark || !cfg->mds) return set_error(PMX_ERR_ARG, "pmx_ctx_create: null ark/mds");
-    const uint64_t t64 = (uint64_t)cfg->rate + cfg->capacity;
-    if (cfg->rate == 0) return set_error(PMX_ERR_CONFIG, "rate must be >= 1");
-    if (t64 > PMX_MAX_WIDTH) return set_error(PMX_ERR_UNSUPPORTED, "width %llu > PMX_MAX_WIDTH %d", (unsigned long long)t64, PMX_MAX_WIDTH);
-    if (cfg->full_rounds % 2) return set_error(PMX_ERR_CONFIG, "full_rounds must be even (RF/2 rounds on each side, mod.rs:96)");
-    const uint64_t rounds = (uint64_t)cfg->full_rounds + cfg->partial_rounds;
-    if (rounds == 0 || rounds > 4096) return set_error(PMX_ERR_CONFIG, "round count %llu out of range", (unsigned long long)rounds);
-    HostField f;
-    if (!f.init(cfg->modulus)) return set_error(PMX_ERR_CONFIG, "modulus must be odd and > 2");
-    const uint32_t t = (uint32_t)t64;
-    const size_t n_ark = (size_t)rounds * t, n_mds = (size_t)t * t;
-    // every constant must be a reduced residue (ark-ff's invariant for Fp values)
-    for (size_t k = 0; k < n_ark + n_mds; ++k) {
-        const uint64_t *src = k < n_ark ? cfg->ark + 4 * k : cfg->mds + 4 * (k - n_ark);
-        U256 v;
-        std::memcpy(v.l, src, sizeof v.l);
-        if (u256_geq(v, f.p)) return set_error(PMX_ERR_CONFIG, "%s constant %zu is not reduced", k < n_ark ? "ark" : "mds", k < n_ark ? k : k - n_ark);
-    }
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);   // the asserts of PoseidonConfig::new + limits of this build
+    if (rc) return set_error(rc, "%s", err.c_str());
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return set_error(PMX_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(e));
@@ -105,38 +93,28 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
 
     pmx_ctx *ctx = new (std::nothrow) pmx_ctx();
     if (!ctx) return set_error(PMX_ERR_ARG, "out of host memory");
-    std::memset(ctx, 0, sizeof *ctx);
+    std::memset((void *)ctx, 0, sizeof *ctx);
     ctx->device = device;
-    ctx->t = t;
-    int rc = ctx_bind(ctx);
+    ctx->t = pp.t;
+    rc = ctx_bind(ctx);
     if (rc) { delete ctx; return rc; }
 
-    const size_t words = (n_ark + n_mds) * 8;
-    std::vector<uint32_t> h(words);
-    std::memcpy(h.data(), cfg->ark, n_ark * 32);
-    std::memcpy(h.data() + n_ark * 8, cfg->mds, n_mds * 32);
-    e = hipMalloc((void **)&ctx->d_consts, words * 4);
-    if (e == hipSuccess) e = hipMemcpy(ctx->d_consts, h.data(), words * 4, hipMemcpyHostToDevice);
+    const size_t bytes = pp.consts.size() * 4;
+    e = hipMalloc((void **)&ctx->d_consts, bytes);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_consts, pp.consts.data(), bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         if (ctx->d_consts) (void)hipFree(ctx->d_consts);
         delete ctx;
         return hip_fail(e, "pmx_ctx_create: device setup");
     }
-
     DevConfig &d = ctx->dev;
     d.consts = ctx->d_consts;
-    d.n_const_words = (uint32_t)words;
-    d.rate = cfg->rate;
-    d.capacity = cfg->capacity;
-    d.half_full = cfg->full_rounds / 2;
-    d.partial_rounds = cfg->partial_rounds;
-    d.total_rounds = (uint32_t)rounds;
-    d.alpha_lo = (uint32_t)cfg->alpha;
-    d.alpha_hi = (uint32_t)(cfg->alpha >> 32);
-    std::memcpy(d.p, f.p.l, 32);
-    d.inv32 = (uint32_t)f.inv;
-    std::memcpy(d.one, f.r.l, 32);
+    d.n_const_words = (uint32_t)pp.consts.size();
+    d.mds_offset = (uint32_t)pp.mds_offset;
+    d.rounds = pp.c;
+    d.field = pp.f;
+    d.one = pp.one;
     *out = ctx;
     return PMX_OK;
 }
@@ -242,7 +220,7 @@ extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, ui
 static int check_modes(const pmx_ctx *ctx, const uint32_t *tag, const uint32_t *index, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         if (tag[i] > PMX_MODE_SQUEEZING) return set_error(PMX_ERR_ARG, "sponge %zu: mode tag %u is neither Absorbing nor Squeezing", i, tag[i]);
-        if (index[i] > ctx->dev.rate) return set_error(PMX_ERR_ARG, "sponge %zu: mode index %u > rate %u", i, index[i], ctx->dev.rate);
+        if (index[i] > ctx->dev.rounds.rate) return set_error(PMX_ERR_ARG, "sponge %zu: mode index %u > rate %u", i, index[i], ctx->dev.rounds.rate);
     }
     return PMX_OK;
 }
@@ -294,7 +272,7 @@ extern "C" int pmx_sponge_squeeze_batch(pmx_ctx *ctx, uint64_t *states, uint32_t
 extern "C" int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_leaves, void *stream) {
     if (!ctx || !d_nodes) return set_error(PMX_ERR_ARG, "pmx_merkle_2to1_dev: null pointer");
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two");
-    if (ctx->dev.rate < 2) return set_error(PMX_ERR_CONFIG, "2-to-1 compression needs rate >= 2");
+    if (ctx->dev.rounds.rate < 2) return set_error(PMX_ERR_CONFIG, "2-to-1 compression needs rate >= 2");
     size_t src = 0, width = n_leaves;
     while (width > 1) {  // one level: parents[i] = H(children[2i], children[2i+1]); rows of 2 elements in, 1 out
         int rc = pmx_hash_batch_dev(ctx, d_nodes + src * 4, 2, d_nodes + (src + width) * 4, 1, width / 2, stream);

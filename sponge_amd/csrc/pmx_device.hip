@@ -3,11 +3,13 @@
 // Work decomposition: one lane owns one sponge state; a wavefront owns 64 contiguous states of the
 // [n][t][4]u64 batch.  State I/O goes through LDS so that every global access is a full-width
 // 16-B-per-lane contiguous stream, whatever t is.  Round constants and the MDS matrix are wave-uniform.
+// Arithmetic: pmx_field.hpp (unsaturated 9 x 29-bit Montgomery form); round schedule: pmx_permute.hpp.
 //
 // Two engines implement the same interface:
-//   RegEngine<T, ALPHA>  state in VGPRs, loops over elements unrolled, ARK+MDS staged in LDS.   (t = 3)
-//   LdsEngine<ALPHA>     any width at run time: state kept in LDS as [element][lane] (conflict-free
-//                        16-B accesses), element loops rolled, constants through the scalar cache.
+//   RegEngine<T, ALPHA>  state in VGPRs, element loops unrolled, ARK+MDS staged in LDS.            (t = 3)
+//   LdsEngine<ALPHA>     any width at run time: state kept in LDS as [element][limb][lane]
+//                        (conflict-free 4-byte accesses), element loops rolled, constants through the
+//                        scalar cache.
 //
 // Reference semantics implemented here (file:line in /root/reference):
 //   permute        src/poseidon/mod.rs:95-118   (apply_ark :76-80, apply_s_box :63-74, apply_mds :82-93)
@@ -19,66 +21,51 @@
 #include "pmx_field.hpp"
 #include "pmx_internal.hpp"
 #include "pmx_launch.hpp"
+#include "pmx_permute.hpp"
+
+#ifndef PMX_CONSTS_IN_LDS
+#define PMX_CONSTS_IN_LDS 1   // RegEngine: 1 = stage ARK/MDS in LDS (broadcast reads), 0 = scalar loads from global
+#endif
 
 namespace pmx {
 
 extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 
-__device__ __forceinline__ void init_field(FieldRt &f, const DevConfig &c) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f.p[i] = c.p[i];
-    f.inv32 = c.inv32;
-}
-
-// The wave-uniform scalars of a config, copied out of the kernel-argument block by value so that they
-// stay in SGPRs (holding a reference to the by-value kernel argument sends it to scratch).
-struct Rounds {
-    const uint32_t *consts;
-    uint32_t rate, capacity, half_full, partial_rounds, total_rounds;
-    uint64_t alpha;
-    __device__ __forceinline__ explicit Rounds(const DevConfig &d)
-        : consts(d.consts), rate(d.rate), capacity(d.capacity), half_full(d.half_full),
-          partial_rounds(d.partial_rounds), total_rounds(d.total_rounds),
-          alpha(((uint64_t)d.alpha_hi << 32) | d.alpha_lo) {}
-};
-
-__device__ __forceinline__ bool is_full_round(uint32_t r, const Rounds &c) {
-    return r < c.half_full || r >= c.half_full + c.partial_rounds;
-}
-
 // ------------------------------------------------------------------------------------------------
-// RegEngine: t known at compile time, state in registers.
-// LDS: [constants: n_const_words u32][staging: kThreads * T * 2 uint4]
+// RegEngine: t known at compile time, state in registers (internal field form).
+// LDS: [constants: n_const_words u32, rounded up to 16 B][staging: kThreads * T * 2 uint4]
 // ------------------------------------------------------------------------------------------------
 template <int T, int ALPHA>
 struct RegEngine {
     static constexpr int kThreads = 256;
-    static constexpr int kChunks = 2 * T;  // 16-byte chunks per state
+    static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
 
     Fe s[T];
     Rounds c;
     FieldRt f;
-    const uint32_t *lconst;  // LDS copy of ark|mds
-    uint4 *stage;            // LDS staging for coalesced state I/O
     Fe one;
+    const uint32_t *ark;  // constants (LDS or global)
+    const uint32_t *mds;
+    uint4 *stage;         // LDS staging for coalesced state I/O
 
-    static size_t lds_bytes(const DevConfig &c, uint32_t /*t*/) {
-        return (size_t)((c.n_const_words + 3) / 4) * 16 + (size_t)kThreads * kChunks * 16;
+    static size_t lds_bytes(const DevConfig &d, uint32_t /*t*/) {
+        return (PMX_CONSTS_IN_LDS ? (size_t)((d.n_const_words + 3) / 4) * 16 : 0) + (size_t)kThreads * kChunks * 16;
     }
 
-    __device__ __forceinline__ explicit RegEngine(const DevConfig &cfg) : c(cfg) {
-        init_field(f, cfg);
-        const uint32_t const_chunks = (cfg.n_const_words + 3) / 4;
-        const uint4 *g = reinterpret_cast<const uint4 *>(cfg.consts);
+    __device__ __forceinline__ explicit RegEngine(const DevConfig &d) : c(d.rounds), f(d.field), one(d.one) {
+#if PMX_CONSTS_IN_LDS
+        const uint32_t const_chunks = (d.n_const_words + 3) / 4;
+        const uint4 *g = reinterpret_cast<const uint4 *>(d.consts);
         for (uint32_t q = threadIdx.x; q < const_chunks; q += kThreads) pmx_lds[q] = g[q];
-        lconst = reinterpret_cast<const uint32_t *>(pmx_lds);
+        ark = reinterpret_cast<const uint32_t *>(pmx_lds);
         stage = pmx_lds + const_chunks;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) one.l[i] = cfg.one[i];
         __syncthreads();
+#else
+        ark = d.consts;
+        stage = pmx_lds;
+#endif
+        mds = ark + d.mds_offset;
     }
-
-    __device__ __forceinline__ uint32_t width() const { return T; }
 
     __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -101,7 +88,7 @@ struct RegEngine {
         if (threadIdx.x < valid) {
 #pragma unroll
             for (int i = 0; i < T; ++i)
-                s[i] = fe_from_u4(stage[threadIdx.x * kChunks + 2 * i], stage[threadIdx.x * kChunks + 2 * i + 1]);
+                s[i] = fe_from_abi(abi_from_u4(stage[threadIdx.x * kChunks + 2 * i], stage[threadIdx.x * kChunks + 2 * i + 1]), f);
         } else {
             zero();
         }
@@ -115,8 +102,9 @@ struct RegEngine {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-            stage[threadIdx.x * kChunks + 2 * i] = fe_lo(s[i]);
-            stage[threadIdx.x * kChunks + 2 * i + 1] = fe_hi(s[i]);
+            const Abi a = fe_to_abi(s[i], f);
+            stage[threadIdx.x * kChunks + 2 * i] = abi_lo(a);
+            stage[threadIdx.x * kChunks + 2 * i + 1] = abi_hi(a);
         }
         __syncthreads();
 #pragma unroll
@@ -132,7 +120,7 @@ struct RegEngine {
 #pragma unroll
         for (int k = 1; k < T; ++k) {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) r.l[w] = (i == (uint32_t)k) ? s[k].l[w] : r.l[w];
+            for (int w = 0; w < kN; ++w) r.l[w] = (i == (uint32_t)k) ? s[k].l[w] : r.l[w];
         }
         return r;
     }
@@ -140,40 +128,18 @@ struct RegEngine {
 #pragma unroll
         for (int k = 0; k < T; ++k) {
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s[k].l[w] = (i == (uint32_t)k) ? v.l[w] : s[k].l[w];
+            for (int w = 0; w < kN; ++w) s[k].l[w] = (i == (uint32_t)k) ? v.l[w] : s[k].l[w];
         }
     }
 
-    __device__ __forceinline__ void permute() {
-        const uint32_t *ark = lconst;
-        const uint32_t *mds = lconst + (size_t)c.total_rounds * T * 8;
-        const uint64_t alpha = c.alpha;
-        for (uint32_t r = 0; r < c.total_rounds; ++r) {
-#pragma unroll
-            for (int i = 0; i < T; ++i) s[i] = fe_add(s[i], fe_load(ark + ((size_t)r * T + i) * 8), f);
-            s[0] = fe_sbox<ALPHA>(s[0], alpha, one, f);
-            if (is_full_round(r, c)) {
-#pragma unroll
-                for (int i = 1; i < T; ++i) s[i] = fe_sbox<ALPHA>(s[i], alpha, one, f);
-            }
-            Fe ns[T];
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                Fe acc = fe_mul(s[0], fe_load(mds + ((size_t)i * T) * 8), f);
-#pragma unroll
-                for (int j = 1; j < T; ++j) acc = fe_add(acc, fe_mul(s[j], fe_load(mds + ((size_t)i * T + j) * 8), f), f);
-                ns[i] = acc;
-            }
-#pragma unroll
-            for (int i = 0; i < T; ++i) s[i] = ns[i];
-        }
-    }
+    __device__ __forceinline__ void permute() { permute_dense<T, ALPHA>(s, ark, mds, c, one, f); }
 };
 
 // ------------------------------------------------------------------------------------------------
 // LdsEngine: width is a run-time value.  Each wave keeps its 64 states in LDS as
-// cur[(element*2 + half) * 64 + lane] (16-byte granules), with a second buffer for the MDS output.
-// LDS: per wave 2 buffers x t x 2 x 64 uint4  (t KiB each).
+// cur[(element * 9 + limb) * 64 + lane] u32, with a second buffer for the MDS output.
+// LDS per wave: 2 buffers x t x 9 x 64 x 4 B  (2.25 t KiB each); the second buffer doubles as the
+// staging area of the coalesced ABI load/store (t x 32 B x 64 fits one buffer).
 // ------------------------------------------------------------------------------------------------
 template <int ALPHA>
 struct LdsEngine {
@@ -181,53 +147,68 @@ struct LdsEngine {
 
     Rounds c;
     FieldRt f;
+    Fe one;
+    const uint32_t *ark;
+    const uint32_t *mds;
     uint32_t t;
     uint32_t lane;
-    uint4 *cur;
-    uint4 *nxt;
-    Fe one;
+    uint32_t *cur;
+    uint32_t *nxt;
 
-    static size_t lds_bytes(const DevConfig & /*c*/, uint32_t t) {
-        return (size_t)(kThreads / 64) * 2 * t * 2 * 64 * 16;
-    }
+    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t t) { return (size_t)(kThreads / 64) * 2 * t * kN * 64 * 4; }
 
-    __device__ __forceinline__ explicit LdsEngine(const DevConfig &cfg) : c(cfg) {
-        init_field(f, cfg);
+    __device__ __forceinline__ explicit LdsEngine(const DevConfig &d) : c(d.rounds), f(d.field), one(d.one) {
+        ark = d.consts;
+        mds = d.consts + d.mds_offset;
         t = c.rate + c.capacity;
         lane = threadIdx.x & 63;
         const uint32_t wave = threadIdx.x >> 6;
-        cur = pmx_lds + (size_t)wave * 2 * (t * 2 * 64);
-        nxt = cur + t * 2 * 64;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) one.l[i] = cfg.one[i];
+        cur = reinterpret_cast<uint32_t *>(pmx_lds) + (size_t)wave * 2 * (t * kN * 64);
+        nxt = cur + t * kN * 64;
     }
 
-    __device__ __forceinline__ uint32_t width() const { return t; }
-
-    __device__ __forceinline__ Fe get(uint32_t i) const { return fe_from_u4(cur[(i * 2) * 64 + lane], cur[(i * 2 + 1) * 64 + lane]); }
+    __device__ __forceinline__ Fe get(uint32_t i) const {
+        Fe r;
+#pragma unroll
+        for (int w = 0; w < kN; ++w) r.l[w] = cur[(i * kN + w) * 64 + lane];
+        return r;
+    }
     __device__ __forceinline__ void set(uint32_t i, const Fe &v) {
-        cur[(i * 2) * 64 + lane] = fe_lo(v);
-        cur[(i * 2 + 1) * 64 + lane] = fe_hi(v);
+#pragma unroll
+        for (int w = 0; w < kN; ++w) cur[(i * kN + w) * 64 + lane] = v.l[w];
+    }
+    __device__ __forceinline__ void set_next(uint32_t i, const Fe &v) {
+#pragma unroll
+        for (int w = 0; w < kN; ++w) nxt[(i * kN + w) * 64 + lane] = v.l[w];
+    }
+    __device__ __forceinline__ void swap() {
+        uint32_t *tmp = cur;
+        cur = nxt;
+        nxt = tmp;
     }
 
     __device__ __forceinline__ void zero() {
         for (uint32_t i = 0; i < t; ++i) set(i, fe_zero());
     }
 
-    // wave-level: 64 contiguous states = 64*2t contiguous 16-B chunks in global memory
+    // wave-level: 64 contiguous ABI states = 64*2t contiguous 16-B chunks in global memory, staged through
+    // the `nxt` buffer (chunk q of the wave at uint4 index q), then converted element by element
     __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
         const size_t first = ((size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u));
         const size_t valid = n > first ? (n - first < 64 ? n - first : 64) : 0;
         const uint32_t chunks = 2 * t;
         const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + first * chunks;
         const uint32_t n_chunks = (uint32_t)valid * chunks;
+        uint4 *st = reinterpret_cast<uint4 *>(nxt);
         __syncthreads();
         for (uint32_t k = 0; k < chunks; ++k) {
             const uint32_t q = lane + k * 64;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (q < n_chunks) v = g[q];
-            cur[(q % chunks) * 64 + q / chunks] = v;  // q/chunks = state within wave, q%chunks = chunk of state
+            st[q] = v;
         }
+        __syncthreads();
+        for (uint32_t i = 0; i < t; ++i) set(i, fe_from_abi(abi_from_u4(st[lane * chunks + 2 * i], st[lane * chunks + 2 * i + 1]), f));
         __syncthreads();
     }
 
@@ -237,49 +218,30 @@ struct LdsEngine {
         const uint32_t chunks = 2 * t;
         uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * chunks;
         const uint32_t n_chunks = (uint32_t)valid * chunks;
+        uint4 *st = reinterpret_cast<uint4 *>(nxt);
+        __syncthreads();
+        for (uint32_t i = 0; i < t; ++i) {
+            const Abi a = fe_to_abi(get(i), f);
+            st[lane * chunks + 2 * i] = abi_lo(a);
+            st[lane * chunks + 2 * i + 1] = abi_hi(a);
+        }
         __syncthreads();
         for (uint32_t k = 0; k < chunks; ++k) {
             const uint32_t q = lane + k * 64;
-            if (q < n_chunks) g[q] = cur[(q % chunks) * 64 + q / chunks];
+            if (q < n_chunks) g[q] = st[q];
         }
         __syncthreads();
     }
 
     __device__ __forceinline__ void permute() {
-        const uint32_t *ark = c.consts;
-        const uint32_t *mds = c.consts + (size_t)c.total_rounds * t * 8;
-        const uint64_t alpha = c.alpha;
-        uint4 *const home = cur;
-        for (uint32_t r = 0; r < c.total_rounds; ++r) {
-            const uint32_t n_sbox = is_full_round(r, c) ? t : 1;
-            for (uint32_t i = 0; i < t; ++i) {
-                Fe x = fe_add(get(i), fe_load(ark + ((size_t)r * t + i) * 8), f);
-                if (i < n_sbox) x = fe_sbox<ALPHA>(x, alpha, one, f);
-                set(i, x);
-            }
-            for (uint32_t i = 0; i < t; ++i) {
-                Fe acc = fe_mul(get(0), fe_load(mds + ((size_t)i * t) * 8), f);
-                for (uint32_t j = 1; j < t; ++j)
-                    acc = fe_add(acc, fe_mul(get(j), fe_load(mds + ((size_t)i * t + j) * 8), f), f);
-                nxt[(i * 2) * 64 + lane] = fe_lo(acc);
-                nxt[(i * 2 + 1) * 64 + lane] = fe_hi(acc);
-            }
-            uint4 *tmp = cur;
-            cur = nxt;
-            nxt = tmp;
-        }
-        // Lanes may permute a different number of times (per-sponge modes) and other lanes read this
-        // lane's slots in store_states: always leave the state in the buffer it started in.
+        uint32_t *const home = cur;
+        permute_dense_rt<ALPHA>(*this, t, ark, mds, c, one, f);
+        // Lanes may permute a different number of times (per-sponge modes) while load/store_states use the
+        // wave-uniform `nxt` as staging: always leave the state in the buffer it started in.
         if (cur != home) {
-            for (uint32_t q = 0; q < 2 * t; ++q) nxt[q * 64 + lane] = cur[q * 64 + lane];
-            tmp_swap();
+            for (uint32_t q = 0; q < t * kN; ++q) nxt[q * 64 + lane] = cur[q * 64 + lane];
+            swap();
         }
-    }
-
-    __device__ __forceinline__ void tmp_swap() {
-        uint4 *tmp = cur;
-        cur = nxt;
-        nxt = tmp;
     }
 };
 
@@ -287,8 +249,8 @@ struct LdsEngine {
 // Kernels (identical for both engines)
 // ------------------------------------------------------------------------------------------------
 template <class Engine>
-__global__ void __launch_bounds__(Engine::kThreads) permute_kernel(const DevConfig c, uint64_t *states, size_t n) {
-    Engine e(c);
+__global__ void __launch_bounds__(Engine::kThreads) permute_kernel(const DevConfig d, uint64_t *states, size_t n) {
+    Engine e(d);
     e.load_states(states, n);
     e.permute();
     e.store_states(states, n);
@@ -310,9 +272,11 @@ __device__ __forceinline__ uint32_t absorb_elements(Engine &e, const uint64_t *r
             }
         }
         if (active) {
-            const Fe x = fe_load(reinterpret_cast<const uint32_t *>(row + 4 * k));
+            const Fe x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)), e.f);
             const uint32_t pos = c.capacity + idx;
-            e.set(pos, fe_add(e.get(pos), x, e.f));  // state[capacity + idx] += element (mod.rs:128,143)
+            // state[capacity + idx] += element (mod.rs:128,143); normalised so the permutation's own lazy
+            // round-constant add stays within the limb bounds
+            e.set(pos, fe_normalize(fe_add_lazy(e.get(pos), x)));
             idx += 1;
         }
     }
@@ -337,7 +301,7 @@ __device__ __forceinline__ uint32_t squeeze_elements(Engine &e, uint64_t *row, s
             const bool last = idx + rem <= c.rate;
             const uint32_t take = last ? (uint32_t)rem : c.rate - idx;
             for (uint32_t k = 0; k < take; ++k)
-                fe_store(reinterpret_cast<uint32_t *>(row + 4 * (pos + k)), e.get(c.capacity + idx + k));
+                abi_store(reinterpret_cast<uint32_t *>(row + 4 * (pos + k)), fe_to_abi(e.get(c.capacity + idx + k), e.f));
             if (last) {
                 idx += take;
                 done = true;
@@ -354,8 +318,8 @@ __device__ __forceinline__ uint32_t squeeze_elements(Engine &e, uint64_t *row, s
 
 template <class Engine>
 __global__ void __launch_bounds__(Engine::kThreads)
-    hash_kernel(const DevConfig c, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n) {
-    Engine e(c);
+    hash_kernel(const DevConfig d, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n) {
+    Engine e(d);
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
     e.zero();                                                  // CryptographicSponge::new, mod.rs:219-230
@@ -368,9 +332,9 @@ __global__ void __launch_bounds__(Engine::kThreads)
 
 template <class Engine>
 __global__ void __launch_bounds__(Engine::kThreads)
-    absorb_kernel(const DevConfig c, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index, const uint64_t *in,
+    absorb_kernel(const DevConfig d, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index, const uint64_t *in,
                   size_t in_len, size_t n) {
-    Engine e(c);
+    Engine e(d);
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
     e.load_states(states, n);
@@ -386,9 +350,9 @@ __global__ void __launch_bounds__(Engine::kThreads)
 
 template <class Engine>
 __global__ void __launch_bounds__(Engine::kThreads)
-    squeeze_kernel(const DevConfig c, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index, uint64_t *out,
+    squeeze_kernel(const DevConfig d, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index, uint64_t *out,
                    size_t out_len, size_t n) {
-    Engine e(c);
+    Engine e(d);
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
     e.load_states(states, n);
@@ -443,7 +407,7 @@ struct Launch {
 // alpha 5 and 17 have dedicated addition chains, other exponents share the generic S-box.
 #define PMX_DISPATCH(CALL)                                                                  \
     do {                                                                                    \
-        const uint64_t alpha = ((uint64_t)c.alpha_hi << 32) | c.alpha_lo;                   \
+        const uint64_t alpha = c.rounds.alpha;                                              \
         if (t == 3) {                                                                       \
             if (alpha == 5) return Launch<RegEngine<3, 5>>::CALL;                           \
             if (alpha == 17) return Launch<RegEngine<3, 17>>::CALL;                         \

@@ -1,22 +1,35 @@
-// Prime-field arithmetic for gfx950: 256-bit Montgomery residues as 8 x 32-bit limbs (the same bytes as
-// the ABI's 4 little-endian u64 limbs).  CDNA4 has no 64x64 multiplier; the unit of multiply work is
-// v_mad_u64_u32 (32x32+64 -> 64 with carry-out), so everything is written at 32-bit granularity.
+// Prime-field arithmetic of the gfx950 Poseidon kernels.
 //
-// Structure (product scanning / Comba): a column accumulator of 96 bits (64-bit `acc` + 32-bit `ovf`)
-// receives one v_mad_u64_u32 + one v_addc_co_u32 per limb product.  Wide (512-bit) results are only
-// reduced when needed:
-//     mul_wide / sqr_wide / dot_wide   ->  17-limb unreduced sums of products
-//     redc                             ->  Montgomery reduction of such a sum, fully reduced to [0, p)
-// so an MDS row (a t-term dot product) pays ONE reduction, and a squaring does 36 instead of 64 products.
+// Measured on MI355X (profiles/r01/valu_microbench.txt): v_mad_u64_u32 (32x32+64 -> 64) issues at HALF
+// the v_add_u32 rate, and so does every carry instruction (v_add_co / v_addc_co) and every 64-bit add.
+// A saturated 8 x 32-bit representation pays one carry instruction per limb product, i.e. doubles the
+// multiply cost.  The kernels therefore compute in an UNSATURATED radix:
 //
-// Replaces the ark-ff Fp<MontBackend<_,4>,4> operations the reference's hot path calls:
+//     9 limbs of 29 bits (261 bits) held in uint32_t, Montgomery radix R' = 2^261.
+//
+//   * a limb product is < 2^58 (2^59/2^60 with lazily added operands), so up to 27 of them plus the 9
+//     reduction products are summed in ONE 64-bit column accumulator by bare v_mad_u64_u32 - no carries;
+//   * p < 2^255 leaves >= 6 spare bits: Montgomery outputs are < 1.3 p without any conditional
+//     subtraction, additions are plain limb-wise adds, and nothing is compared against p until the final
+//     conversion back to the ABI form;
+//   * multiplication and reduction are interleaved column by column (one live accumulator).
+//
+// ABI form (4 x u64 = 8 x u32 limbs, x * 2^256 mod p, fully reduced - ark-ff's Fp<MontBackend<_,4>,4>)
+// is converted on load (x2^256 -> x2^261: one Montgomery product with 2^266 mod p) and on store (one
+// product with 2^256 mod p, then the only exact reduction to [0, p)).  Results are therefore
+// limb-identical to ark-ff's for:
 //   add_assign / +=   reference src/poseidon/mod.rs:78,88,128,143
 //   mul               reference src/poseidon/mod.rs:87
 //   pow(&[alpha])     reference src/poseidon/mod.rs:67,72
-// Every public result is a fully reduced residue in [0, p): limb-identical to ark-ff's.
 //
-// The same source compiles for the host (portable C++ in place of the two asm statements) so that the
-// algorithms are unit-tested on CPU against the oracle (tools/host_field_check.cpp).
+// Bounds (B = value / p; "norm" = every limb < 2^29, "lazy" = every limb < 2^30):
+//   redc output      norm, B < T / (p * 2^261) + 1            (T = the reduced integer)
+//   fe_add_lazy      inputs norm -> output lazy, B = Ba + Bb
+//   column sums      <= 27 products (one side lazy) + 9 reduction products + carry  < 2^64  (see field_check)
+// p < 2^255  =>  p / 2^261 < 2^-6: with every operand B <= 4, T <= 3 * 16 p^2 gives outputs B < 1.75.
+//
+// The same source compiles for the host so the algorithms are unit-tested on CPU against the oracle
+// (tools/host_field_check.cpp); on the device `acc += (uint64_t)a * b` is exactly one v_mad_u64_u32.
 #pragma once
 #include <cstdint>
 
@@ -29,257 +42,302 @@
 
 namespace pmx {
 
+constexpr int kW = 29;                       // bits per limb
+constexpr int kN = 9;                        // limbs
+constexpr uint32_t kMask = (1u << kW) - 1;
+constexpr int kFeStride = 12;                // u32 words per stored constant (9 used; 48-byte aligned rows)
+
 struct Fe {
-    uint32_t l[8];
+    uint32_t l[kN];
 };
 
-// Modulus view: run-time values, wave-uniform (SGPRs on the device).
+// ABI element: 8 x 32-bit limbs of x * 2^256 mod p
+struct Abi {
+    uint32_t w[8];
+};
+
+// Modulus view: wave-uniform run-time values (SGPRs on the device).
 struct FieldRt {
-    uint32_t p[8];   // modulus limbs
-    uint32_t inv32;  // -p^-1 mod 2^32
-};
-
-// An unreduced sum of at most `lazy_terms` products of reduced residues: value < 2^512 + small, 17 limbs.
-struct Wide {
-    uint32_t w[17];
+    uint32_t p[kN];     // modulus, 29-bit limbs
+    uint32_t pinv;      // -p^-1 mod 2^29
+    uint32_t p32[8];    // modulus, 32-bit limbs (final exact reduction)
+    Fe to_int;          // 2^266 mod p, plain integer in 29-bit limbs: ABI -> internal
+    Fe to_abi;          // 2^256 mod p, plain integer in 29-bit limbs: internal -> ABI
 };
 
 PMX_FN Fe fe_zero() {
     Fe z;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z.l[i] = 0;
+    for (int i = 0; i < kN; ++i) z.l[i] = 0;
     return z;
 }
 
-// ---- column accumulator primitives -------------------------------------------------------------------
-// (acc, ovf) += a * b
-PMX_FN void mac(uint64_t &acc, uint32_t &ovf, uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint64_t carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "v"(b));
-    asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(ovf), "+s"(carry));
-#else
-    const unsigned __int128 t = (unsigned __int128)acc + (uint64_t)a * b;
-    acc = (uint64_t)t;
-    ovf += (uint32_t)(t >> 64);
-#endif
+// limb-wise add, no carry propagation: inputs norm -> output lazy
+PMX_FN Fe fe_add_lazy(const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
 }
 
-// same with b wave-uniform (an SGPR operand: modulus limbs, scalar-loaded constants)
-PMX_FN void mac_s(uint64_t &acc, uint32_t &ovf, uint32_t a, uint32_t b_uniform) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint64_t carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "s"(b_uniform));
-    asm("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(ovf), "+s"(carry));
-#else
-    mac(acc, ovf, a, b_uniform);
-#endif
+// carry propagation: any limbs < 2^32 (value < 2^261) -> norm
+PMX_FN Fe fe_normalize(const Fe &a) {
+    Fe r;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < kN - 1; ++i) {
+        const uint32_t v = a.l[i] + carry;   // < 2^32 as long as a.l[i] < 2^32 - 8
+        r.l[i] = v & kMask;
+        carry = v >> kW;
+    }
+    r.l[kN - 1] = a.l[kN - 1] + carry;
+    return r;
 }
 
-// (acc, ovf) += x  (32-bit)
-PMX_FN void acc_add(uint64_t &acc, uint32_t &ovf, uint32_t x) {
-    const uint64_t prev = acc;
-    acc += x;
-    ovf += (acc < prev) ? 1u : 0u;
-}
-
-// (acc, ovf) = 2 * (acc, ovf)
-PMX_FN void acc_double(uint64_t &acc, uint32_t &ovf) {
-    ovf = (ovf << 1) | (uint32_t)(acc >> 63);
-    acc <<= 1;
-}
-
-// emit the low limb and shift the accumulator down one limb
-PMX_FN uint32_t acc_shift(uint64_t &acc, uint32_t &ovf) {
-    const uint32_t out = (uint32_t)acc;
-    acc = (acc >> 32) | ((uint64_t)ovf << 32);
-    ovf = 0;
+// ---- interleaved (column-wise) Montgomery dot product -------------------------------------------------------
+// returns  (sum_{j<T} a[j]*b[j]) * 2^-261  mod p  as a norm element, B < sum / (p 2^261) + 1.
+// Operands: a[] lazy (limbs < 2^30), b[] norm.  Column k of the products and of the running m*p are summed
+// in 64-bit accumulators; one accumulator takes at most 3 terms (27 products * 2^59 + 9 * 2^58 + carry
+// < 2^64, checked in tests/test_hostcheck.py), so wider dots use ceil(T/3) accumulators whose low 29 bits
+// and carries are combined once per column.
+template <int T>
+PMX_FN Fe mont_dot(const Fe *a, const Fe *b, const FieldRt &f) {
+    constexpr int G = (T + 2) / 3;
+    uint32_t m[kN];
+    Fe out;
+    uint64_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * kN - 1; ++k) {
+        const int lo_i = k < kN ? 0 : k - (kN - 1);
+        const int hi_i = k < kN ? k : kN - 1;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = lo_i; i <= hi_i; ++i) acc[t / 3] += (uint64_t)a[t].l[i] * b[t].l[k - i];
+        }
+#pragma unroll
+        for (int j = lo_i; j <= hi_i; ++j) {
+            if (j < k || k >= kN) acc[0] += (uint64_t)m[j] * f.p[k - j];   // m_k itself is added below
+        }
+        if constexpr (G == 1) {
+            if (k < kN) {
+                m[k] = ((uint32_t)acc[0] * f.pinv) & kMask;
+                acc[0] += (uint64_t)m[k] * f.p[0];   // low 29 bits are now zero
+            } else {
+                out.l[k - kN] = (uint32_t)acc[0] & kMask;
+            }
+            acc[0] >>= kW;
+        } else {
+            uint32_t low = (uint32_t)acc[0] & kMask;
+            uint64_t carry = acc[0] >> kW;
+#pragma unroll
+            for (int g = 1; g < G; ++g) {
+                low += (uint32_t)acc[g] & kMask;
+                carry += acc[g] >> kW;
+                acc[g] = 0;
+            }
+            if (k < kN) {
+                m[k] = (low * f.pinv) & kMask;
+                const uint64_t v = (uint64_t)m[k] * f.p[0] + low;   // low 29 bits are zero
+                acc[0] = carry + (v >> kW);
+            } else {
+                out.l[k - kN] = low & kMask;
+                acc[0] = carry + (low >> kW);
+            }
+        }
+    }
+    out.l[kN - 1] = (uint32_t)acc[0];
     return out;
 }
 
-// ---- conditional subtraction / modular add ---------------------------------------------------------------
-// t (8 limbs + carry word `hi`) -> t - p if t >= p
-PMX_FN Fe fe_cond_sub(const uint32_t t[8], uint32_t hi, const FieldRt &f, uint32_t *hi_out = nullptr) {
-    uint32_t d[8];
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint64_t v = (uint64_t)t[i] - f.p[i] - borrow;
-        d[i] = (uint32_t)v;
-        borrow = (uint32_t)(v >> 32) & 1u;
-    }
-    const bool take = (hi != 0) | (borrow == 0);
-    Fe r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = take ? d[i] : t[i];
-    if (hi_out) *hi_out = take ? hi - borrow : hi;
-    return r;
-}
+PMX_FN Fe mont_mul(const Fe &a, const Fe &b, const FieldRt &f) { return mont_dot<1>(&a, &b, f); }
 
-PMX_FN Fe fe_add(const Fe &a, const Fe &b, const FieldRt &f) {
-    uint32_t s[8];
-    uint32_t carry = 0;
+// a^2 * 2^-261: cross products once against the doubled operand (45 limb products instead of 81)
+PMX_FN Fe mont_sqr(const Fe &a, const FieldRt &f) {
+    uint32_t d[kN];  // 2 * a_j
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint64_t v = (uint64_t)a.l[i] + b.l[i] + carry;
-        s[i] = (uint32_t)v;
-        carry = (uint32_t)(v >> 32);
-    }
-    return fe_cond_sub(s, carry, f);
-}
-
-// ---- wide products -----------------------------------------------------------------------------------------
-// Column k of the schoolbook product a*b, accumulated into (acc, ovf).  BS: b is wave-uniform.
-template <bool BS>
-PMX_FN void mul_column(uint64_t &acc, uint32_t &ovf, const Fe &a, const Fe &b, int k) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = k - i;
-        if (j >= 0 && j < 8) {
-            if constexpr (BS) mac_s(acc, ovf, a.l[i], b.l[j]);
-            else mac(acc, ovf, a.l[i], b.l[j]);
-        }
-    }
-}
-
-// r = sum_{j<T} a[j] * b[j]   (unreduced; the caller guarantees the sum fits the lazy bound)
-template <int T, bool BS>
-PMX_FN Wide dot_wide(const Fe *a, const Fe *b) {
-    Wide r;
+    for (int i = 0; i < kN; ++i) d[i] = a.l[i] << 1;
+    uint32_t m[kN];
+    Fe out;
     uint64_t acc = 0;
-    uint32_t ovf = 0;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) {
+    for (int k = 0; k < 2 * kN - 1; ++k) {
 #pragma unroll
-        for (int j = 0; j < T; ++j) mul_column<BS>(acc, ovf, a[j], b[j], k);
-        r.w[k] = acc_shift(acc, ovf);
-    }
-    r.w[15] = (uint32_t)acc;
-    r.w[16] = (uint32_t)(acc >> 32);
-    return r;
-}
-
-PMX_FN Wide mul_wide(const Fe &a, const Fe &b) { return dot_wide<1, false>(&a, &b); }
-
-// a^2: cross products once, doubled, plus the squares (36 limb products instead of 64)
-PMX_FN Wide sqr_wide(const Fe &a) {
-    Wide r;
-    uint64_t acc = 0;
-    uint32_t ovf = 0;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) {
-        // carry from the previous column is already in (acc, ovf); cross terms go to a fresh accumulator
-        uint64_t cacc = 0;
-        uint32_t covf = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kN; ++i) {
             const int j = k - i;
-            if (j > i && j < 8) mac(cacc, covf, a.l[i], a.l[j]);
+            if (j > i && j < kN) acc += (uint64_t)a.l[i] * d[j];
         }
-        acc_double(cacc, covf);
-        if ((k & 1) == 0) mac(cacc, covf, a.l[k / 2], a.l[k / 2]);
-        // (acc, ovf) += (cacc, covf)
-        const uint64_t prev = acc;
-        acc += cacc;
-        ovf += covf + ((acc < prev) ? 1u : 0u);
-        r.w[k] = acc_shift(acc, ovf);
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+        if (k < kN) {
+#pragma unroll
+            for (int j = 0; j < k; ++j) acc += (uint64_t)m[j] * f.p[k - j];
+            m[k] = ((uint32_t)acc * f.pinv) & kMask;
+            acc += (uint64_t)m[k] * f.p[0];
+        } else {
+#pragma unroll
+            for (int j = k - (kN - 1); j < kN; ++j) acc += (uint64_t)m[j] * f.p[k - j];
+            out.l[k - kN] = (uint32_t)acc & kMask;
+        }
+        acc >>= kW;
     }
-    r.w[15] = (uint32_t)acc;
-    r.w[16] = (uint32_t)(acc >> 32);
-    return r;
+    out.l[kN - 1] = (uint32_t)acc;
+    return out;
 }
 
-// r += x * 2^256  (adds a reduced residue into the upper half: used for  w*z0 + z_i  before one reduction)
-PMX_FN void wide_add_hi(Wide &r, const Fe &x) {
-    uint32_t carry = 0;
+// ---- run-time-width dot products: explicit column array ---------------------------------------------------------
+// 18 64-bit columns; terms are added with cols_mul_acc and the columns re-compressed at least every 3 terms.
+struct Cols {
+    uint64_t c[2 * kN];
+};
+
+PMX_FN void cols_zero(Cols &t) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint64_t v = (uint64_t)r.w[8 + i] + x.l[i] + carry;
-        r.w[8 + i] = (uint32_t)v;
-        carry = (uint32_t)(v >> 32);
-    }
-    r.w[16] += carry;
+    for (int k = 0; k < 2 * kN; ++k) t.c[k] = 0;
 }
 
-// Montgomery reduction: (T + m*p) / 2^256 fully reduced to [0, p).
-// Requires T < 2^256 * 2p  (so the quotient is < 3p): the host checks the lazy bounds per modulus.
-PMX_FN Fe redc(const Wide &t, const FieldRt &f) {
-    uint32_t m[8];
-    uint32_t out[8];
-    uint64_t acc = 0;
-    uint32_t ovf = 0;
+PMX_FN void cols_mul_acc(Cols &t, const Fe &a, const Fe &b) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        acc_add(acc, ovf, t.w[k]);
+    for (int i = 0; i < kN; ++i) {
 #pragma unroll
-        for (int j = 0; j < k; ++j) mac_s(acc, ovf, m[j], f.p[k - j]);
-        m[k] = (uint32_t)acc * f.inv32;
-        mac_s(acc, ovf, m[k], f.p[0]);
-        (void)acc_shift(acc, ovf);  // low limb is zero by construction
+        for (int j = 0; j < kN; ++j) t.c[i + j] += (uint64_t)a.l[i] * b.l[j];
     }
-#pragma unroll
-    for (int k = 8; k < 16; ++k) {
-        acc_add(acc, ovf, t.w[k]);
-#pragma unroll
-        for (int j = k - 7; j < 8; ++j) mac_s(acc, ovf, m[j], f.p[k - j]);
-        out[k - 8] = acc_shift(acc, ovf);
-    }
-    uint32_t hi = (uint32_t)acc + t.w[16];
-    // quotient < 3p: at most two subtractions; after the first it is < 2p <= 2^256 (p < 2^255 is enforced)
-    uint32_t hi2;
-    const Fe once = fe_cond_sub(out, hi, f, &hi2);
-    return fe_cond_sub(once.l, hi2, f);
 }
 
-PMX_FN Fe fe_mul(const Fe &a, const Fe &b, const FieldRt &f) { return redc(mul_wide(a, b), f); }
-PMX_FN Fe fe_sqr(const Fe &a, const FieldRt &f) { return redc(sqr_wide(a), f); }
+// push every column's bits above 29 into the next column
+PMX_FN void cols_compress(Cols &t) {
+#pragma unroll
+    for (int k = 0; k < 2 * kN - 1; ++k) {
+        t.c[k + 1] += t.c[k] >> kW;
+        t.c[k] &= kMask;
+    }
+}
 
-// x^alpha.  5 and 17 use the shortest chains; anything else is MSB-first square-and-multiply seeded
-// with x (alpha is wave-uniform, so the branches are scalar).  alpha == 0 -> one, alpha == 1 -> x.
+// Montgomery reduction of compressed columns (each < 2^30): norm result, B < value / (p 2^261) + 1
+PMX_FN Fe cols_redc(Cols &t, const FieldRt &f) {
+#pragma unroll
+    for (int k = 0; k < kN; ++k) {
+        const uint32_t m = ((uint32_t)t.c[k] * f.pinv) & kMask;
+#pragma unroll
+        for (int j = 0; j < kN; ++j) t.c[k + j] += (uint64_t)m * f.p[j];
+        t.c[k + 1] += t.c[k] >> kW;
+    }
+    Fe out;
+#pragma unroll
+    for (int k = kN; k < 2 * kN - 1; ++k) {
+        out.l[k - kN] = (uint32_t)t.c[k] & kMask;
+        t.c[k + 1] += t.c[k] >> kW;
+    }
+    out.l[kN - 1] = (uint32_t)t.c[2 * kN - 1];
+    return out;
+}
+
+// x^alpha on the internal form.  5 and 17 use the shortest chains; anything else is MSB-first
+// square-and-multiply seeded with x (alpha is wave-uniform, so the branches are scalar).
+// x may be lazy with B <= 4; the result is norm with B < 1.3.  `one` = 2^261 mod p.
 template <int ALPHA>
 PMX_FN Fe fe_sbox(const Fe &x, uint64_t alpha, const Fe &one, const FieldRt &f) {
     if constexpr (ALPHA == 5) {
-        const Fe x2 = fe_sqr(x, f);
-        const Fe x4 = fe_sqr(x2, f);
-        return fe_mul(x4, x, f);
+        const Fe x2 = mont_sqr(x, f);
+        const Fe x4 = mont_sqr(x2, f);
+        return mont_mul(x4, x, f);
     } else if constexpr (ALPHA == 17) {
-        Fe y = fe_sqr(x, f);
-        y = fe_sqr(y, f);
-        y = fe_sqr(y, f);
-        y = fe_sqr(y, f);
-        return fe_mul(y, x, f);
+        Fe y = mont_sqr(x, f);
+        y = mont_sqr(y, f);
+        y = mont_sqr(y, f);
+        y = mont_sqr(y, f);
+        return mont_mul(y, x, f);
     } else {
         if (alpha == 0) return one;
+        if (alpha == 1) return fe_normalize(x);
         const int top = 63 - __builtin_clzll(alpha);
-        Fe acc = x;
-        for (int bit = top - 1; bit >= 0; --bit) {
-            acc = fe_sqr(acc, f);
-            if ((alpha >> bit) & 1) acc = fe_mul(acc, x, f);
+        Fe acc = mont_sqr(x, f);
+        if ((alpha >> (top - 1)) & 1) acc = mont_mul(acc, x, f);
+        for (int bit = top - 2; bit >= 0; --bit) {
+            acc = mont_sqr(acc, f);
+            if ((alpha >> bit) & 1) acc = mont_mul(acc, x, f);
         }
         return acc;
     }
 }
 
-#if defined(__HIPCC__)
-// 32-byte element <-> two 16-byte vectors
-__device__ __forceinline__ Fe fe_from_u4(const uint4 &lo, const uint4 &hi) {
+// ---- ABI <-> internal ------------------------------------------------------------------------------------------
+// bit-slice 8 x 32 -> 9 x 29 (value < 2^256)
+PMX_FN Fe limbs_32_to_29(const Abi &x) {
     Fe r;
-    r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w;
-    r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+        const int bit = kW * i, wi = bit / 32, sh = bit % 32;
+        uint64_t pair = x.w[wi];
+        if (wi + 1 < 8) pair |= (uint64_t)x.w[wi + 1] << 32;
+        r.l[i] = (uint32_t)(pair >> sh) & kMask;
+    }
     return r;
 }
-__device__ __forceinline__ uint4 fe_lo(const Fe &a) { return make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]); }
-__device__ __forceinline__ uint4 fe_hi(const Fe &a) { return make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]); }
 
-__device__ __forceinline__ Fe fe_load(const uint32_t *ptr) {  // 16-byte aligned (global or LDS)
-    const uint4 *q = reinterpret_cast<const uint4 *>(ptr);
-    return fe_from_u4(q[0], q[1]);
+// 9 x 29 (norm, value < 2^256) -> 8 x 32
+PMX_FN Abi limbs_29_to_32(const Fe &x) {
+    Abi r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int bit = 32 * k, li = bit / kW, sh = bit % kW;   // word k starts inside limb li
+        uint64_t v = (uint64_t)x.l[li] >> sh;
+        if (li + 1 < kN) v |= (uint64_t)x.l[li + 1] << (kW - sh);
+        if (li + 2 < kN && 2 * kW - sh < 32) v |= (uint64_t)x.l[li + 2] << (2 * kW - sh);
+        r.w[k] = (uint32_t)v;
+    }
+    return r;
 }
-__device__ __forceinline__ void fe_store(uint32_t *ptr, const Fe &a) {
+
+// x*2^256 (reduced) -> x*2^261 (norm, B < 1.02)
+PMX_FN Fe fe_from_abi(const Abi &x, const FieldRt &f) { return mont_mul(limbs_32_to_29(x), f.to_int, f); }
+
+// x*2^261 (norm or lazy, B <= 4) -> x*2^256 fully reduced to [0, p)
+PMX_FN Abi fe_to_abi(const Fe &x, const FieldRt &f) {
+    const Abi t = limbs_29_to_32(mont_mul(x, f.to_abi, f));   // B < 1.1: at most one subtraction
+    uint32_t d[8];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t v = (uint64_t)t.w[i] - f.p32[i] - borrow;
+        d[i] = (uint32_t)v;
+        borrow = (uint32_t)(v >> 32) & 1u;
+    }
+    Abi r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.w[i] = borrow ? t.w[i] : d[i];
+    return r;
+}
+
+#if defined(__HIPCC__)
+// 32-byte ABI element <-> two 16-byte vectors
+__device__ __forceinline__ Abi abi_from_u4(const uint4 &lo, const uint4 &hi) {
+    Abi r;
+    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+    r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ uint4 abi_lo(const Abi &a) { return make_uint4(a.w[0], a.w[1], a.w[2], a.w[3]); }
+__device__ __forceinline__ uint4 abi_hi(const Abi &a) { return make_uint4(a.w[4], a.w[5], a.w[6], a.w[7]); }
+
+__device__ __forceinline__ Abi abi_load(const uint32_t *ptr) {  // 16-byte aligned global or LDS address
+    const uint4 *q = reinterpret_cast<const uint4 *>(ptr);
+    return abi_from_u4(q[0], q[1]);
+}
+__device__ __forceinline__ void abi_store(uint32_t *ptr, const Abi &a) {
     uint4 *q = reinterpret_cast<uint4 *>(ptr);
-    q[0] = fe_lo(a);
-    q[1] = fe_hi(a);
+    q[0] = abi_lo(a);
+    q[1] = abi_hi(a);
 }
 #endif
+
+// a stored constant: kFeStride words, 9 used (wave-uniform address -> scalar loads / LDS broadcast)
+PMX_FN Fe fe_const(const uint32_t *ptr) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) r.l[i] = ptr[i];
+    return r;
+}
 
 }  // namespace pmx

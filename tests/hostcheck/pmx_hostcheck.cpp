@@ -1,0 +1,143 @@
+// CPU-side check of the KERNEL ALGORITHMS (test infrastructure, not a product path): the field arithmetic
+// and permutation templates of sponge_amd/csrc/pmx_field.hpp / pmx_permute.hpp are compiled for the host and
+// exported so that tests/test_hostcheck.py can compare them with the oracle without a GPU.  The product
+// library never links this file; libposeidon_mi355x.so has no CPU data path.
+//
+// Build: g++ -O2 -std=c++17 -fPIC -shared -I sponge_amd/csrc tests/hostcheck/pmx_hostcheck.cpp -o tests/hostcheck/libpmx_hostcheck.so
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "pmx_prepare.hpp"
+
+using namespace pmx;
+
+static Abi load_abi(const uint64_t *p) {
+    Abi a;
+    std::memcpy(a.w, p, 32);
+    return a;
+}
+static void store_abi(uint64_t *p, const Abi &a) { std::memcpy(p, a.w, 32); }
+
+template <int T>
+static void permute_t(const Prepared &pp, uint64_t *states, size_t n) {
+    const uint32_t *ark = pp.consts.data();
+    const uint32_t *mds = pp.consts.data() + pp.mds_offset;
+    for (size_t k = 0; k < n; ++k) {
+        Fe s[T];
+        for (int i = 0; i < T; ++i) s[i] = fe_from_abi(load_abi(states + (k * T + i) * 4), pp.f);
+        if (pp.c.alpha == 5) permute_dense<T, 5>(s, ark, mds, pp.c, pp.one, pp.f);
+        else if (pp.c.alpha == 17) permute_dense<T, 17>(s, ark, mds, pp.c, pp.one, pp.f);
+        else permute_dense<T, 0>(s, ark, mds, pp.c, pp.one, pp.f);
+        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi(s[i], pp.f));
+    }
+}
+
+// run-time-width path (what LdsEngine runs), state in two plain arrays
+struct HostState {
+    Fe cur[PMX_MAX_WIDTH], nxt[PMX_MAX_WIDTH];
+    Fe get(uint32_t i) const { return cur[i]; }
+    void set(uint32_t i, const Fe &x) { cur[i] = x; }
+    void set_next(uint32_t i, const Fe &x) { nxt[i] = x; }
+    void swap() { for (int i = 0; i < PMX_MAX_WIDTH; ++i) { Fe t = cur[i]; cur[i] = nxt[i]; nxt[i] = t; } }
+};
+
+extern "C" int hc_permute_rt(const pmx_config *cfg, uint64_t *states, size_t n) {
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);
+    if (rc) return rc;
+    const uint32_t t = pp.t;
+    const uint32_t *ark = pp.consts.data();
+    const uint32_t *mds = pp.consts.data() + pp.mds_offset;
+    for (size_t k = 0; k < n; ++k) {
+        HostState st;
+        for (uint32_t i = 0; i < t; ++i) st.cur[i] = fe_from_abi(load_abi(states + (k * t + i) * 4), pp.f);
+        if (pp.c.alpha == 5) permute_dense_rt<5>(st, t, ark, mds, pp.c, pp.one, pp.f);
+        else if (pp.c.alpha == 17) permute_dense_rt<17>(st, t, ark, mds, pp.c, pp.one, pp.f);
+        else permute_dense_rt<0>(st, t, ark, mds, pp.c, pp.one, pp.f);
+        for (uint32_t i = 0; i < t; ++i) store_abi(states + (k * t + i) * 4, fe_to_abi(st.cur[i], pp.f));
+    }
+    return PMX_OK;
+}
+
+extern "C" int hc_permute(const pmx_config *cfg, uint64_t *states, size_t n) {
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);
+    if (rc) return rc;
+    switch (pp.t) {
+        case 2: permute_t<2>(pp, states, n); break;
+        case 3: permute_t<3>(pp, states, n); break;
+        case 4: permute_t<4>(pp, states, n); break;
+        case 5: permute_t<5>(pp, states, n); break;
+        case 9: permute_t<9>(pp, states, n); break;
+        default: return PMX_ERR_UNSUPPORTED;
+    }
+    return PMX_OK;
+}
+
+// op: 0 mul, 1 sqr(a), 2 dot3(a[0..3), b[0..3)), 3 round trip abi->internal->abi
+extern "C" int hc_field_op(const uint64_t modulus[4], int op, const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    pmx_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    std::memcpy(cfg.modulus, modulus, 32);
+    cfg.full_rounds = 2; cfg.partial_rounds = 0; cfg.rate = 1; cfg.capacity = 0; cfg.alpha = 5;
+    uint64_t zeros[8] = {0};
+    cfg.ark = zeros; cfg.mds = zeros;
+    Prepared pp;
+    std::string err;
+    int rc = prepare(&cfg, pp, err);
+    if (rc) return rc;
+    const FieldRt &f = pp.f;
+    if (op == 0) {
+        store_abi(out, fe_to_abi(mont_mul(fe_from_abi(load_abi(a), f), fe_from_abi(load_abi(b), f), f), f));
+    } else if (op == 1) {
+        store_abi(out, fe_to_abi(mont_sqr(fe_from_abi(load_abi(a), f), f), f));
+    } else if (op == 2) {
+        Fe x[3], y[3];
+        for (int i = 0; i < 3; ++i) { x[i] = fe_from_abi(load_abi(a + 4 * i), f); y[i] = fe_from_abi(load_abi(b + 4 * i), f); }
+        store_abi(out, fe_to_abi(mont_dot<3>(x, y, f), f));
+    } else if (op == 3) {
+        store_abi(out, fe_to_abi(fe_from_abi(load_abi(a), f), f));
+    } else {
+        return PMX_ERR_ARG;
+    }
+    return PMX_OK;
+}
+
+// Largest value any 64-bit column accumulator can reach in mont_dot<T> when every a-limb is `amax`,
+// every b-limb `bmax` (worst case over all inputs, ignoring field semantics).  Returned as hi:lo.
+extern "C" void hc_worst_column(int terms, uint32_t amax, uint32_t bmax, uint64_t *hi, uint64_t *lo) {
+    unsigned __int128 worst = 0, acc = 0;
+    for (int k = 0; k < 2 * kN - 1; ++k) {
+        const int nprod = (k < kN) ? k + 1 : 2 * kN - 1 - k;
+        acc += (unsigned __int128)terms * nprod * amax * bmax;
+        const int nred = (k < kN) ? k + 1 : 2 * kN - 1 - k;   // m_j * p_{k-j} terms incl. m_k * p_0
+        acc += (unsigned __int128)nred * kMask * kMask;
+        if (acc > worst) worst = acc;
+        acc >>= kW;
+    }
+    *hi = (uint64_t)(worst >> 64);
+    *lo = (uint64_t)worst;
+}
+
+// Same for mont_sqr with every limb of the operand equal to `amax` (cross products use the doubled limb).
+extern "C" void hc_worst_sqr_column(uint32_t amax, uint64_t *hi, uint64_t *lo) {
+    unsigned __int128 worst = 0, acc = 0;
+    for (int k = 0; k < 2 * kN - 1; ++k) {
+        int cross = 0;
+        for (int i = 0; i < kN; ++i) {
+            const int j = k - i;
+            if (j > i && j < kN) ++cross;
+        }
+        acc += (unsigned __int128)cross * amax * (2ull * amax);
+        if ((k & 1) == 0) acc += (unsigned __int128)amax * amax;
+        const int nred = (k < kN) ? k + 1 : 2 * kN - 1 - k;
+        acc += (unsigned __int128)nred * kMask * kMask;
+        if (acc > worst) worst = acc;
+        acc >>= kW;
+    }
+    *hi = (uint64_t)(worst >> 64);
+    *lo = (uint64_t)worst;
+}

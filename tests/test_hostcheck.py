@@ -1,0 +1,118 @@
+"""The kernel ALGORITHMS (unsaturated 9x29-bit Montgomery arithmetic, interleaved dot/REDC, round schedule)
+compiled for the host and compared with the oracle on CPU.  This exercises the exact templates the HIP
+kernels instantiate (sponge_amd/csrc/pmx_field.hpp, pmx_permute.hpp); it is test infrastructure - the
+product library has no CPU data path."""
+import ctypes
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from sponge_amd._lib import PmxConfig
+from oracle import cref
+from oracle import poseidon_oracle as O
+
+from helpers import golden, ints, oracle_config
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    subprocess.check_call(["make", "-C", HERE, "all"], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(HERE, "libpmx_hostcheck.so"))
+    lib.hc_permute.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    lib.hc_permute_rt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    lib.hc_field_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.hc_worst_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.hc_worst_sqr_column.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+def mont_limbs(vals, p):
+    return cref.elems_to_limbs(vals, p)
+
+
+def field_op(hc, p, op, a_vals, b_vals):
+    mod = np.array(O.to_limbs(p), dtype=np.uint64)
+    a = mont_limbs(a_vals, p)
+    b = mont_limbs(b_vals, p)
+    out = np.zeros(4, dtype=np.uint64)
+    assert hc.hc_field_op(mod.ctypes.data, op, a.ctypes.data, b.ctypes.data, out.ctypes.data) == 0
+    raw = O.from_limbs([int(x) for x in out])
+    assert raw < p, "result not fully reduced"
+    return O.from_mont(raw, p)
+
+
+@pytest.mark.parametrize("p", [O.BLS12_381_FR, O.BN254_FR])
+def test_field_ops_match_bigint(hc, p):
+    rng = random.Random(p & 0xFFFF)
+    edge = [0, 1, 2, p - 1, p - 2, (1 << 255) % p, (p - 1) // 2, (1 << 29) - 1, 1 << 232]
+    pairs = [(a, b) for a in edge for b in edge] + [(rng.randrange(p), rng.randrange(p)) for _ in range(300)]
+    for a, b in pairs:
+        assert field_op(hc, p, 0, [a], [b]) == a * b % p
+        assert field_op(hc, p, 1, [a], [b]) == a * a % p
+        assert field_op(hc, p, 3, [a], [b]) == a
+    for _ in range(200):
+        xs = [rng.choice(edge + [rng.randrange(p)]) for _ in range(3)]
+        ys = [rng.choice(edge + [rng.randrange(p)]) for _ in range(3)]
+        assert field_op(hc, p, 2, xs, ys) == sum(x * y for x, y in zip(xs, ys)) % p
+
+
+def test_column_accumulators_cannot_overflow(hc):
+    """Worst case over ALL limb patterns: 3-term dot, one side lazily added (limbs < 2^30), the other
+    normalised (< 2^29), plus the 9 reduction products and the carry, stays below 2^64."""
+    hi = np.zeros(1, dtype=np.uint64)
+    lo = np.zeros(1, dtype=np.uint64)
+    for terms, amax, bmax, ok in [(3, (1 << 30) - 1, (1 << 29) - 1, True),     # MDS row on x + c
+                                  (1, (1 << 30) - 1, (1 << 30) - 1, True),     # product of two lazy operands
+                                  (6, (1 << 29) - 1, (1 << 29) - 1, True),     # 6 normalised terms
+                                  (7, (1 << 29) - 1, (1 << 29) - 1, False),    # ... is the limit
+                                  (4, (1 << 30) - 1, (1 << 30) - 1, False)]:   # and so is this
+        hc.hc_worst_column(terms, amax, bmax, hi.ctypes.data, lo.ctypes.data)
+        assert (int(hi[0]) == 0) == ok, (terms, amax, bmax, int(hi[0]), int(lo[0]))
+    hc.hc_worst_sqr_column((1 << 30) - 1, hi.ctypes.data, lo.ctypes.data)     # squaring a lazily added operand
+    assert int(hi[0]) == 0
+
+
+def run_permute(hc, name, states, rt=False):
+    cfg = oracle_config(name)
+    p = cfg.p
+    ark = mont_limbs([v for row in cfg.ark for v in row], p)
+    mds = mont_limbs([v for row in cfg.mds for v in row], p)
+    c = PmxConfig()
+    c.full_rounds, c.partial_rounds, c.alpha = cfg.full_rounds, cfg.partial_rounds, cfg.alpha
+    c.rate, c.capacity = cfg.rate, cfg.capacity
+    for i, l in enumerate(O.to_limbs(p)):
+        c.modulus[i] = l
+    c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+    out = np.ascontiguousarray(states, dtype=np.uint64).copy()
+    n = out.size // (cfg.t * 4)
+    fn = hc.hc_permute_rt if rt else hc.hc_permute
+    assert fn(ctypes.byref(c), out.ctypes.data, n) == 0
+    return out
+
+
+@pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31", "bls_t4_a5_8_56", "bls_t9_a5_8_57",
+                                  "bls_t3_a257_8_13", "bn254_t9_a5_8_57", "bn254_t3_a5_8_57",
+                                  "reference_test_a17_8_29"])
+def test_permutation_templates_match_golden(hc, name):
+    cfg = oracle_config(name)
+    vecs = golden("permute_vectors.json")[name]
+    states = mont_limbs([x for v in vecs for x in ints(v["in"])], cfg.p).reshape(len(vecs), cfg.t, 4)
+    want = [x for v in vecs for x in ints(v["out"])]
+    for rt in (False, True):     # compile-time-width template and run-time-width (LDS engine) template
+        out = run_permute(hc, name, states, rt=rt)
+        assert cref.limbs_to_elems(out, cfg.p) == want, ("rt" if rt else "static")
+
+
+def test_permutation_templates_match_c_oracle_on_random_batch(hc):
+    from sponge_amd import synth
+    import sponge_amd as S
+    for name, f in [("bls_t3_a5_8_31", S.BLS12_381_FR), ("bn254_t3_a5_8_57", S.BN254_FR)]:
+        states = synth.random_elements(f, 512 * 3, seed=77).reshape(512, 3, 4)
+        got = run_permute(hc, name, states)
+        want = cref.CRef(oracle_config(name)).permute_batch(states, threads=0)
+        assert np.array_equal(got, want)
