@@ -112,6 +112,10 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.consts = ctx->d_consts;
     d.n_const_words = (uint32_t)pp.consts.size();
     d.mds_offset = (uint32_t)pp.mds_offset;
+    d.opt_offset = (uint32_t)pp.opt_offset;
+    d.opt_sparse_offset = (uint32_t)pp.opt_sparse_offset;
+    d.opt_bdense_offset = (uint32_t)pp.opt_bdense_offset;
+    d.has_opt = pp.has_opt ? 1u : 0u;
     d.rounds = pp.c;
     d.field = pp.f;
     d.one = pp.one;

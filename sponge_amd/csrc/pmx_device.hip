@@ -35,7 +35,7 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 // RegEngine: t known at compile time, state in registers (internal field form).
 // LDS: [constants: n_const_words u32, rounded up to 16 B][staging: kThreads * T * 2 uint4]
 // ------------------------------------------------------------------------------------------------
-template <int T, int ALPHA>
+template <int T, int ALPHA, bool OPT>
 struct RegEngine {
     static constexpr int kThreads = 256;
     static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
@@ -44,27 +44,40 @@ struct RegEngine {
     Rounds c;
     FieldRt f;
     Fe one;
-    const uint32_t *ark;  // constants (LDS or global)
-    const uint32_t *mds;
+    OptTables tb;         // constants (LDS or global)
     uint4 *stage;         // LDS staging for coalesced state I/O
 
+    // words of the constant table this engine uses: [mds | ark' | sparse | bdense] or [ark | mds]
+    __host__ __device__ __forceinline__ static uint32_t first_word(const DevConfig &d) { return OPT ? d.mds_offset : 0; }
+    __host__ __device__ __forceinline__ static uint32_t last_word(const DevConfig &d) { return OPT ? d.n_const_words : d.opt_offset; }
+
     static size_t lds_bytes(const DevConfig &d, uint32_t /*t*/) {
-        return (PMX_CONSTS_IN_LDS ? (size_t)((d.n_const_words + 3) / 4) * 16 : 0) + (size_t)kThreads * kChunks * 16;
+        return (PMX_CONSTS_IN_LDS ? (size_t)((last_word(d) - first_word(d) + 3) / 4) * 16 : 0) + (size_t)kThreads * kChunks * 16;
     }
 
     __device__ __forceinline__ explicit RegEngine(const DevConfig &d) : c(d.rounds), f(d.field), one(d.one) {
+        const uint32_t w0 = first_word(d);
 #if PMX_CONSTS_IN_LDS
-        const uint32_t const_chunks = (d.n_const_words + 3) / 4;
-        const uint4 *g = reinterpret_cast<const uint4 *>(d.consts);
+        const uint32_t const_chunks = (last_word(d) - w0 + 3) / 4;
+        const uint4 *g = reinterpret_cast<const uint4 *>(d.consts + w0);   // offsets are multiples of 12 words = 48 B
         for (uint32_t q = threadIdx.x; q < const_chunks; q += kThreads) pmx_lds[q] = g[q];
-        ark = reinterpret_cast<const uint32_t *>(pmx_lds);
+        const uint32_t *base = reinterpret_cast<const uint32_t *>(pmx_lds) - w0;
         stage = pmx_lds + const_chunks;
         __syncthreads();
 #else
-        ark = d.consts;
+        const uint32_t *base = d.consts;
         stage = pmx_lds;
 #endif
-        mds = ark + d.mds_offset;
+        tb.mds = base + d.mds_offset;
+        if constexpr (OPT) {
+            tb.ark = base + d.opt_offset;
+            tb.sparse = base + d.opt_sparse_offset;
+            tb.bdense = base + d.opt_bdense_offset;
+        } else {
+            tb.ark = base;
+            tb.sparse = nullptr;
+            tb.bdense = nullptr;
+        }
     }
 
     __device__ __forceinline__ void zero() {
@@ -132,7 +145,10 @@ struct RegEngine {
         }
     }
 
-    __device__ __forceinline__ void permute() { permute_dense<T, ALPHA>(s, ark, mds, c, one, f); }
+    __device__ __forceinline__ void permute() {
+        if constexpr (OPT) permute_opt<T, ALPHA>(s, tb, c, one, f);
+        else permute_dense<T, ALPHA>(s, tb.ark, tb.mds, c, one, f);
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -403,16 +419,18 @@ struct Launch {
     }
 };
 
-// Engine choice: width 3 runs from registers; every other width uses the LDS-resident engine.
+// Engine choice: width 3 runs from registers, on the optimised schedule whenever its tables exist (the dense
+// schedule remains for configs without a partial section); every other width uses the LDS-resident engine.
 // alpha 5 and 17 have dedicated addition chains, other exponents share the generic S-box.
 #define PMX_DISPATCH(CALL)                                                                  \
     do {                                                                                    \
         const uint64_t alpha = c.rounds.alpha;                                              \
-        if (t == 3) {                                                                       \
-            if (alpha == 5) return Launch<RegEngine<3, 5>>::CALL;                           \
-            if (alpha == 17) return Launch<RegEngine<3, 17>>::CALL;                         \
-            return Launch<RegEngine<3, 0>>::CALL;                                           \
+        if (t == 3 && c.has_opt) {                                                          \
+            if (alpha == 5) return Launch<RegEngine<3, 5, true>>::CALL;                     \
+            if (alpha == 17) return Launch<RegEngine<3, 17, true>>::CALL;                   \
+            return Launch<RegEngine<3, 0, true>>::CALL;                                     \
         }                                                                                   \
+        if (t == 3) return Launch<RegEngine<3, 0, false>>::CALL;                            \
         if (alpha == 5) return Launch<LdsEngine<5>>::CALL;                                  \
         if (alpha == 17) return Launch<LdsEngine<17>>::CALL;                                \
         return Launch<LdsEngine<0>>::CALL;                                                  \

@@ -63,6 +63,8 @@ struct FieldRt {
     uint32_t p32[8];    // modulus, 32-bit limbs (final exact reduction)
     Fe to_int;          // 2^266 mod p, plain integer in 29-bit limbs: ABI -> internal
     Fe to_abi;          // 2^256 mod p, plain integer in 29-bit limbs: internal -> ABI
+    uint32_t two_p[kN]; // 2p, 29-bit limbs (fe_add_weak)
+    uint32_t two_p_thr; // two_p[8] + 2: top-limb threshold above which 2p is subtracted
 };
 
 PMX_FN Fe fe_zero() {
@@ -78,6 +80,27 @@ PMX_FN Fe fe_add_lazy(const Fe &a, const Fe &b) {
 #pragma unroll
     for (int i = 0; i < kN; ++i) r.l[i] = a.l[i] + b.l[i];
     return r;
+}
+
+// u + r with a cheap magnitude cap, for accumulators that are never multiplied down (the identity lanes
+// of the sparse partial rounds).  u norm B < 2.75, r norm B < 1.3  ->  norm, B < 2.1.
+// The (un-normalised) top limb decides whether 2p is subtracted: top >= two_p_thr implies sum > 2p, and
+// otherwise sum < 2p + 3 * 2^232; signed carries then renormalise the limbs.
+PMX_FN Fe fe_add_weak(const Fe &u, const Fe &r, const FieldRt &f) {
+    const bool sub = (u.l[kN - 1] + r.l[kN - 1]) >= f.two_p_thr;
+    Fe out;
+    int32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+        const int32_t d = (int32_t)(u.l[i] + r.l[i]) - (int32_t)(sub ? f.two_p[i] : 0u) + carry;
+        if (i < kN - 1) {
+            out.l[i] = (uint32_t)d & kMask;
+            carry = d >> kW;   // arithmetic shift: borrows propagate as -1
+        } else {
+            out.l[i] = (uint32_t)d;
+        }
+    }
+    return out;
 }
 
 // carry propagation: any limbs < 2^32 (value < 2^261) -> norm

@@ -111,6 +111,14 @@ struct HostField {
         return out;
     }
 
+    U256 neg(const U256 &a) const {
+        if (u256_is_zero(a)) return a;
+        U256 d;
+        u256_sub(d, p, a);
+        return d;
+    }
+    U256 sub(const U256 &a, const U256 &b) const { return add(a, neg(b)); }
+
     U256 to_mont(const U256 &x) const { return mul(x, r2); }
     U256 from_mont(const U256 &x) const {
         U256 one = {{1, 0, 0, 0}};

@@ -13,9 +13,11 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 // Kernel-argument block of a validated config (see pmx_prepare.hpp).  The constant table lives in device
 // memory in the internal field form: ark [rounds][t][kFeStride] words, then mds [t][t][kFeStride] words.
 struct DevConfig {
-    const uint32_t *consts;   // device
+    const uint32_t *consts;   // device; layout: pmx_prepare.hpp Prepared::consts
     uint32_t n_const_words;   // words in consts
-    uint32_t mds_offset;      // word offset of the MDS matrix inside consts
+    uint32_t mds_offset;      // word offsets inside consts
+    uint32_t opt_offset, opt_sparse_offset, opt_bdense_offset;
+    uint32_t has_opt;         // optimised schedule tables present
     Rounds rounds;
     FieldRt field;
     Fe one;                   // 2^261 mod p

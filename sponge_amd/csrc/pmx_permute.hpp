@@ -7,7 +7,19 @@
 #pragma once
 #include "pmx_field.hpp"
 
+#include <type_traits>
+
 namespace pmx {
+
+// Guaranteed compile-time unrolling of the element loops (#pragma unroll gives up on bodies this large, and a
+// rolled loop would index the register-resident state dynamically, i.e. push it to scratch memory).
+template <int I, int N, class F>
+PMX_FN void static_for(F &&fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(fn);
+    }
+}
 
 // Wave-uniform scalars of a config (by value: SGPRs).
 struct Rounds {
@@ -28,19 +40,74 @@ PMX_FN void permute_dense(Fe (&s)[T], const uint32_t *ark, const uint32_t *mds, 
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = ark + (size_t)r * T * kFeStride;
         Fe y[T];
-#pragma unroll
-        for (int i = 0; i < T; ++i) y[i] = fe_add_lazy(s[i], fe_const(rk + i * kFeStride));   // lazy, B < 2.3
+        static_for<0, T>([&](auto i) { y[i] = fe_add_lazy(s[i], fe_const(rk + i * kFeStride)); });   // lazy, B < 2.3
         y[0] = fe_sbox<ALPHA>(y[0], c.alpha, one, f);
         if (is_full_round(r, c)) {
-#pragma unroll
-            for (int i = 1; i < T; ++i) y[i] = fe_sbox<ALPHA>(y[i], c.alpha, one, f);
+            static_for<1, T>([&](auto i) { y[i] = fe_sbox<ALPHA>(y[i], c.alpha, one, f); });
         }
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
+        static_for<0, T>([&](auto i) {
             Fe row[T];
-#pragma unroll
-            for (int j = 0; j < T; ++j) row[j] = fe_const(mds + ((size_t)i * T + j) * kFeStride);
+            static_for<0, T>([&](auto j) { row[j] = fe_const(mds + ((size_t)i * T + j) * kFeStride); });
             s[i] = mont_dot<T>(y, row, f);   // new[i] = sum_j mds[i][j] * y[j], one reduction
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Optimised schedule (exact algebraic rewrite of the same permutation; Poseidon paper, appendix B):
+// the RP partial rounds only touch state[0] non-linearly, so a change of basis on lanes 1..t-1 turns each
+// partial-round matrix into  [[m00, v^T], [w, I]]  (2t-1 products instead of t^2) and moves the round
+// constants of lanes 1..t-1 out of the partial section.  The host derives the tables (pmx_prepare.hpp):
+//   ark      [total_rounds][T]  as before, except: partial round k keeps only lane 0 (= e_k), and the first
+//            full round after the partial section has the deferred constants folded in
+//   sparse   [RP-1][2T-1]       per partial round k < RP-1: row0[T] = (m00, v), then w[T-1]
+//   bdense   [T][T]             matrix of the last partial round (M times the accumulated basis change)
+// Outputs are identical mod p to the dense schedule.
+struct OptTables {
+    const uint32_t *ark, *mds, *sparse, *bdense;
+};
+
+template <int T, int ALPHA>
+PMX_FN void full_round(Fe (&s)[T], const uint32_t *rk, const uint32_t *mat, const Rounds &c, const Fe &one,
+                       const FieldRt &f) {
+    Fe y[T];
+    static_for<0, T>([&](auto i) {
+        y[i] = fe_sbox<ALPHA>(fe_add_lazy(s[i], fe_const(rk + i * kFeStride)), c.alpha, one, f);
+    });
+    static_for<0, T>([&](auto i) {
+        Fe row[T];
+        static_for<0, T>([&](auto j) { row[j] = fe_const(mat + ((size_t)i * T + j) * kFeStride); });
+        s[i] = mont_dot<T>(y, row, f);
+    });
+}
+
+template <int T, int ALPHA>
+PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
+    const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
+    for (uint32_t r = 0; r < c.total_rounds; ++r) {
+        const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
+        if (r < first_partial || r > last_partial) {
+            full_round<T, ALPHA>(s, rk, tb.mds, c, one, f);
+            continue;
+        }
+        // partial round: lanes 1..T-1 stay norm with B < 2.1 (fe_add_weak); lane 0 is re-derived every round
+        Fe z[T];
+        z[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
+        static_for<1, T>([&](auto i) { z[i] = s[i]; });
+        if (r < last_partial) {
+            const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
+            Fe row[T];
+            static_for<0, T>([&](auto j) { row[j] = fe_const(sp + j * kFeStride); });
+            s[0] = mont_dot<T>(z, row, f);
+            static_for<1, T>([&](auto i) {
+                s[i] = fe_add_weak(s[i], mont_mul(z[0], fe_const(sp + (T + i - 1) * kFeStride), f), f);
+            });
+        } else {   // last partial round: dense matrix B
+            static_for<0, T>([&](auto i) {
+                Fe row[T];
+                static_for<0, T>([&](auto j) { row[j] = fe_const(tb.bdense + ((size_t)i * T + j) * kFeStride); });
+                s[i] = mont_dot<T>(z, row, f);
+            });
         }
     }
 }

@@ -33,9 +33,133 @@ struct Prepared {
     Fe one;                         // 2^261 mod p
     Rounds c;
     uint32_t t;
-    std::vector<uint32_t> consts;   // ark [rounds][t][kFeStride] | mds [t][t][kFeStride]
-    size_t mds_offset;              // in words
+    // one table, kFeStride words per element, offsets in words:
+    //   [0, mds_offset)            ark      [rounds][t]      dense schedule
+    //   [mds_offset, opt_offset)   mds      [t][t]
+    //   -- only when has_opt (see pmx_permute.hpp: OptTables) --
+    //   opt_offset                 ark'     [rounds][t]
+    //   opt_sparse_offset          sparse   [RP-1][2t-1]
+    //   opt_bdense_offset          bdense   [t][t]
+    std::vector<uint32_t> consts;
+    size_t mds_offset;
+    bool has_opt;
+    size_t opt_offset, opt_sparse_offset, opt_bdense_offset;
 };
+
+// ---- small dense linear algebra over the ABI Montgomery form (host only) ----------------------------------------
+typedef std::vector<std::vector<U256>> HostMat;
+
+inline HostMat mat_identity(const HostField &f, size_t n) {
+    HostMat m(n, std::vector<U256>(n, U256{{0, 0, 0, 0}}));
+    for (size_t i = 0; i < n; ++i) m[i][i] = f.r;
+    return m;
+}
+
+inline HostMat mat_mul(const HostField &f, const HostMat &a, const HostMat &b) {
+    const size_t n = a.size(), k = b.size(), m = b[0].size();
+    HostMat r(n, std::vector<U256>(m, U256{{0, 0, 0, 0}}));
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < m; ++j)
+            for (size_t l = 0; l < k; ++l) r[i][j] = f.add(r[i][j], f.mul(a[i][l], b[l][j]));
+    return r;
+}
+
+inline std::vector<U256> mat_vec(const HostField &f, const HostMat &a, const std::vector<U256> &v) {
+    std::vector<U256> r(a.size(), U256{{0, 0, 0, 0}});
+    for (size_t i = 0; i < a.size(); ++i)
+        for (size_t j = 0; j < v.size(); ++j) r[i] = f.add(r[i], f.mul(a[i][j], v[j]));
+    return r;
+}
+
+// Gauss-Jordan inverse; false if singular
+inline bool mat_inverse(const HostField &f, HostMat a, HostMat &inv) {
+    const size_t n = a.size();
+    inv = mat_identity(f, n);
+    for (size_t col = 0; col < n; ++col) {
+        size_t piv = col;
+        while (piv < n && u256_is_zero(a[piv][col])) ++piv;
+        if (piv == n) return false;
+        std::swap(a[piv], a[col]);
+        std::swap(inv[piv], inv[col]);
+        const U256 d = f.inverse(a[col][col]);
+        for (size_t j = 0; j < n; ++j) {
+            a[col][j] = f.mul(a[col][j], d);
+            inv[col][j] = f.mul(inv[col][j], d);
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (i == col || u256_is_zero(a[i][col])) continue;
+            const U256 k = a[i][col];
+            for (size_t j = 0; j < n; ++j) {
+                a[i][j] = f.sub(a[i][j], f.mul(k, a[col][j]));
+                inv[i][j] = f.sub(inv[i][j], f.mul(k, inv[col][j]));
+            }
+        }
+    }
+    return true;
+}
+
+// Derives the tables of the optimised schedule from (ark, mds).  Notation of pmx_permute.hpp / DESIGN.md:
+// basis change N_k = diag(1, Nh_k) on lanes 1..t-1, Nh_0 = I;  B_k = M N_k;  for k < RP-1: Nh_{k+1} = lower-right
+// block of B_k, sparse_k = N_{k+1}^-1 B_k = [[b00, bv],[Bh^-1 bw, I]].  Round constants of lanes 1.. are deferred
+// (vector D) and re-enter through lane 0 (e_k) and through the first full round after the partial section.
+inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full, uint32_t rp, uint32_t rounds,
+                              const std::vector<U256> &ark, const HostMat &M, std::vector<U256> &ark_opt,
+                              std::vector<U256> &sparse, std::vector<U256> &bdense) {
+    if (rp == 0 || half_full == 0 || t < 2 || half_full + rp >= rounds) return false;
+    const size_t n = t - 1;
+    const U256 zero = {{0, 0, 0, 0}};
+    ark_opt = ark;
+    sparse.assign((size_t)(rp - 1) * (2 * t - 1), zero);
+    HostMat Nh = mat_identity(f, n);
+    HostMat B;
+    // D_0 = c_0[1:], e_0 = c_0[0]
+    std::vector<U256> D(n);
+    {
+        const size_t r0 = (size_t)half_full * t;
+        for (size_t i = 0; i < n; ++i) { D[i] = ark[r0 + 1 + i]; ark_opt[r0 + 1 + i] = zero; }
+    }
+    for (uint32_t k = 0; k < rp; ++k) {
+        // B = M * diag(1, Nh)
+        B.assign(t, std::vector<U256>(t, zero));
+        for (size_t i = 0; i < t; ++i) {
+            B[i][0] = M[i][0];
+            for (size_t j = 0; j < n; ++j)
+                for (size_t l = 0; l < n; ++l) B[i][1 + j] = f.add(B[i][1 + j], f.mul(M[i][1 + l], Nh[l][j]));
+        }
+        if (k + 1 == rp) break;
+        HostMat Bh(n, std::vector<U256>(n)), Bh_inv;
+        for (size_t i = 0; i < n; ++i)
+            for (size_t j = 0; j < n; ++j) Bh[i][j] = B[1 + i][1 + j];
+        if (!mat_inverse(f, Bh, Bh_inv)) return false;
+        U256 *sp = &sparse[(size_t)k * (2 * t - 1)];
+        for (size_t j = 0; j < t; ++j) sp[j] = B[0][j];                  // row0 = (b00, bv)
+        std::vector<U256> bw(n);
+        for (size_t i = 0; i < n; ++i) bw[i] = B[1 + i][0];
+        const std::vector<U256> w = mat_vec(f, Bh_inv, bw);              // Bh^-1 bw
+        for (size_t i = 0; i < n; ++i) sp[t + i] = w[i];
+        // constants of the next partial round in the new basis
+        const size_t rn = (size_t)(half_full + k + 1) * t;
+        std::vector<U256> c1(n);
+        for (size_t i = 0; i < n; ++i) c1[i] = ark[rn + 1 + i];
+        const std::vector<U256> ct = mat_vec(f, Bh_inv, c1);
+        U256 e = ark[rn];
+        for (size_t j = 0; j < n; ++j) e = f.add(e, f.mul(B[0][1 + j], D[j]));   // + bv . D_k
+        ark_opt[rn] = e;
+        for (size_t i = 0; i < n; ++i) { ark_opt[rn + 1 + i] = zero; D[i] = f.add(D[i], ct[i]); }
+        Nh = Bh;
+    }
+    bdense.assign((size_t)t * t, zero);
+    for (size_t i = 0; i < t; ++i)
+        for (size_t j = 0; j < t; ++j) bdense[i * t + j] = B[i][j];
+    // E = B [0; D] joins the constants of the first full round after the partial section
+    const size_t rf = (size_t)(half_full + rp) * t;
+    for (size_t i = 0; i < t; ++i) {
+        U256 e = zero;
+        for (size_t j = 0; j < n; ++j) e = f.add(e, f.mul(B[i][1 + j], D[j]));
+        ark_opt[rf + i] = f.add(ark[rf + i], e);
+    }
+    return true;
+}
 
 // Returns PMX_OK or an error code with a message in `err`.
 inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
@@ -65,7 +189,33 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         }
         to_limbs29(times_pow2(hf, v, 5), &out.consts[k * kFeStride]);   // x*2^256 -> x*2^261
     }
+    // optimised schedule
+    {
+        std::vector<U256> ark(n_ark), ark_opt, sparse, bdense;
+        for (size_t k = 0; k < n_ark; ++k) std::memcpy(ark[k].l, cfg->ark + 4 * k, 32);
+        HostMat M(t, std::vector<U256>(t));
+        for (size_t i = 0; i < t; ++i)
+            for (size_t j = 0; j < t; ++j) std::memcpy(M[i][j].l, cfg->mds + 4 * (i * t + j), 32);
+        out.has_opt = derive_opt_tables(hf, t, cfg->full_rounds / 2, cfg->partial_rounds, (uint32_t)rounds, ark, M,
+                                        ark_opt, sparse, bdense);
+        out.opt_offset = out.consts.size();
+        out.opt_sparse_offset = out.opt_bdense_offset = out.opt_offset;
+        if (out.has_opt) {
+            out.opt_sparse_offset = out.opt_offset + n_ark * kFeStride;
+            out.opt_bdense_offset = out.opt_sparse_offset + sparse.size() * kFeStride;
+            out.consts.resize(out.opt_bdense_offset + bdense.size() * kFeStride, 0u);
+            size_t k = out.opt_offset / kFeStride;
+            for (const auto *vec : {&ark_opt, &sparse, &bdense})
+                for (const U256 &v : *vec) to_limbs29(times_pow2(hf, v, 5), &out.consts[(k++) * kFeStride]);
+        }
+    }
     FieldRt &f = out.f;
+    {
+        U256 two_p;
+        u256_add(two_p, hf.p, hf.p);   // p < 2^255: no carry
+        to_limbs29(two_p, f.two_p);
+        f.two_p_thr = f.two_p[kN - 1] + 2;
+    }
     to_limbs29(hf.p, f.p);
     f.pinv = (uint32_t)hf.inv & kMask;
     std::memcpy(f.p32, hf.p.l, 32);

@@ -25,6 +25,7 @@ def hc():
     lib = ctypes.CDLL(os.path.join(HERE, "libpmx_hostcheck.so"))
     lib.hc_permute.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_rt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    lib.hc_permute_opt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_field_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_sqr_column.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
@@ -77,7 +78,7 @@ def test_column_accumulators_cannot_overflow(hc):
     assert int(hi[0]) == 0
 
 
-def run_permute(hc, name, states, rt=False):
+def run_permute(hc, name, states, rt=False, opt=False):
     cfg = oracle_config(name)
     p = cfg.p
     ark = mont_limbs([v for row in cfg.ark for v in row], p)
@@ -90,7 +91,7 @@ def run_permute(hc, name, states, rt=False):
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
     out = np.ascontiguousarray(states, dtype=np.uint64).copy()
     n = out.size // (cfg.t * 4)
-    fn = hc.hc_permute_rt if rt else hc.hc_permute
+    fn = hc.hc_permute_opt if opt else (hc.hc_permute_rt if rt else hc.hc_permute)
     assert fn(ctypes.byref(c), out.ctypes.data, n) == 0
     return out
 
@@ -106,6 +107,8 @@ def test_permutation_templates_match_golden(hc, name):
     for rt in (False, True):     # compile-time-width template and run-time-width (LDS engine) template
         out = run_permute(hc, name, states, rt=rt)
         assert cref.limbs_to_elems(out, cfg.p) == want, ("rt" if rt else "static")
+    out = run_permute(hc, name, states, opt=True)     # optimised schedule (sparse partial rounds)
+    assert cref.limbs_to_elems(out, cfg.p) == want, "opt"
 
 
 def test_permutation_templates_match_c_oracle_on_random_batch(hc):
@@ -113,6 +116,6 @@ def test_permutation_templates_match_c_oracle_on_random_batch(hc):
     import sponge_amd as S
     for name, f in [("bls_t3_a5_8_31", S.BLS12_381_FR), ("bn254_t3_a5_8_57", S.BN254_FR)]:
         states = synth.random_elements(f, 512 * 3, seed=77).reshape(512, 3, 4)
-        got = run_permute(hc, name, states)
         want = cref.CRef(oracle_config(name)).permute_batch(states, threads=0)
-        assert np.array_equal(got, want)
+        assert np.array_equal(run_permute(hc, name, states), want)
+        assert np.array_equal(run_permute(hc, name, states, opt=True), want)
