@@ -28,11 +28,33 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
+VALU_MAD_PEAK = 3.19e13       # v_mad_u64_u32 lane-instructions/s, measured (profiles/r01/valu_microbench.txt)
+
 WORKLOADS = {
-    # name: (field, rate, alpha, RF, RP, log2 states per GPU, seed, description)
+    # name: (field, rate, alpha, RF, RP, log2 units per GPU, seed, description)
     "c2": ("bls12_381_fr", 2, 5, 8, 31, 20, 0x5EED0002, "bls12_381_fr t=3 alpha=5 RF=8 RP=31, 2^20 states/GPU"),
     "c3": ("bn254_fr", 8, 5, 8, 57, 18, 0x5EED0003, "bn254_fr t=9 alpha=5 RF=8 RP=57, 2^18 states/GPU"),
+    # 2-to-1 Merkle compression: every rank reduces its own 2^21-leaf subtree level by level (2^21 - 1
+    # permutations), the subtree roots are all-gathered and the top log2(N) levels finished on every rank
+    "c5": ("bls12_381_fr", 2, 5, 8, 31, 21, 0x5EED0005, "bls12_381_fr t=3 alpha=5 2-to-1 Merkle tree, 2^21 leaves/GPU"),
 }
+
+
+def mads_per_permutation(t, alpha, rf, rp, optimised):
+    """v_mad_u64_u32 count of one permutation as implemented (pmx_field.hpp): product 81, square 45,
+    reduction 81 limb products; one reduction per S-box step and per matrix row."""
+    sqr, mul = 45 + 81, 81 + 81
+    chain = {5: 2 * sqr + mul, 17: 4 * sqr + mul}.get(alpha)
+    if chain is None:
+        bits = bin(alpha)[3:]
+        chain = len(bits) * sqr + bits.count("1") * mul
+    dot = 81 * t + 81
+    full = t * chain + t * dot
+    if optimised:
+        partial = (rp - 1) * (chain + dot + (t - 1) * mul) + (chain + t * dot)
+    else:
+        partial = rp * (chain + t * dot)
+    return rf * full + partial
 
 
 def parse_args():
@@ -115,33 +137,54 @@ def main():
     cfg = S.poseidon_config_from_lfsr(field, rate, alpha, rf, rp)
     ctx = cfg.context(local_rank)
 
-    # this rank's shard of the global seeded batch [world*n][t][4]
-    host = synth.random_elements(field, n * t, seed, offset=rank * n * t)
-    n_buf = 2 if (world > 1 and args.gather == "overlap") else 1
-    bufs = [torch.from_numpy(host.view(np.int64).copy()).to(dev).reshape(n, t, 4) for _ in range(n_buf)]
-    gathered = [torch.empty((world * n, t, 4), dtype=torch.int64, device=dev) for _ in range(n_buf)] \
-        if (world > 1 and args.gather != "none") else None
-    pending = [None] * n_buf
+    from sponge_amd import distributed as D
+
     stream = torch.cuda.current_stream()
+    merkle = args.workload == "c5"
+    if merkle:
+        # leaves of this rank's subtree, resident in the first n rows of the node array [2n-1][4]
+        host = synth.random_elements(field, n, seed, offset=rank * n)
+        nodes = torch.zeros((2 * n - 1, 4), dtype=torch.int64, device=dev)
+        nodes[:n] = torch.from_numpy(host.view(np.int64).copy()).to(dev)
+        top = torch.zeros((2 * world - 1, 4), dtype=torch.int64, device=dev)
+        units_per_step = float(world) * (n - 1) + (world - 1)          # permutations per step, all ranks
 
-    def step(i):
-        b = i % n_buf
-        if pending[b] is not None:           # the gather that still reads this buffer
-            pending[b].wait()
-            pending[b] = None
-        ctx.permute_batch_dev(bufs[b].data_ptr(), n, stream.cuda_stream)
-        if gathered is not None:
-            work = dist.all_gather_into_tensor(gathered[b].view(-1), bufs[b].view(-1), async_op=True)
-            if args.gather == "serial":
-                work.wait()
-            else:
-                pending[b] = work
+        def step(i):
+            ctx.merkle_2to1_dev(nodes.data_ptr(), n, stream.cuda_stream)
+            if world > 1:
+                top[:world] = D.all_gather_equal(nodes[2 * n - 2:2 * n - 1])   # 32-byte subtree roots
+                ctx.merkle_2to1_dev(top.data_ptr(), world, stream.cuda_stream)
 
-    def drain():
-        for b in range(n_buf):
-            if pending[b] is not None:
+        def drain():
+            pass
+    else:
+        # this rank's shard of the global seeded batch [world*n][t][4]
+        host = synth.random_elements(field, n * t, seed, offset=rank * n * t)
+        n_buf = 2 if (world > 1 and args.gather == "overlap") else 1
+        bufs = [torch.from_numpy(host.view(np.int64).copy()).to(dev).reshape(n, t, 4) for _ in range(n_buf)]
+        gathered = [torch.empty((world * n, t, 4), dtype=torch.int64, device=dev) for _ in range(n_buf)] \
+            if (world > 1 and args.gather != "none") else None
+        pending = [None] * n_buf
+        units_per_step = float(world) * n
+
+        def step(i):
+            b = i % n_buf
+            if pending[b] is not None:           # the gather that still reads this buffer
                 pending[b].wait()
                 pending[b] = None
+            ctx.permute_batch_dev(bufs[b].data_ptr(), n, stream.cuda_stream)
+            if gathered is not None:
+                _, work = D.all_gather_equal(bufs[b], out=gathered[b], async_op=True)
+                if args.gather == "serial":
+                    work.wait()
+                else:
+                    pending[b] = work
+
+        def drain():
+            for b in range(n_buf):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
 
     def barrier():
         if world > 1:
@@ -169,25 +212,31 @@ def main():
     elapsed, dev_s = float(times[0]), float(times[1])
 
     if rank == 0:
-        perms = float(world) * n * args.steps
-        value = perms / elapsed
-        # dominant kernel: permute_kernel; its average launch duration from the HIP events of this rank's
-        # stream (at N=1 the timed region holds nothing but the K back-to-back launches)
+        value = units_per_step * args.steps / elapsed
+        # dominant kernel: permute_kernel (hash_kernel in the Merkle mode); its average launch duration from the
+        # HIP events on this rank's launch stream (at N=1 the timed region holds nothing but the back-to-back launches)
         kernel_s = dev_s / args.steps
-        algo_bytes = 2 * t * 32 * n                       # 2*t*32 B per permutation, n per launch
+        per_gpu_units = units_per_step / world
+        bytes_per_unit = 96 if merkle else 2 * t * 32       # 2*t*32 B per permutation; 64 in + 32 out per 2-to-1
+        algo_bytes = bytes_per_unit * per_gpu_units
         achieved = algo_bytes / kernel_s / 1e9
+        mads = mads_per_permutation(t, alpha, rf, rp, optimised=(t == 3)) + (3 if merkle else 2 * t) * 162   # + ABI conversions
+        mad_rate = mads * per_gpu_units / kernel_s
         out = {
             "metric": "Poseidon permutations/sec", "value": value, "unit": "permutations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32-limb Montgomery (256-bit modular integer)", "data": "synthetic",
-            "config": {"workload": desc, "states_per_gpu": n, "total_states": world * n,
-                       "gather": (args.gather if world > 1 else "n/a"), "sharding": f"contiguous x{world}"},
+            "vs_baseline": None, "dtype": "u32 (9x29-bit limb Montgomery, 255-bit modular integers)", "data": "synthetic",
+            "config": {"workload": desc, "units_per_gpu": n, "permutations_per_step": units_per_step,
+                       "gather": (args.gather if (world > 1 and not merkle) else ("roots" if merkle and world > 1 else "n/a")),
+                       "sharding": f"contiguous x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
-                         "kernel": "pmx::permute_kernel", "kernel_ms": 1e3 * kernel_s,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "integer-VALU bound, not HBM bound: see DESIGN.md (v_mad_u64_u32 roofline)"},
+                         "kernel": "pmx::hash_kernel (per tree level)" if merkle else "pmx::permute_kernel",
+                         "kernel_ms": 1e3 * kernel_s, "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "integer-VALU bound, not HBM bound (DESIGN.md): see int_valu"},
+            "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": VALU_MAD_PEAK,
+                         "unit": "lane-instr/s", "frac": mad_rate / VALU_MAD_PEAK, "mads_per_permutation": mads},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(field_name, rate, alpha, rf, rp, seed, args.cpu_seconds)

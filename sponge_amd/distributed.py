@@ -1,0 +1,41 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).  Sponge states are independent (reference src/poseidon/mod.rs:62-183 has no
+cross-state data flow), so the batch is cut into contiguous shards and there is NO collective on the data
+path; RCCL is used only for the final gather of results (and for the 32-byte subtree roots of the Merkle mode).
+"""
+from __future__ import annotations
+
+from typing import Callable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous partition: rank g owns [start, start+count); the first n_total % world ranks get one more."""
+    base, extra = divmod(n_total, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def all_gather_equal(local: torch.Tensor, out: torch.Tensor | None = None, async_op: bool = False):
+    """All-gather of equally sized shards into [world * n, ...] in rank order (ring/direct all-gather by RCCL)."""
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), async_op=async_op)
+    return (out, work) if async_op else out
+
+
+def merkle_root_sharded(leaves_local: torch.Tensor, subtree_root: Callable[[torch.Tensor], torch.Tensor],
+                        ) -> torch.Tensor:
+    """2-to-1 Merkle root of world * m leaves, m a power of two per rank, world a power of two.
+    Every rank reduces its own contiguous subtree with `subtree_root` (the GPU tree kernel), the 32-byte
+    subtree roots are all-gathered, and every rank finishes the top log2(world) levels with the same function."""
+    world = dist.get_world_size()
+    assert world & (world - 1) == 0, "world size must be a power of two"
+    root_local = subtree_root(leaves_local).reshape(1, 4)
+    if world == 1:
+        return root_local.reshape(4)
+    roots = all_gather_equal(root_local)              # [world][4], rank order = leaf order
+    return subtree_root(roots).reshape(4)

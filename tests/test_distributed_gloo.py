@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercise the sharding, the final gather and the sharded
+Merkle reduction exactly as bench.py drives them on GPUs (there the per-rank engine is the HIP library; here
+the oracle's C restatement stands in as the per-rank engine so that no GPU is needed)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import sponge_amd as S
+from sponge_amd import distributed as D
+from sponge_amd import synth
+from oracle import cref
+
+from helpers import oracle_config
+
+WORLD = 2
+N_PER_RANK = 256
+SEED = 0x5EED0004
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        f = S.BLS12_381_FR
+        cr = cref.CRef(oracle_config("bls_t3_a5_8_31"))
+        t = 3
+        start, count = D.shard_bounds(WORLD * N_PER_RANK, WORLD, rank)
+        assert count == N_PER_RANK and start == rank * N_PER_RANK
+        # 1. sharded permutation + final gather
+        shard = synth.random_elements(f, count * t, SEED, offset=start * t).reshape(count, t, 4)
+        out_local = cr.permute_batch(shard, threads=1)
+        gathered = D.all_gather_equal(torch.from_numpy(out_local.view(np.int64)))
+        # 2. sharded Merkle root
+        leaves = synth.random_elements(f, count, SEED + 1, offset=start)
+
+        def subtree_root(x: torch.Tensor) -> torch.Tensor:
+            nodes = cr.merkle(x.numpy().view(np.uint64).reshape(-1, 4), threads=1)
+            return torch.from_numpy(nodes[-1].view(np.int64).copy())
+
+        root = D.merkle_root_sharded(torch.from_numpy(leaves.view(np.int64)), subtree_root)
+        if rank == 0:
+            results["gathered"] = gathered.numpy().view(np.uint64).copy()
+            results["root"] = root.numpy().view(np.uint64).copy()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_gather_and_merkle():
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(_free_port(), results), nprocs=WORLD, join=True)
+    f = S.BLS12_381_FR
+    cr = cref.CRef(oracle_config("bls_t3_a5_8_31"))
+    whole = synth.random_elements(f, WORLD * N_PER_RANK * 3, SEED).reshape(WORLD * N_PER_RANK, 3, 4)
+    assert np.array_equal(results["gathered"].reshape(-1, 3, 4), cr.permute_batch(whole, threads=2))
+    leaves = synth.random_elements(f, WORLD * N_PER_RANK, SEED + 1)
+    assert np.array_equal(results["root"].reshape(4), cr.merkle(leaves, threads=2)[-1])
+
+
+@pytest.mark.parametrize("n,world", [(10, 3), (8, 8), (7, 8), (1 << 24, 8), (5, 1)])
+def test_shard_bounds_partition(n, world):
+    spans = [D.shard_bounds(n, world, r) for r in range(world)]
+    assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+    for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+        assert s0 + c0 == s1
+    assert max(c for _, c in spans) - min(c for _, c in spans) <= 1

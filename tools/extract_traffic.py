@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) into HBM bytes per launch of
+the dominant kernel, with the gfx950 corrections of MI355X_MICROARCH.md section HBM: both counters are in KiB,
+and FETCH_SIZE reports exactly half of a wide (16 B/lane) coalesced read stream, so it is doubled.
+usage: extract_traffic.py <fetch_dir> <write_dir> <kernel-substring> <workload> <out.json>"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_launch(directory, counter, kernel_sub):
+    vals = []
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row.get("Counter_Name") == counter and kernel_sub in row.get("Kernel_Name", ""):
+                vals.append(float(row["Counter_Value"]))
+    return vals
+
+
+def main():
+    fetch_dir, write_dir, kernel_sub, workload, out = sys.argv[1:6]
+    fetch = per_launch(fetch_dir, "FETCH_SIZE", kernel_sub)
+    write = per_launch(write_dir, "WRITE_SIZE", kernel_sub)
+    if not fetch or not write:
+        raise SystemExit(f"no counter rows found (fetch {len(fetch)}, write {len(write)})")
+    f_kib = sorted(fetch)[len(fetch) // 2]
+    w_kib = sorted(write)[len(write) // 2]
+    rec = {"kernel": kernel_sub, "launches_seen": [len(fetch), len(write)],
+           "FETCH_SIZE_KiB_median": f_kib, "WRITE_SIZE_KiB_median": w_kib,
+           "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 64 B per 128 B request)",
+           "bytes_per_launch": (2 * f_kib + w_kib) * 1024}
+    data = {}
+    if os.path.exists(out):
+        data = json.load(open(out))
+    data[workload] = rec
+    json.dump(data, open(out, "w"), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
