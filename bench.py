@@ -220,7 +220,7 @@ def main():
         bytes_per_unit = 96 if merkle else 2 * t * 32       # 2*t*32 B per permutation; 64 in + 32 out per 2-to-1
         algo_bytes = bytes_per_unit * per_gpu_units
         achieved = algo_bytes / kernel_s / 1e9
-        mads = mads_per_permutation(t, alpha, rf, rp, optimised=(t == 3)) + (3 if merkle else 2 * t) * 162   # + ABI conversions
+        mads = mads_per_permutation(t, alpha, rf, rp, optimised=(t == 3 or (4 <= t <= 9 and alpha == 5))) + (3 if merkle else 2 * t) * 162   # + ABI conversions
         mad_rate = mads * per_gpu_units / kernel_s
         out = {
             "metric": "Poseidon permutations/sec", "value": value, "unit": "permutations/s",

@@ -152,6 +152,110 @@ struct RegEngine {
 };
 
 // ------------------------------------------------------------------------------------------------
+// HybridEngine: t = 4..9 on the optimised schedule.  State in registers (9t VGPRs); one wave per workgroup
+// with one LDS scratch array [element][limb][lane] (2.25 t KiB) that gives the rolled element loops of the full
+// rounds their dynamic indexing (pmx_permute.hpp: permute_hybrid) and doubles as the staging area of the
+// coalesced ABI load/store.  Constants come through the scalar cache (the table is up to 80 KiB at t = 9).
+// ------------------------------------------------------------------------------------------------
+template <int T, int ALPHA>
+struct HybridEngine {
+    static constexpr int kThreads = 64;
+    static constexpr int kChunks = 2 * T;
+
+    struct Scratch {
+        uint32_t *base;   // + lane
+        __device__ __forceinline__ Fe get(uint32_t i) const {
+            Fe r;
+#pragma unroll
+            for (int w = 0; w < kN; ++w) r.l[w] = base[(i * kN + w) * 64];
+            return r;
+        }
+        __device__ __forceinline__ void set(uint32_t i, const Fe &v) {
+#pragma unroll
+            for (int w = 0; w < kN; ++w) base[(i * kN + w) * 64] = v.l[w];
+        }
+    };
+
+    Fe s[T];
+    Rounds c;
+    FieldRt f;
+    Fe one;
+    OptTables tb;
+    Scratch sc;
+
+    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return (size_t)T * kN * 64 * 4; }
+
+    __device__ __forceinline__ explicit HybridEngine(const DevConfig &d) : c(d.rounds), f(d.field), one(d.one) {
+        tb.mds = d.consts + d.mds_offset;
+        tb.ark = d.consts + d.opt_offset;
+        tb.sparse = d.consts + d.opt_sparse_offset;
+        tb.bdense = d.consts + d.opt_bdense_offset;
+        sc.base = reinterpret_cast<uint32_t *>(pmx_lds) + threadIdx.x;
+    }
+
+    __device__ __forceinline__ void zero() {
+        static_for<0, T>([&](auto i) { s[i] = fe_zero(); });
+    }
+
+    __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
+        const size_t first = (size_t)blockIdx.x * kThreads;
+        const size_t valid = n > first ? (n - first < (size_t)kThreads ? n - first : (size_t)kThreads) : 0;
+        const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + first * kChunks;
+        const uint32_t n_chunks = (uint32_t)valid * kChunks;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            const uint32_t q = threadIdx.x + k * kThreads;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < n_chunks) v = g[q];
+            pmx_lds[q] = v;
+        }
+        __syncthreads();
+        Abi a[T];
+        static_for<0, T>([&](auto i) { a[i] = abi_from_u4(pmx_lds[threadIdx.x * kChunks + 2 * i], pmx_lds[threadIdx.x * kChunks + 2 * i + 1]); });
+        __syncthreads();   // the staging area is the scratch array: finish reading before anyone writes slots
+        static_for<0, T>([&](auto i) { s[i] = fe_from_abi(a[i], f); });
+    }
+
+    __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {
+        const size_t first = (size_t)blockIdx.x * kThreads;
+        const size_t valid = n > first ? (n - first < (size_t)kThreads ? n - first : (size_t)kThreads) : 0;
+        uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * kChunks;
+        const uint32_t n_chunks = (uint32_t)valid * kChunks;
+        __syncthreads();
+        static_for<0, T>([&](auto i) {
+            const Abi a = fe_to_abi(s[i], f);
+            pmx_lds[threadIdx.x * kChunks + 2 * i] = abi_lo(a);
+            pmx_lds[threadIdx.x * kChunks + 2 * i + 1] = abi_hi(a);
+        });
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            const uint32_t q = threadIdx.x + k * kThreads;
+            if (q < n_chunks) g[q] = pmx_lds[q];
+        }
+        __syncthreads();
+    }
+
+    __device__ __forceinline__ Fe get(uint32_t i) const {
+        Fe r = s[0];
+        static_for<1, T>([&](auto k) {
+#pragma unroll
+            for (int w = 0; w < kN; ++w) r.l[w] = (i == (uint32_t)k) ? s[k].l[w] : r.l[w];
+        });
+        return r;
+    }
+    __device__ __forceinline__ void set(uint32_t i, const Fe &v) {
+        static_for<0, T>([&](auto k) {
+#pragma unroll
+            for (int w = 0; w < kN; ++w) s[k].l[w] = (i == (uint32_t)k) ? v.l[w] : s[k].l[w];
+        });
+    }
+
+    __device__ __forceinline__ void permute() { permute_hybrid<T, ALPHA>(s, sc, tb, c, one, f); }
+};
+
+// ------------------------------------------------------------------------------------------------
 // LdsEngine: width is a run-time value.  Each wave keeps its 64 states in LDS as
 // cur[(element * 9 + limb) * 64 + lane] u32, with a second buffer for the MDS output.
 // LDS per wave: 2 buffers x t x 9 x 64 x 4 B  (2.25 t KiB each); the second buffer doubles as the
@@ -420,7 +524,8 @@ struct Launch {
 };
 
 // Engine choice: width 3 runs from registers, on the optimised schedule whenever its tables exist (the dense
-// schedule remains for configs without a partial section); every other width uses the LDS-resident engine.
+// schedule remains for configs without a partial section); widths 4..9 with alpha = 5 (the reference's default
+// table, src/test.rs:14-22) run on the register/LDS hybrid; everything else uses the LDS-resident engine.
 // alpha 5 and 17 have dedicated addition chains, other exponents share the generic S-box.
 #define PMX_DISPATCH(CALL)                                                                  \
     do {                                                                                    \
@@ -431,6 +536,14 @@ struct Launch {
             return Launch<RegEngine<3, 0, true>>::CALL;                                     \
         }                                                                                   \
         if (t == 3) return Launch<RegEngine<3, 0, false>>::CALL;                            \
+        if (c.has_opt && alpha == 5) {                                                      \
+            if (t == 4) return Launch<HybridEngine<4, 5>>::CALL;                            \
+            if (t == 5) return Launch<HybridEngine<5, 5>>::CALL;                            \
+            if (t == 6) return Launch<HybridEngine<6, 5>>::CALL;                            \
+            if (t == 7) return Launch<HybridEngine<7, 5>>::CALL;                            \
+            if (t == 8) return Launch<HybridEngine<8, 5>>::CALL;                            \
+            if (t == 9) return Launch<HybridEngine<9, 5>>::CALL;                            \
+        }                                                                                   \
         if (alpha == 5) return Launch<LdsEngine<5>>::CALL;                                  \
         if (alpha == 17) return Launch<LdsEngine<17>>::CALL;                                \
         return Launch<LdsEngine<0>>::CALL;                                                  \

@@ -112,6 +112,63 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Optimised schedule for wider states (t = 4..9): the state lives in registers, but loops over ELEMENTS in the
+// full rounds (t S-boxes, t matrix rows) are rolled to keep the code inside the instruction cache; a rolled
+// loop needs dynamic indexing, which goes through `Scratch` (one LDS slot array per lane on the device):
+//   sc.set(i, x) / sc.get(i)   i may be a run-time value
+// Matrix rows accumulate term by term into explicit 64-bit columns (only one 9-limb constant live at a time),
+// re-compressed every 3 terms.  The sparse partial rounds are fully unrolled and never touch the scratch.
+template <int T, class Scratch>
+PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
+    for (uint32_t i = 0; i < (uint32_t)T; ++i) {
+        const uint32_t *row = mat + (size_t)i * T * kFeStride;
+        Cols acc;
+        cols_zero(acc);
+        static_for<0, T>([&](auto j) {
+            cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
+            if (j % 3 == 2 || j == T - 1) cols_compress(acc);
+        });
+        sc.set(i, cols_redc(acc, f));
+    }
+    static_for<0, T>([&](auto i) { s[i] = sc.get(i); });
+}
+
+template <int T, int ALPHA, class Scratch>
+PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
+                           const FieldRt &f) {
+    const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
+    for (uint32_t r = 0; r < c.total_rounds; ++r) {
+        const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
+        if (r < first_partial || r > last_partial) {            // full round
+            static_for<0, T>([&](auto i) { sc.set(i, s[i]); });
+            for (uint32_t i = 0; i < (uint32_t)T; ++i)
+                sc.set(i, fe_sbox<ALPHA>(fe_add_lazy(sc.get(i), fe_const(rk + i * kFeStride)), c.alpha, one, f));
+            static_for<0, T>([&](auto i) { s[i] = sc.get(i); });
+            matrix_rows_rolled<T>(s, sc, tb.mds, f);
+            continue;
+        }
+        // partial round: lanes 1..T-1 stay norm with B < 2.1 (fe_add_weak); lane 0 is re-derived every round
+        s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
+        if (r < last_partial) {
+            const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
+            Cols acc;
+            cols_zero(acc);
+            static_for<0, T>([&](auto j) {
+                cols_mul_acc(acc, s[j], fe_const(sp + j * kFeStride));
+                if (j % 3 == 2 || j == T - 1) cols_compress(acc);
+            });
+            const Fe z0 = s[0];
+            s[0] = cols_redc(acc, f);
+            static_for<1, T>([&](auto i) {
+                s[i] = fe_add_weak(s[i], mont_mul(z0, fe_const(sp + (T + i - 1) * kFeStride), f), f);
+            });
+        } else {
+            matrix_rows_rolled<T>(s, sc, tb.bdense, f);         // last partial round: dense matrix B
+        }
+    }
+}
+
 // Dense schedule, width known only at run time.  `State` provides get(i) / set(i, x) on the current state and
 // set_next(i, x) / swap() on a second buffer (LDS on the device).  Element loops are rolled.
 template <int ALPHA, class State>

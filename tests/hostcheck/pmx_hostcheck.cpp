@@ -36,6 +36,47 @@ static void permute_opt_t(const Prepared &pp, uint64_t *states, size_t n) {
     }
 }
 
+struct HostScratch {
+    Fe slot[PMX_MAX_WIDTH];
+    Fe get(uint32_t i) const { return slot[i]; }
+    void set(uint32_t i, const Fe &x) { slot[i] = x; }
+};
+
+template <int T>
+static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
+    OptTables tb;
+    tb.ark = pp.consts.data() + pp.opt_offset;
+    tb.mds = pp.consts.data() + pp.mds_offset;
+    tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
+    tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
+    for (size_t k = 0; k < n; ++k) {
+        Fe s[T];
+        HostScratch sc;
+        for (int i = 0; i < T; ++i) s[i] = fe_from_abi(load_abi(states + (k * T + i) * 4), pp.f);
+        if (pp.c.alpha == 5) permute_hybrid<T, 5>(s, sc, tb, pp.c, pp.one, pp.f);
+        else if (pp.c.alpha == 17) permute_hybrid<T, 17>(s, sc, tb, pp.c, pp.one, pp.f);
+        else permute_hybrid<T, 0>(s, sc, tb, pp.c, pp.one, pp.f);
+        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi(s[i], pp.f));
+    }
+}
+
+// register + scratch hybrid on the optimised schedule (what HybridEngine runs)
+extern "C" int hc_permute_hybrid(const pmx_config *cfg, uint64_t *states, size_t n) {
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);
+    if (rc) return rc;
+    if (!pp.has_opt) return PMX_ERR_UNSUPPORTED;
+    switch (pp.t) {
+        case 3: permute_hybrid_t<3>(pp, states, n); break;
+        case 4: permute_hybrid_t<4>(pp, states, n); break;
+        case 5: permute_hybrid_t<5>(pp, states, n); break;
+        case 9: permute_hybrid_t<9>(pp, states, n); break;
+        default: return PMX_ERR_UNSUPPORTED;
+    }
+    return PMX_OK;
+}
+
 // optimised (sparse partial rounds) schedule; PMX_ERR_UNSUPPORTED when the tables cannot be derived
 extern "C" int hc_permute_opt(const pmx_config *cfg, uint64_t *states, size_t n) {
     Prepared pp;
