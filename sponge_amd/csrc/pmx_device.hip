@@ -38,6 +38,7 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 template <int T, int ALPHA, bool OPT>
 struct RegEngine {
     static constexpr int kThreads = 256;
+    static constexpr int kMinWaves = 1;
     static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
 
     Fe s[T];
@@ -55,17 +56,17 @@ struct RegEngine {
         return (PMX_CONSTS_IN_LDS ? (size_t)((last_word(d) - first_word(d) + 3) / 4) * 16 : 0) + (size_t)kThreads * kChunks * 16;
     }
 
-    __device__ __forceinline__ explicit RegEngine(const DevConfig &d) : c(d.rounds), f(d.field), one(d.one) {
+    __device__ __forceinline__ RegEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
         const uint32_t w0 = first_word(d);
 #if PMX_CONSTS_IN_LDS
         const uint32_t const_chunks = (last_word(d) - w0 + 3) / 4;
-        const uint4 *g = reinterpret_cast<const uint4 *>(d.consts + w0);   // offsets are multiples of 12 words = 48 B
+        const uint4 *g = reinterpret_cast<const uint4 *>(consts + w0);   // offsets are multiples of 12 words = 48 B
         for (uint32_t q = threadIdx.x; q < const_chunks; q += kThreads) pmx_lds[q] = g[q];
         const uint32_t *base = reinterpret_cast<const uint32_t *>(pmx_lds) - w0;
         stage = pmx_lds + const_chunks;
         __syncthreads();
 #else
-        const uint32_t *base = d.consts;
+        const uint32_t *base = consts;
         stage = pmx_lds;
 #endif
         tb.mds = base + d.mds_offset;
@@ -160,6 +161,7 @@ struct RegEngine {
 template <int T, int ALPHA>
 struct HybridEngine {
     static constexpr int kThreads = 64;
+    static constexpr int kMinWaves = 2;   // waves per SIMD the register allocation must allow (<= 256 VGPRs)
     static constexpr int kChunks = 2 * T;
 
     struct Scratch {
@@ -185,11 +187,11 @@ struct HybridEngine {
 
     static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return (size_t)T * kN * 64 * 4; }
 
-    __device__ __forceinline__ explicit HybridEngine(const DevConfig &d) : c(d.rounds), f(d.field), one(d.one) {
-        tb.mds = d.consts + d.mds_offset;
-        tb.ark = d.consts + d.opt_offset;
-        tb.sparse = d.consts + d.opt_sparse_offset;
-        tb.bdense = d.consts + d.opt_bdense_offset;
+    __device__ __forceinline__ HybridEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
+        tb.mds = consts + d.mds_offset;
+        tb.ark = consts + d.opt_offset;
+        tb.sparse = consts + d.opt_sparse_offset;
+        tb.bdense = consts + d.opt_bdense_offset;
         sc.base = reinterpret_cast<uint32_t *>(pmx_lds) + threadIdx.x;
     }
 
@@ -264,6 +266,7 @@ struct HybridEngine {
 template <int ALPHA>
 struct LdsEngine {
     static constexpr int kThreads = 128;
+    static constexpr int kMinWaves = 1;
 
     Rounds c;
     FieldRt f;
@@ -277,9 +280,9 @@ struct LdsEngine {
 
     static size_t lds_bytes(const DevConfig & /*d*/, uint32_t t) { return (size_t)(kThreads / 64) * 2 * t * kN * 64 * 4; }
 
-    __device__ __forceinline__ explicit LdsEngine(const DevConfig &d) : c(d.rounds), f(d.field), one(d.one) {
-        ark = d.consts;
-        mds = d.consts + d.mds_offset;
+    __device__ __forceinline__ LdsEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
+        ark = consts;
+        mds = consts + d.mds_offset;
         t = c.rate + c.capacity;
         lane = threadIdx.x & 63;
         const uint32_t wave = threadIdx.x >> 6;
@@ -369,8 +372,8 @@ struct LdsEngine {
 // Kernels (identical for both engines)
 // ------------------------------------------------------------------------------------------------
 template <class Engine>
-__global__ void __launch_bounds__(Engine::kThreads) permute_kernel(const DevConfig d, uint64_t *states, size_t n) {
-    Engine e(d);
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves) permute_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states, size_t n) {
+    Engine e(d, consts);
     e.load_states(states, n);
     e.permute();
     e.store_states(states, n);
@@ -437,9 +440,10 @@ __device__ __forceinline__ uint32_t squeeze_elements(Engine &e, uint64_t *row, s
 }
 
 template <class Engine>
-__global__ void __launch_bounds__(Engine::kThreads)
-    hash_kernel(const DevConfig d, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n) {
-    Engine e(d);
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
+    hash_kernel(const DevConfig d, const uint32_t *__restrict__ consts, const uint64_t *__restrict__ in, size_t in_len,
+                uint64_t *__restrict__ out, size_t out_len, size_t n) {
+    Engine e(d, consts);
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
     e.zero();                                                  // CryptographicSponge::new, mod.rs:219-230
@@ -450,11 +454,32 @@ __global__ void __launch_bounds__(Engine::kThreads)
     (void)squeeze_elements(e, row_out, out_len, 0, true, active);
 }
 
+// 2-to-1 compression, the Merkle-tree primitive:  out = (new; absorb([l, r]); squeeze_native(1))[0]
+//   = permute(state with state[capacity] = l, state[capacity+1] = r, rest 0)[capacity]      (rate >= 2),
+// because absorbing rate-many-or-fewer elements into a fresh sponge permutes exactly once, at the squeeze
+// (src/poseidon/mod.rs:126-135, 324-328).  One permutation site, 64 contiguous bytes in and 32 out per lane.
 template <class Engine>
-__global__ void __launch_bounds__(Engine::kThreads)
-    absorb_kernel(const DevConfig d, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index, const uint64_t *in,
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
+    compress_kernel(const DevConfig d, const uint32_t *__restrict__ consts, const uint64_t *__restrict__ in,
+                    uint64_t *__restrict__ out, size_t n) {
+    Engine e(d, consts);
+    const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
+    const bool active = gid < n;
+    const uint32_t *pair = reinterpret_cast<const uint32_t *>(in + (active ? gid : 0) * 8);
+    e.zero();
+    e.set(e.c.capacity, fe_from_abi(abi_load(pair), e.f));
+    e.set(e.c.capacity + 1, fe_from_abi(abi_load(pair + 8), e.f));
+    e.permute();
+    const Abi digest = fe_to_abi(e.get(e.c.capacity), e.f);
+    if (active) abi_store(reinterpret_cast<uint32_t *>(out + gid * 4), digest);
+}
+
+template <class Engine>
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
+    absorb_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
+                  uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, const uint64_t *__restrict__ in,
                   size_t in_len, size_t n) {
-    Engine e(d);
+    Engine e(d, consts);
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
     e.load_states(states, n);
@@ -469,10 +494,11 @@ __global__ void __launch_bounds__(Engine::kThreads)
 }
 
 template <class Engine>
-__global__ void __launch_bounds__(Engine::kThreads)
-    squeeze_kernel(const DevConfig d, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index, uint64_t *out,
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
+    squeeze_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
+                   uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ out,
                    size_t out_len, size_t n) {
-    Engine e(d);
+    Engine e(d, consts);
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
     e.load_states(states, n);
@@ -500,25 +526,30 @@ struct Launch {
 
     static hipError_t permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
         hipLaunchKernelGGL(permute_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
-                           states, n);
+                           c.consts, states, n);
         return hipGetLastError();
     }
     static hipError_t hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out,
                            size_t out_len, size_t n, hipStream_t st) {
-        hipLaunchKernelGGL(hash_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c, in,
-                           in_len, out, out_len, n);
+        hipLaunchKernelGGL(hash_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
+                           c.consts, in, in_len, out, out_len, n);
+        return hipGetLastError();
+    }
+    static hipError_t compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
+        hipLaunchKernelGGL(compress_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
+                           c.consts, in, out, n);
         return hipGetLastError();
     }
     static hipError_t absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                              const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {
         hipLaunchKernelGGL(absorb_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
-                           states, tag, index, in, in_len, n);
+                           c.consts, states, tag, index, in, in_len, n);
         return hipGetLastError();
     }
     static hipError_t squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                               uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
         hipLaunchKernelGGL(squeeze_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
-                           states, tag, index, out, out_len, n);
+                           c.consts, states, tag, index, out, out_len, n);
         return hipGetLastError();
     }
 };
@@ -555,6 +586,9 @@ hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                        size_t n, hipStream_t st) {
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
+}
+hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
+    PMX_DISPATCH(compress(c, t, in, out, n, st));
 }
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {

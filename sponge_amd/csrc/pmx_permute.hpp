@@ -125,9 +125,9 @@ PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, con
         const uint32_t *row = mat + (size_t)i * T * kFeStride;
         Cols acc;
         cols_zero(acc);
-        static_for<0, T>([&](auto j) {
+        static_for<0, T>([&](auto j) {   // operands are norm here: 5 terms (45 products < 2^58) per compression
             cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
-            if (j % 3 == 2 || j == T - 1) cols_compress(acc);
+            if (j % 5 == 4 || j == T - 1) cols_compress(acc);
         });
         sc.set(i, cols_redc(acc, f));
     }
@@ -156,7 +156,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             cols_zero(acc);
             static_for<0, T>([&](auto j) {
                 cols_mul_acc(acc, s[j], fe_const(sp + j * kFeStride));
-                if (j % 3 == 2 || j == T - 1) cols_compress(acc);
+                if (j % 5 == 4 || j == T - 1) cols_compress(acc);
             });
             const Fe z0 = s[0];
             s[0] = cols_redc(acc, f);
