@@ -474,6 +474,44 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     if (active) abi_store(reinterpret_cast<uint32_t *>(out + gid * 4), digest);
 }
 
+// The same 2-to-1 compression with ONE state spread over a quad of lanes (pmx_permute.hpp, cooperative schedule;
+// t = 3, rate 2, capacity 1): lane q of a quad holds state element q (lane 3 idles), the three z values of a
+// round are exchanged with quad-broadcast DPP moves.  Used for the narrow (latency-bound) levels of a tree.
+template <int ALPHA>
+__global__ void __launch_bounds__(256, 2)
+    compress_coop_kernel(const DevConfig d, const uint32_t *__restrict__ consts, const uint64_t *__restrict__ in,
+                         uint64_t *__restrict__ out, size_t n) {
+    const Rounds c(d.rounds);
+    const FieldRt f(d.field);
+    const Fe one(d.one);
+    const uint32_t table_chunks = c.total_rounds * 3 * kCoopElems * kFeStride / 4;
+    const uint4 *g4 = reinterpret_cast<const uint4 *>(consts + d.coop_offset);
+    for (uint32_t k = threadIdx.x; k < table_chunks; k += 256) pmx_lds[k] = g4[k];
+    __syncthreads();
+    const uint32_t *coop = reinterpret_cast<const uint32_t *>(pmx_lds);
+
+    const uint32_t q = threadIdx.x & 3;
+    const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool active = g < n;
+    Fe s = fe_zero();                                        // state = [0, l, r]
+    if (active && (q == 1 || q == 2)) s = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(in + (g * 2 + (q - 1)) * 4)), f);
+    const uint32_t role = q < 3 ? q : 2;                     // the idle lane shadows lane 2 (its result is never read)
+    for (uint32_t r = 0; r < c.total_rounds; ++r) {
+        const uint32_t *entry = coop + ((size_t)r * 3 + role) * kCoopElems * kFeStride;
+        const Fe z = coop_pre<ALPHA>(s, entry, is_full_round(r, c) || q == 0, c, one, f);
+        Fe zz[3];
+#pragma unroll
+        for (int w = 0; w < kN; ++w) {
+            zz[0].l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)z.l[w], 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+            zz[1].l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)z.l[w], 0x55, 0xf, 0xf, false);   // quad_perm [1,1,1,1]
+            zz[2].l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)z.l[w], 0xaa, 0xf, 0xf, false);   // quad_perm [2,2,2,2]
+        }
+        s = coop_post(zz, entry, f);
+    }
+    const Abi digest = fe_to_abi(s, f);
+    if (active && q == 1) abi_store(reinterpret_cast<uint32_t *>(out + g * 4), digest);   // state[capacity]
+}
+
 template <class Engine>
 __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     absorb_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
@@ -587,7 +625,23 @@ hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_
                        size_t n, hipStream_t st) {
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
+// Levels of at most this many compressions run on the cooperative kernel: up to here the one-lane-per-state kernel
+// has at most half a wave per SIMD and is bound by the 51k-multiply dependent chain of a single permutation.
+static constexpr size_t kCoopMaxUnits = 32768;
+
+template <int ALPHA>
+static hipError_t launch_compress_coop(const DevConfig &c, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
+    const size_t lds = (size_t)c.rounds.total_rounds * 3 * kCoopElems * kFeStride * 4;
+    hipLaunchKernelGGL(compress_coop_kernel<ALPHA>, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, c, c.consts, in, out, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
+    if (t == 3 && c.has_opt && n <= kCoopMaxUnits) {
+        if (c.rounds.alpha == 5) return launch_compress_coop<5>(c, in, out, n, st);
+        if (c.rounds.alpha == 17) return launch_compress_coop<17>(c, in, out, n, st);
+        return launch_compress_coop<0>(c, in, out, n, st);
+    }
     PMX_DISPATCH(compress(c, t, in, out, n, st));
 }
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,

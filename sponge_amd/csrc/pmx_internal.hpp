@@ -16,8 +16,8 @@ struct DevConfig {
     const uint32_t *consts;   // device; layout: pmx_prepare.hpp Prepared::consts
     uint32_t n_const_words;   // words in consts
     uint32_t mds_offset;      // word offsets inside consts
-    uint32_t opt_offset, opt_sparse_offset, opt_bdense_offset;
-    uint32_t has_opt;         // optimised schedule tables present
+    uint32_t opt_offset, opt_sparse_offset, opt_bdense_offset, coop_offset;
+    uint32_t has_opt;         // optimised schedule tables present (and, for t = 3, the cooperative table)
     Rounds rounds;
     FieldRt field;
     Fe one;                   // 2^261 mod p

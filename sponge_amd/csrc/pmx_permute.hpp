@@ -169,6 +169,37 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Cooperative form of the optimised t = 3 schedule: ONE state is spread over three lanes (lane q holds element
+// q), which shortens the dependent chain of a single permutation from 51k to 29k multiplies.  It exists for
+// latency-bound launches (the narrow upper levels of a Merkle tree), where lanes are plentiful and the time of
+// one permutation on a lone wave is what is paid.  Every round is the same instruction stream for all lanes:
+//     x  = s + ark'[r][q]                      (0 for lanes 1, 2 in partial rounds: their constants are deferred)
+//     z  = S-box(x) if (full round or q == 0) else x
+//     s  = dot3((z_0, z_1, z_2), row[r][q])    after gathering the three z across the lanes
+// with row[r][q] = M[q] in full rounds, B[q] in the last partial round, and in the sparse partial rounds
+//     q = 0: (m00, v_1, v_2)      q = 1: (w_1, ONE, 0)      q = 2: (w_2, 0, ONE)
+// i.e. the identity lanes take "+ u_i" as a product with ONE = 2^261 mod p inside the same reduction, so their
+// magnitude is re-normalised every round (no fe_add_weak) and the code is uniform across lanes.
+// Table (pmx_prepare.hpp): coop[r][q][0] = ark'[r][q], coop[r][q][1..3] = row[r][q][0..2].
+constexpr int kCoopElems = 4;   // elements per (round, lane)
+
+template <int ALPHA>
+PMX_FN Fe coop_pre(const Fe &s, const uint32_t *entry, bool apply_sbox, const Rounds &c, const Fe &one, const FieldRt &f) {
+    const Fe x = fe_add_lazy(s, fe_const(entry));
+    const Fe y = fe_sbox<ALPHA>(x, c.alpha, one, f);   // computed by every lane (uniform stream), kept where it applies
+    Fe z;
+#pragma unroll
+    for (int w = 0; w < kN; ++w) z.l[w] = apply_sbox ? y.l[w] : x.l[w];
+    return z;
+}
+
+PMX_FN Fe coop_post(const Fe (&z)[3], const uint32_t *entry, const FieldRt &f) {
+    Fe row[3];
+    static_for<0, 3>([&](auto j) { row[j] = fe_const(entry + (1 + j) * kFeStride); });
+    return mont_dot<3>(z, row, f);
+}
+
 // Dense schedule, width known only at run time.  `State` provides get(i) / set(i, x) on the current state and
 // set_next(i, x) / swap() on a second buffer (LDS on the device).  Element loops are rolled.
 template <int ALPHA, class State>

@@ -44,6 +44,9 @@ struct Prepared {
     size_t mds_offset;
     bool has_opt;
     size_t opt_offset, opt_sparse_offset, opt_bdense_offset;
+    //   -- only when has_opt and t == 3 (pmx_permute.hpp: cooperative schedule) --
+    //   coop_offset                coop     [rounds][3][4]
+    size_t coop_offset;
 };
 
 // ---- small dense linear algebra over the ABI Montgomery form (host only) ----------------------------------------
@@ -207,6 +210,45 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
             size_t k = out.opt_offset / kFeStride;
             for (const auto *vec : {&ark_opt, &sparse, &bdense})
                 for (const U256 &v : *vec) to_limbs29(times_pow2(hf, v, 5), &out.consts[(k++) * kFeStride]);
+        }
+    }
+    // cooperative t = 3 table: per (round, lane): ark' element, then the lane's matrix row of that round
+    out.coop_offset = out.consts.size();
+    if (out.has_opt && t == 3) {
+        const uint32_t half = cfg->full_rounds / 2, rp = cfg->partial_rounds;
+        const uint32_t *ark_o = &out.consts[out.opt_offset];
+        const uint32_t *mds_i = &out.consts[out.mds_offset];
+        const uint32_t *sparse_i = &out.consts[out.opt_sparse_offset];
+        const uint32_t *bdense_i = &out.consts[out.opt_bdense_offset];
+        uint32_t one29[kN];
+        to_limbs29(times_pow2(hf, hf.r, 5), one29);
+        out.consts.resize(out.coop_offset + (size_t)rounds * 3 * kCoopElems * kFeStride, 0u);
+        // (the resize may move the buffer: re-take the pointers)
+        ark_o = &out.consts[out.opt_offset];
+        mds_i = &out.consts[out.mds_offset];
+        sparse_i = &out.consts[out.opt_sparse_offset];
+        bdense_i = &out.consts[out.opt_bdense_offset];
+        auto put = [&](size_t r, size_t q, size_t slot, const uint32_t *src) {
+            std::memcpy(&out.consts[out.coop_offset + ((r * 3 + q) * kCoopElems + slot) * kFeStride], src, kN * 4);
+        };
+        for (size_t r = 0; r < rounds; ++r) {
+            for (size_t q = 0; q < 3; ++q) {
+                put(r, q, 0, ark_o + (r * 3 + q) * kFeStride);
+                const bool partial = r >= half && r < half + rp;
+                if (!partial) {
+                    for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, mds_i + (q * 3 + j) * kFeStride);
+                } else if (r + 1 == half + rp) {
+                    for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, bdense_i + (q * 3 + j) * kFeStride);
+                } else {
+                    const uint32_t *sp = sparse_i + (r - half) * 5 * kFeStride;   // row0[3], w[2]
+                    if (q == 0) {
+                        for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, sp + j * kFeStride);
+                    } else {
+                        put(r, q, 1, sp + (3 + q - 1) * kFeStride);   // w_q * z_0
+                        put(r, q, 1 + q, one29);                      // + ONE * z_q   (other slot stays 0)
+                    }
+                }
+            }
         }
     }
     FieldRt &f = out.f;

@@ -36,6 +36,34 @@ static void permute_opt_t(const Prepared &pp, uint64_t *states, size_t n) {
     }
 }
 
+// cooperative t = 3 schedule, three "lanes" simulated in turn
+extern "C" int hc_permute_coop(const pmx_config *cfg, uint64_t *states, size_t n) {
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);
+    if (rc) return rc;
+    if (!pp.has_opt || pp.t != 3) return PMX_ERR_UNSUPPORTED;
+    const uint32_t *coop = pp.consts.data() + pp.coop_offset;
+    for (size_t k = 0; k < n; ++k) {
+        Fe s[3];
+        for (int i = 0; i < 3; ++i) s[i] = fe_from_abi(load_abi(states + (k * 3 + i) * 4), pp.f);
+        for (uint32_t r = 0; r < pp.c.total_rounds; ++r) {
+            Fe z[3], nxt[3];
+            for (int q = 0; q < 3; ++q) {
+                const uint32_t *entry = coop + ((size_t)r * 3 + q) * kCoopElems * kFeStride;
+                const bool sbox = is_full_round(r, pp.c) || q == 0;
+                if (pp.c.alpha == 5) z[q] = coop_pre<5>(s[q], entry, sbox, pp.c, pp.one, pp.f);
+                else if (pp.c.alpha == 17) z[q] = coop_pre<17>(s[q], entry, sbox, pp.c, pp.one, pp.f);
+                else z[q] = coop_pre<0>(s[q], entry, sbox, pp.c, pp.one, pp.f);
+            }
+            for (int q = 0; q < 3; ++q) nxt[q] = coop_post(z, coop + ((size_t)r * 3 + q) * kCoopElems * kFeStride, pp.f);
+            for (int q = 0; q < 3; ++q) s[q] = nxt[q];
+        }
+        for (int i = 0; i < 3; ++i) store_abi(states + (k * 3 + i) * 4, fe_to_abi(s[i], pp.f));
+    }
+    return PMX_OK;
+}
+
 struct HostScratch {
     Fe slot[PMX_MAX_WIDTH];
     Fe get(uint32_t i) const { return slot[i]; }

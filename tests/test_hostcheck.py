@@ -27,6 +27,7 @@ def hc():
     lib.hc_permute_rt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_opt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_hybrid.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    lib.hc_permute_coop.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_field_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_sqr_column.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
@@ -79,7 +80,7 @@ def test_column_accumulators_cannot_overflow(hc):
     assert int(hi[0]) == 0
 
 
-def run_permute(hc, name, states, rt=False, opt=False, hybrid=False):
+def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False):
     cfg = oracle_config(name)
     p = cfg.p
     ark = mont_limbs([v for row in cfg.ark for v in row], p)
@@ -92,7 +93,7 @@ def run_permute(hc, name, states, rt=False, opt=False, hybrid=False):
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
     out = np.ascontiguousarray(states, dtype=np.uint64).copy()
     n = out.size // (cfg.t * 4)
-    fn = hc.hc_permute_hybrid if hybrid else (hc.hc_permute_opt if opt else (hc.hc_permute_rt if rt else hc.hc_permute))
+    fn = hc.hc_permute_coop if coop else hc.hc_permute_hybrid if hybrid else (hc.hc_permute_opt if opt else (hc.hc_permute_rt if rt else hc.hc_permute))
     assert fn(ctypes.byref(c), out.ctypes.data, n) == 0
     return out
 
@@ -112,6 +113,9 @@ def test_permutation_templates_match_golden(hc, name):
     assert cref.limbs_to_elems(out, cfg.p) == want, "opt"
     out = run_permute(hc, name, states, hybrid=True)  # register + scratch hybrid (HybridEngine)
     assert cref.limbs_to_elems(out, cfg.p) == want, "hybrid"
+    if cfg.t == 3:
+        out = run_permute(hc, name, states, coop=True)  # three-lanes-per-state schedule (small Merkle levels)
+        assert cref.limbs_to_elems(out, cfg.p) == want, "coop"
 
 
 def test_permutation_templates_match_c_oracle_on_random_batch(hc):
@@ -123,6 +127,7 @@ def test_permutation_templates_match_c_oracle_on_random_batch(hc):
         assert np.array_equal(run_permute(hc, name, states), want)
         assert np.array_equal(run_permute(hc, name, states, opt=True), want)
         assert np.array_equal(run_permute(hc, name, states, hybrid=True), want)
+        assert np.array_equal(run_permute(hc, name, states, coop=True), want)
     from sponge_amd import synth as sy
     states = sy.random_elements(S.BN254_FR, 64 * 9, seed=78).reshape(64, 9, 4)
     want = cref.CRef(oracle_config("bn254_t9_a5_8_57")).permute_batch(states, threads=0)
