@@ -11,6 +11,14 @@
 
 namespace pmx {
 
+// Scheduling fence (device only): keeps the machine scheduler from interleaving the independent lane updates of
+// a wide state, which otherwise blows the register budget (t = 6, 8 spilled kilobytes to scratch without it).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PMX_SCHED_FENCE() ((void)0)
+#endif
+
 // Guaranteed compile-time unrolling of the element loops (#pragma unroll gives up on bodies this large, and a
 // rolled loop would index the register-resident state dynamically, i.e. push it to scratch memory).
 template <int I, int N, class F>
@@ -121,13 +129,14 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
 // re-compressed every 3 terms.  The sparse partial rounds are fully unrolled and never touch the scratch.
 template <int T, class Scratch>
 PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (uint32_t i = 0; i < (uint32_t)T; ++i) {
         const uint32_t *row = mat + (size_t)i * T * kFeStride;
         Cols acc;
         cols_zero(acc);
         static_for<0, T>([&](auto j) {   // operands are norm here: 5 terms (45 products < 2^58) per compression
             cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
-            if (j % 5 == 4 || j == T - 1) cols_compress(acc);
+            if ((j % 5 == 4 && j + 1 < T) || j == T - 1) cols_compress(acc);
         });
         sc.set(i, cols_redc(acc, f));
     }
@@ -142,6 +151,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
         if (r < first_partial || r > last_partial) {            // full round
             static_for<0, T>([&](auto i) { sc.set(i, s[i]); });
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (uint32_t i = 0; i < (uint32_t)T; ++i)
                 sc.set(i, fe_sbox<ALPHA>(fe_add_lazy(sc.get(i), fe_const(rk + i * kFeStride)), c.alpha, one, f));
             static_for<0, T>([&](auto i) { s[i] = sc.get(i); });
@@ -156,13 +166,15 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             cols_zero(acc);
             static_for<0, T>([&](auto j) {
                 cols_mul_acc(acc, s[j], fe_const(sp + j * kFeStride));
-                if (j % 5 == 4 || j == T - 1) cols_compress(acc);
+                if ((j % 5 == 4 && j + 1 < T) || j == T - 1) cols_compress(acc);
             });
             const Fe z0 = s[0];
             s[0] = cols_redc(acc, f);
             static_for<1, T>([&](auto i) {
+                PMX_SCHED_FENCE();
                 s[i] = fe_add_weak(s[i], mont_mul(z0, fe_const(sp + (T + i - 1) * kFeStride), f), f);
             });
+            PMX_SCHED_FENCE();
         } else {
             matrix_rows_rolled<T>(s, sc, tb.bdense, f);         // last partial round: dense matrix B
         }
@@ -208,15 +220,18 @@ PMX_FN void permute_dense_rt(State &st, uint32_t t, const uint32_t *ark, const u
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = ark + (size_t)r * t * kFeStride;
         const uint32_t n_sbox = is_full_round(r, c) ? t : 1;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (uint32_t i = 0; i < t; ++i) {
             Fe x = fe_add_lazy(st.get(i), fe_const(rk + i * kFeStride));
             if (i < n_sbox) x = fe_sbox<ALPHA>(x, c.alpha, one, f);
             st.set(i, x);
         }
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (uint32_t i = 0; i < t; ++i) {
             Cols acc;
             cols_zero(acc);
             uint32_t pending = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (uint32_t j = 0; j < t; ++j) {
                 cols_mul_acc(acc, st.get(j), fe_const(mds + ((size_t)i * t + j) * kFeStride));
                 if (++pending == 3) {   // at most 3 lazy terms per 64-bit column before re-compressing
