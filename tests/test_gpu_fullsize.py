@@ -86,3 +86,15 @@ def test_c5_merkle_2e20_leaves_root_and_decomposition():
     lvl10 = got[2 * m - 1 - 2047: 2 * m - 1 - 1023]      # the level with 1024 nodes
     want_top = c_oracle(name).merkle(lvl10, threads=0)
     assert np.array_equal(want_top[-1], got[-1])
+
+
+def test_wide_and_narrow_compression_kernels_agree_at_the_switch():
+    """A 2^17-leaf tree: level 1 (65536 parents) runs on the one-lane-per-state kernel, level 2 (32768) and above on
+    the cooperative kernel; both against the C restatement."""
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    m = 1 << 17
+    leaves = synth.random_elements(cfg.field, m, seed=0x5EED0017)
+    nodes, root = cfg.context().merkle_2to1(leaves)
+    want = c_oracle(name).merkle(leaves, threads=0)
+    assert np.array_equal(nodes, want)

@@ -172,3 +172,38 @@ def test_bad_arguments_fail_loudly():
     b.mode_tag[0] = 9
     with pytest.raises(S.PmxError):
         b.absorb(np.zeros((2, 1, 4), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("rate", [3, 4, 5, 6, 7, 8])
+def test_default_table_widths_vs_c_oracle(rate):
+    """Every width of the reference's default table (src/test.rs:14-22, constraints-optimised, alpha = 5): the
+    register/LDS hybrid engines on the optimised schedule against the dense C restatement."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    cfg = S.get_default_poseidon_parameters(f, rate, False)
+    ocfg = O.default_bls12_381_config(rate, False)
+    assert (cfg.alpha, cfg.full_rounds, cfg.partial_rounds) == (ocfg.alpha, ocfg.full_rounds, ocfg.partial_rounds)
+    t = rate + 1
+    for n in (1, 65, 200):
+        states = synth.random_elements(f, n * t, seed=1000 * rate + n).reshape(n, t, 4)
+        got = cfg.context().permute_batch(states)
+        want = cref.CRef(ocfg).permute_batch(states, threads=0)
+        assert np.array_equal(got, want), (rate, n)
+    msgs = synth.random_elements(f, 100 * (rate + 2), seed=rate).reshape(100, rate + 2, 4)
+    assert np.array_equal(cfg.context().hash_batch(msgs, rate + 2, 2), cref.CRef(ocfg).hash_batch(msgs, rate + 2, 2, threads=0))
+
+
+@pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31", "bls_t3_a257_8_13", "bn254_t3_a5_8_57",
+                                  "reference_test_a17_8_29", "bls_t4_a5_8_56", "bn254_t9_a5_8_57"])
+def test_merkle_trees_vs_c_oracle(name):
+    """2-to-1 trees through both compression kernels (one lane per state for wide levels, the cooperative
+    quad-per-state kernel for levels of <= 32768 nodes) for every S-box variant."""
+    cfg = product_config(name)
+    cr = c_oracle(name)
+    for m in (2, 64, 4096):
+        leaves = synth.random_elements(cfg.field, m, seed=m)
+        nodes, root = cfg.context().merkle_2to1(leaves)
+        want = cr.merkle(leaves, threads=0)
+        assert np.array_equal(nodes, want), (name, m)
+        assert np.array_equal(root, want[-1])
