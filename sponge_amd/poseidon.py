@@ -290,18 +290,52 @@ class PoseidonSponge:
         c._b = self._b.clone()
         return c
 
-    def absorb(self, elems) -> None:
-        """`elems`: native field elements, [L][4] Montgomery limbs (the Absorb encodings of
-        src/absorb.rs are not part of this path)."""
+    def absorb(self, input) -> None:
+        """CryptographicSponge::absorb (mod.rs:232-254).  `input` is either an `Absorb` object (absorb.py: its
+        to_sponge_field_elements encoding is absorbed, as in the reference) or native field elements given
+        directly as [L][4] Montgomery limbs."""
+        from .absorb import Absorb
+        if isinstance(input, Absorb):
+            elems = self.parameters.field.from_ints(input.to_sponge_field_elements_as_vec(self.parameters.field))
+        else:
+            elems = input
         elems = np.ascontiguousarray(elems, dtype=np.uint64).reshape(1, -1, 4)
         self._b.absorb(elems)
+
+    def fork(self, domain: bytes) -> "PoseidonSponge":
+        """CryptographicSponge::fork (src/lib.rs:149-157): clone, then absorb len(domain) as usize bytes ++ domain,
+        as a Vec<u8>."""
+        from .absorb import Bytes, Usize
+        new_sponge = self.clone()
+        new_sponge.absorb(Bytes(Usize(len(domain)).to_sponge_bytes_as_vec() + bytes(domain)))
+        return new_sponge
 
     def squeeze_native_field_elements(self, num_elements: int) -> np.ndarray:
         return self._b.squeeze_native_field_elements(num_elements)[0]
 
-    def squeeze_field_elements(self, num_elements: int) -> np.ndarray:
-        """Native-field case of squeeze_field_elements::<F> (mod.rs:306-311): identical to the native squeeze."""
-        return self.squeeze_native_field_elements(num_elements)
+    def squeeze_field_elements(self, num_elements: int, field2: Optional[Field] = None):
+        """squeeze_field_elements::<F2> (mod.rs:306-317).  Native field (default): identical to the native squeeze
+        ([n][4] limbs).  Another field: the bit-recomposition of src/lib.rs:61-100, returned as canonical integers."""
+        if field2 is None or field2.modulus == self.parameters.field.modulus:
+            return self.squeeze_native_field_elements(num_elements)
+        return self.squeeze_field_elements_with_sizes([None] * num_elements, field2)
+
+    def squeeze_field_elements_with_sizes(self, sizes, field2: Field) -> List[int]:
+        """Non-native default (src/lib.rs:61-100): every requested element takes MODULUS_BIT_SIZE(F2) - 1 bits
+        (FieldElementSize::num_bits ignores the Truncated value, src/lib.rs:45-52), little-endian, reduced mod p2.
+        `sizes`: None for Full, an int for Truncated(n)."""
+        if len(sizes) == 0:
+            return []
+        nb = field2.modulus_bit_size - 1
+        for sz in sizes:
+            if sz is not None and sz > field2.modulus_bit_size:
+                raise ValueError("num_bits is greater than the capacity of the field.")   # src/lib.rs:48
+        bits = self.squeeze_bits(nb * len(sizes))
+        out = []
+        for k in range(len(sizes)):
+            window = bits[k * nb:(k + 1) * nb]
+            out.append(sum(1 << i for i, b in enumerate(window) if b) % field2.modulus)
+        return out
 
     def squeeze_bytes(self, num_bytes: int) -> bytes:                     # mod.rs:256-270
         f = self.parameters.field

@@ -8,7 +8,7 @@
 #include <cstring>
 #include <string>
 
-#include "../../sponge_amd/host/poseidon_sponge.hpp"
+#include "../../sponge_amd/host/absorb.hpp"
 
 using namespace pmx_host;
 
@@ -40,6 +40,52 @@ static void test_grain_lfsr_and_default_parameters() {
         (void)PoseidonConfig::make(Fr, 8, 31, 17, c2.mds, bad_ark, 2, 1);
     } catch (const Error &e) { threw = e.code == PMX_ERR_CONFIG; }
     EXPECT(threw);
+}
+
+static void test_absorb_encodings_host() {
+    const Field Fr = Field::bls12_381_fr();
+    // "abc" -> u64-LE length 3, then the bytes, in one 31-byte chunk: 3 + 0x636261 * 2^64
+    auto e = collect_sponge_field_elements(Fr, std::vector<uint8_t>{'a', 'b', 'c'});
+    EXPECT(e.size() == 1 && e[0] == fp_from_bigint(Fr, {3, 0x636261, 0, 0}));
+    // 8 + 24 = 32 bytes -> two elements
+    EXPECT(collect_sponge_field_elements(Fr, std::vector<uint8_t>(24, 7)).size() == 2);
+    // signed: -2 -> p - 2; bool; option; with_length
+    auto m2 = collect_sponge_field_elements(Fr, (int16_t)-2);
+    EXPECT(fp_into_bigint(Fr, m2[0])[0] == Fr.modulus[0] - 2);
+    EXPECT(collect_sponge_bytes((int16_t)-2) == (std::vector<uint8_t>{0xfe, 0xff}));
+    EXPECT(collect_sponge_bytes(std::optional<uint8_t>(3)) == (std::vector<uint8_t>{1, 3}));
+    EXPECT(collect_sponge_bytes(std::optional<uint8_t>()) == (std::vector<uint8_t>{0}));
+    auto wl = collect_sponge_field_elements(Fr, with_length(std::vector<uint64_t>{5, 6}));
+    EXPECT(wl.size() == 3 && wl[0] == fp_from_u64(Fr, 2) && wl[2] == fp_from_u64(Fr, 6));
+    // test_macros (src/poseidon/tests.rs:101-116): collect_* equals the long-hand calls
+    std::vector<uint8_t> expected;
+    to_sponge_bytes(std::vector<int32_t>{6, 5, 4, 3, 2, 1}, expected);
+    to_sponge_bytes(FpOf{Fr, fp_from_u64(Fr, 42)}, expected);
+    EXPECT(expected.size() == 24 + 32);
+    EXPECT(collect_sponge_bytes(std::vector<int32_t>{6, 5, 4, 3, 2, 1}, FpOf{Fr, fp_from_u64(Fr, 42)}) == expected);
+    // list_with_nonconstant_size_element (tests.rs:57-69): the per-list lengths separate the two encodings
+    using B = std::vector<uint8_t>;
+    const B a1{1, 2, 3, 4}, a2{5, 6}, b1{1, 2}, b2{3, 4, 5, 6};
+    EXPECT(collect_sponge_bytes(with_length(a1), with_length(a2)) != collect_sponge_bytes(with_length(b1), with_length(b2)));
+    EXPECT(collect_sponge_bytes(a1, a2) == collect_sponge_bytes(b1, b2));
+}
+
+static void test_macros_and_fork_on_gpu() {
+    // src/poseidon/tests.rs:87-99: absorb!(s, vec![1..6], Fr::from(114514)) == two absorb calls; fork changes the output
+    const Field Fr = Field::bls12_381_fr();
+    auto sponge_param = get_default_poseidon_parameters(Fr, 2, false).value();
+    auto sponge1 = PoseidonSponge::make(sponge_param);
+    std::vector<Fp> e1, e2;
+    to_sponge_field_elements(Fr, std::vector<int32_t>{1, 2, 3, 4, 5, 6}, e1);
+    to_sponge_field_elements(Fr, FpOf{Fr, fp_from_u64(Fr, 114514)}, e2);
+    sponge1.absorb(e1);
+    sponge1.absorb(e2);
+    auto sponge2 = PoseidonSponge::make(sponge_param);
+    absorb(sponge2, std::vector<int32_t>{1, 2, 3, 4, 5, 6}, FpOf{Fr, fp_from_u64(Fr, 114514)});
+    auto forked = fork(sponge2, {'d', 'o', 'm'});
+    auto expected = sponge1.squeeze_native_field_elements(3);
+    EXPECT(sponge2.squeeze_native_field_elements(3) == expected);
+    EXPECT(forked.squeeze_native_field_elements(3) != expected);
 }
 
 static void test_poseidon_sponge_consistency() {
@@ -84,7 +130,9 @@ int main(int argc, char **argv) {
     const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
     try {
         test_grain_lfsr_and_default_parameters();
+        test_absorb_encodings_host();
         if (!host_only) {
+            test_macros_and_fork_on_gpu();
             test_poseidon_sponge_consistency();
             test_squeeze_cast_native_and_state_roundtrip();
         } else {
