@@ -626,8 +626,8 @@ hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
 // Levels of at most this many compressions run on the cooperative kernel: up to here the one-lane-per-state kernel
-// has at most half a wave per SIMD and is bound by the 51k-multiply dependent chain of a single permutation.
-static constexpr size_t kCoopMaxUnits = 32768;
+// has at most a quarter of a wave per SIMD and is bound by the 51k-multiply dependent chain of a single permutation.
+static constexpr size_t kCoopMaxUnits = 16384;
 
 template <int ALPHA>
 static hipError_t launch_compress_coop(const DevConfig &c, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {

@@ -1,0 +1,45 @@
+// AddressSanitizer + UBSan run of the host-side code paths (GPU sanitizers are unavailable on the pool): the
+// kernel algorithm templates compiled for the host, the table preparation (incl. the optimised-schedule linear
+// algebra) and the Grain-LFSR parameter generator.  Built and run by tests/test_sanitizers.py.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "pmx_hostcheck.cpp"
+#include "../../sponge_amd/csrc/pmx_params.cpp"
+
+namespace pmx {
+int set_error(int code, const char *, ...) { return code; }
+}
+
+int main() {
+    const uint64_t bls[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+    const uint64_t bn[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    struct Case { const uint64_t *p; uint64_t bits; uint32_t rate, rf, rp; uint64_t alpha; };
+    const Case cases[] = {{bls, 255, 2, 8, 31, 5}, {bls, 255, 2, 8, 31, 17}, {bls, 255, 3, 8, 56, 5}, {bn, 254, 8, 8, 57, 5}, {bls, 255, 2, 8, 13, 257}};
+    for (const Case &c : cases) {
+        const uint32_t t = c.rate + 1;
+        std::vector<uint64_t> ark((size_t)(c.rf + c.rp) * t * 4), mds((size_t)t * t * 4);
+        if (pmx_find_poseidon_ark_and_mds(c.p, c.bits, c.rate, c.rf, c.rp, 0, ark.data(), mds.data())) return 1;
+        pmx_config cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        cfg.full_rounds = c.rf; cfg.partial_rounds = c.rp; cfg.alpha = c.alpha; cfg.rate = c.rate; cfg.capacity = 1;
+        std::memcpy(cfg.modulus, c.p, 32);
+        cfg.ark = ark.data(); cfg.mds = mds.data();
+        const size_t n = 5;
+        std::vector<uint64_t> base(n * t * 4);
+        for (size_t i = 0; i < base.size(); ++i) base[i] = (i % 4 == 3) ? (0x0123456789abcdefull >> 3) % (c.p[3]) : 0x9e3779b97f4a7c15ull * (i + 1);
+        std::vector<uint64_t> a = base, b = base, d = base, e = base;
+        if (hc_permute(&cfg, a.data(), n)) { if (t != 2 && t != 3 && t != 4 && t != 5 && t != 9) {} else return 2; }
+        if (hc_permute_rt(&cfg, b.data(), n)) return 3;
+        if (hc_permute_opt(&cfg, d.data(), n)) return 4;
+        if (hc_permute_hybrid(&cfg, e.data(), n)) return 5;
+        if (a != b || a != d || a != e) { std::printf("schedules disagree\n"); return 6; }
+        if (t == 3) {
+            std::vector<uint64_t> g = base;
+            if (hc_permute_coop(&cfg, g.data(), n) || g != a) return 7;
+        }
+    }
+    std::printf("sanitized ok\n");
+    return 0;
+}

@@ -111,3 +111,51 @@ def test_synthetic_batches_are_reduced_and_shardable():
     # splitmix64 known answers (seed 0 stream: 0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4)
     out = synth.splitmix64(np.array([0, 1], dtype=np.uint64))
     assert [int(x) for x in out] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4]
+
+
+def _try_create(cfg_kwargs):
+    """pmx_ctx_create validates the config before it looks for a device, so the reference's
+    PoseidonConfig::new failures (and this build's limits) are observable without a GPU."""
+    import ctypes
+    f = cfg_kwargs.pop("field", S.BLS12_381_FR)
+    t = cfg_kwargs["rate"] + cfg_kwargs["capacity"]
+    rounds = cfg_kwargs["full_rounds"] + cfg_kwargs["partial_rounds"]
+    ark = cfg_kwargs.pop("ark", np.zeros((rounds, t, 4), dtype=np.uint64))
+    mds = cfg_kwargs.pop("mds", np.zeros((t, t, 4), dtype=np.uint64))
+    modulus = cfg_kwargs.pop("modulus", f.modulus)
+    c = _lib.PmxConfig()
+    c.full_rounds, c.partial_rounds = cfg_kwargs["full_rounds"], cfg_kwargs["partial_rounds"]
+    c.alpha, c.rate, c.capacity = cfg_kwargs.get("alpha", 5), cfg_kwargs["rate"], cfg_kwargs["capacity"]
+    for i in range(4):
+        c.modulus[i] = (modulus >> (64 * i)) & (2**64 - 1)
+    c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+    h = ctypes.c_void_p()
+    rc = _lib.lib().pmx_ctx_create(ctypes.byref(c), 0, ctypes.byref(h))
+    msg = _lib.lib().pmx_last_error().decode()
+    if rc == 0:
+        _lib.lib().pmx_ctx_destroy(h)
+    return rc, msg
+
+
+@pytest.mark.parametrize("kwargs,code,needle", [
+    (dict(full_rounds=7, partial_rounds=31, rate=2, capacity=1), _lib.PMX_ERR_CONFIG, "even"),
+    (dict(full_rounds=8, partial_rounds=31, rate=0, capacity=1), _lib.PMX_ERR_CONFIG, "rate"),
+    (dict(full_rounds=8, partial_rounds=31, rate=16, capacity=1), _lib.PMX_ERR_UNSUPPORTED, "width"),
+    (dict(full_rounds=0, partial_rounds=0, rate=2, capacity=1), _lib.PMX_ERR_CONFIG, "round"),
+    (dict(full_rounds=8, partial_rounds=31, rate=2, capacity=1, modulus=(1 << 256) - 189), _lib.PMX_ERR_UNSUPPORTED, "2^255"),
+    (dict(full_rounds=8, partial_rounds=31, rate=2, capacity=1, modulus=(1 << 254)), _lib.PMX_ERR_CONFIG, "odd"),
+    (dict(full_rounds=8, partial_rounds=31, rate=2, capacity=1, modulus=(1 << 61) - 1), _lib.PMX_ERR_UNSUPPORTED, "225"),
+])
+def test_config_validation_without_a_device(kwargs, code, needle):
+    rc, msg = _try_create(dict(kwargs))
+    assert rc == code and needle in msg, (rc, msg)
+
+
+def test_unreduced_constants_are_rejected():
+    bad = np.zeros((39, 3, 4), dtype=np.uint64)
+    bad[5, 1] = np.uint64(0xFFFFFFFFFFFFFFFF)          # >= p
+    rc, msg = _try_create(dict(full_rounds=8, partial_rounds=31, rate=2, capacity=1, ark=bad))
+    assert rc == _lib.PMX_ERR_CONFIG and "ark constant 16 is not reduced" in msg
+    rc, msg = _try_create(dict(full_rounds=8, partial_rounds=31, rate=2, capacity=1))
+    if _lib.lib().pmx_device_count() == 0:            # a valid config then fails only for want of a device
+        assert rc == _lib.PMX_ERR_HIP
