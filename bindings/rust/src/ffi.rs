@@ -1,0 +1,36 @@
+//! Raw bindings of include/poseidon_mi355x.h.
+#![allow(non_camel_case_types)]
+use core::ffi::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct pmx_config {
+    pub full_rounds: u32,
+    pub partial_rounds: u32,
+    pub alpha: u64,
+    pub rate: u32,
+    pub capacity: u32,
+    pub modulus: [u64; 4],
+    pub ark: *const u64, // [full_rounds+partial_rounds][rate+capacity][4]
+    pub mds: *const u64, // [rate+capacity][rate+capacity][4], mds[i][j] row-major
+}
+#[repr(C)]
+pub struct pmx_ctx { _private: [u8; 0] }
+
+pub const PMX_MODE_ABSORBING: u32 = 0;
+pub const PMX_MODE_SQUEEZING: u32 = 1;
+
+extern "C" {
+    pub fn pmx_last_error() -> *const c_char;
+    pub fn pmx_ctx_create(cfg: *const pmx_config, device: c_int, out: *mut *mut pmx_ctx) -> c_int;
+    pub fn pmx_ctx_destroy(ctx: *mut pmx_ctx) -> c_int;
+    pub fn pmx_permute_batch(ctx: *mut pmx_ctx, states: *mut u64, n: usize) -> c_int;
+    pub fn pmx_permute_batch_dev(ctx: *mut pmx_ctx, d_states: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+    pub fn pmx_hash_batch(ctx: *mut pmx_ctx, input: *const u64, in_len: usize, out: *mut u64, out_len: usize, n: usize) -> c_int;
+    pub fn pmx_sponge_absorb_batch(ctx: *mut pmx_ctx, states: *mut u64, mode_tag: *mut u32, mode_index: *mut u32,
+                                   input: *const u64, in_len: usize, n: usize) -> c_int;
+    pub fn pmx_sponge_squeeze_batch(ctx: *mut pmx_ctx, states: *mut u64, mode_tag: *mut u32, mode_index: *mut u32,
+                                    out: *mut u64, out_len: usize, n: usize) -> c_int;
+    pub fn pmx_merkle_2to1(ctx: *mut pmx_ctx, leaves: *const u64, n_leaves: usize, nodes: *mut u64, root: *mut u64) -> c_int;
+    pub fn pmx_find_poseidon_ark_and_mds(modulus: *const u64, prime_bits: u64, rate: u32, full_rounds: u32,
+                                         partial_rounds: u32, skip_matrices: u32, ark_out: *mut u64, mds_out: *mut u64) -> c_int;
+}
