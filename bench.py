@@ -7,8 +7,9 @@ A "step" is one pass of the hot path (pmx_permute_batch_dev: PoseidonSponge::per
 reference src/poseidon/mod.rs:95-118) over one device-resident batch of synthetic random states.
 Workload at N=1: BASELINE.json configs[1] -- 2^20 independent states, BLS12-381 Fr, t=3, alpha=5, 8+31
 rounds.  For N>1 (launched by torch.distributed.run, one rank per GPU) every rank permutes its own
-2^20-state shard (weak scaling, no data-path collective) and the permuted shards are all-gathered over
-RCCL, double-buffered so the gather of step k overlaps the permutation of step k+1 ("final gather").
+2^20-state shard (weak scaling, NO collective on the data path); after the K steps the result shards are
+all-gathered once over RCCL inside the timed region (the "final gather"; --gather overlap|serial gathers after
+every step instead).
 
 Rank 0 prints ONE JSON line.  `value` = permutations per second over all ranks, inputs already in HBM.
 `roofline` prices the permutation kernel against HBM (algorithmic 2*t*32 bytes per permutation);
@@ -64,8 +65,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--states-per-gpu-log2", type=int, default=None)
-    ap.add_argument("--gather", default="overlap", choices=["overlap", "serial", "none"],
-                    help="N>1: all-gather of each step's output shard (RCCL)")
+    ap.add_argument("--gather", default="final", choices=["final", "overlap", "serial", "none"],
+                    help="N>1: 'final' = one RCCL all-gather of the result shards after the K steps (inside the timed "
+                         "region); 'overlap'/'serial' = an all-gather after EVERY step (double-buffered / blocking)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -157,9 +159,13 @@ def main():
 
         def drain():
             pass
+
+        def final_gather():
+            pass
     else:
         # this rank's shard of the global seeded batch [world*n][t][4]
         host = synth.random_elements(field, n * t, seed, offset=rank * n * t)
+        per_step = world > 1 and args.gather in ("overlap", "serial")
         n_buf = 2 if (world > 1 and args.gather == "overlap") else 1
         bufs = [torch.from_numpy(host.view(np.int64).copy()).to(dev).reshape(n, t, 4) for _ in range(n_buf)]
         gathered = [torch.empty((world * n, t, 4), dtype=torch.int64, device=dev) for _ in range(n_buf)] \
@@ -172,8 +178,8 @@ def main():
             if pending[b] is not None:           # the gather that still reads this buffer
                 pending[b].wait()
                 pending[b] = None
-            ctx.permute_batch_dev(bufs[b].data_ptr(), n, stream.cuda_stream)
-            if gathered is not None:
+            ctx.permute_batch_dev(bufs[b].data_ptr(), n, stream.cuda_stream)   # no collective on the data path
+            if per_step:
                 _, work = D.all_gather_equal(bufs[b], out=gathered[b], async_op=True)
                 if args.gather == "serial":
                     work.wait()
@@ -186,6 +192,10 @@ def main():
                     pending[b].wait()
                     pending[b] = None
 
+        def final_gather():                      # the job's epilogue: every rank ends with the whole result
+            if world > 1 and args.gather == "final":
+                D.all_gather_equal(bufs[0], out=gathered[0])
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -194,6 +204,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
+    final_gather()      # also warms RCCL's lazily built rings up, outside the timed region
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -201,6 +212,7 @@ def main():
     for i in range(args.steps):
         step(i)
     drain()
+    final_gather()
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
