@@ -207,3 +207,26 @@ def test_merkle_trees_vs_c_oracle(name):
         want = cr.merkle(leaves, threads=0)
         assert np.array_equal(nodes, want), (name, m)
         assert np.array_equal(root, want[-1])
+
+
+@pytest.mark.parametrize("rate,alpha,rf,rp", [(3, 257, 8, 13), (8, 257, 8, 13), (1, 5, 8, 56), (11, 5, 8, 57), (4, 17, 8, 30)])
+def test_run_time_width_engine_vs_c_oracle(rate, alpha, rf, rp):
+    """Widths / exponents outside the specialised engines run on the LDS-resident run-time-width engine
+    (weights-optimised table alpha = 257, t = 2, t = 12, alpha = 17 at t = 5): dense schedule against the C port."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    cfg = S.poseidon_config_from_lfsr(f, rate, alpha, rf, rp)
+    ocfg = O.make_config(O.BLS12_381_FR, 255, rate, alpha, rf, rp)
+    t = rate + 1
+    cr = cref.CRef(ocfg)
+    for n in (1, 64, 130):
+        states = synth.random_elements(f, n * t, seed=77 * rate + n).reshape(n, t, 4)
+        assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0)), (rate, n)
+    L = 2 * rate + 1
+    msgs = synth.random_elements(f, 70 * L, seed=rate).reshape(70, L, 4)
+    assert np.array_equal(cfg.context().hash_batch(msgs, L, rate + 1), cr.hash_batch(msgs, L, rate + 1, threads=0))
+    if rate >= 2:
+        leaves = synth.random_elements(f, 128, seed=5)
+        nodes, _ = cfg.context().merkle_2to1(leaves)
+        assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
