@@ -1,0 +1,66 @@
+"""2-to-1 Poseidon Merkle trees on the GPU: the natural consumer of the compression mode (SURVEY section 8(f) rank 4;
+the container itself lives upstream in ark-crypto-primitives, not in arkworks-rs/sponge).
+
+A parent is  (PoseidonSponge::new; absorb([left, right]); squeeze_native_field_elements(1))[0]
+(reference src/poseidon/mod.rs:219-254, 321-341).  Nodes are kept as one array [2m-1][4]: leaves, then every level,
+root last - the layout pmx_merkle_2to1 produces.  Authentication paths are verified in batch: all paths advance
+one level per hash_batch call."""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+
+from .poseidon import PoseidonConfig
+
+
+class MerkleTree:
+    def __init__(self, parameters: PoseidonConfig, leaves: np.ndarray, device: int = 0):
+        leaves = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4)
+        m = leaves.shape[0]
+        assert m >= 1 and (m & (m - 1)) == 0, "number of leaves must be a power of two"
+        self.parameters = parameters
+        self.device = device
+        self.n_leaves = m
+        self.depth = m.bit_length() - 1
+        if m == 1:
+            self.nodes, self._root = leaves.copy(), leaves[0].copy()
+        else:
+            self.nodes, self._root = parameters.context(device).merkle_2to1(leaves)
+
+    @property
+    def root(self) -> np.ndarray:
+        return self._root
+
+    def level_offset(self, level: int) -> int:
+        """Index of the first node of `level` (0 = leaves) in `nodes`."""
+        return 2 * self.n_leaves - (self.n_leaves >> (level - 1) if level else 2 * self.n_leaves)
+
+    def path(self, leaf_index: int) -> np.ndarray:
+        """Sibling of the leaf, then of each ancestor, bottom-up: [depth][4]."""
+        assert 0 <= leaf_index < self.n_leaves
+        out = np.zeros((self.depth, 4), dtype=np.uint64)
+        idx = leaf_index
+        for level in range(self.depth):
+            out[level] = self.nodes[self.level_offset(level) + (idx ^ 1)]
+            idx >>= 1
+        return out
+
+
+def verify_paths(parameters: PoseidonConfig, leaves: np.ndarray, indices, paths: np.ndarray, root: np.ndarray,
+                 device: int = 0) -> np.ndarray:
+    """k authentication paths at once: leaves [k][4], indices [k], paths [k][depth][4] -> bool[k]."""
+    cur = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4).copy()
+    idx = np.asarray(indices, dtype=np.int64).copy()
+    paths = np.ascontiguousarray(paths, dtype=np.uint64)
+    k, depth = cur.shape[0], paths.shape[1] if paths.ndim == 3 else 0
+    ctx = parameters.context(device)
+    for level in range(depth):
+        sib = paths[:, level, :]
+        right = (idx & 1).astype(bool)[:, None]             # current node is the right child
+        pair = np.empty((k, 2, 4), dtype=np.uint64)
+        pair[:, 0, :] = np.where(right, sib, cur)
+        pair[:, 1, :] = np.where(right, cur, sib)
+        cur = ctx.hash_batch(pair, 2, 1).reshape(k, 4)
+        idx >>= 1
+    return np.all(cur == np.asarray(root, dtype=np.uint64).reshape(1, 4), axis=1)

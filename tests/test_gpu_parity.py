@@ -230,3 +230,26 @@ def test_run_time_width_engine_vs_c_oracle(rate, alpha, rf, rp):
         leaves = synth.random_elements(f, 128, seed=5)
         nodes, _ = cfg.context().merkle_2to1(leaves)
         assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
+
+
+def test_merkle_tree_paths():
+    """Tree container + batch path verification (2-to-1 compression mode) against the oracle's tree."""
+    from oracle import poseidon_oracle as O
+    cfg = product_config("bls_t3_a5_8_31")
+    f = cfg.field
+    m = 64
+    leaves = synth.random_elements(f, m, seed=11)
+    tree = S.MerkleTree(cfg, leaves)
+    levels = O.merkle_levels(oracle_config("bls_t3_a5_8_31"), f.to_ints(leaves))
+    assert f.to_ints(tree.root.reshape(1, 4)) == levels[-1]
+    idx = [0, 1, 37, 63]
+    paths = np.stack([tree.path(i) for i in idx])
+    for i, p in zip(idx, paths):                      # siblings bottom-up
+        want = [levels[l][(i >> l) ^ 1] for l in range(6)]
+        assert f.to_ints(p) == want
+    ok = S.verify_paths(cfg, leaves[idx], idx, paths, tree.root)
+    assert ok.all()
+    bad = paths.copy()
+    bad[2, 3, 0] ^= np.uint64(1)                      # corrupt one sibling of the third path
+    assert list(S.verify_paths(cfg, leaves[idx], idx, bad, tree.root)) == [True, True, False, True]
+    assert not S.verify_paths(cfg, leaves[[1, 0]], [0, 1], paths[:2], tree.root).any()   # wrong leaves
