@@ -185,7 +185,11 @@ struct HybridEngine {
     OptTables tb;
     Scratch sc;
 
-    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return (size_t)T * kN * 64 * 4; }
+    // scratch slots for elements 0..T-2 (2304 B each) or the ABI staging of 64 states (2048 T B), whichever is larger
+    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) {
+        const size_t scratch = (size_t)(T - 1) * kN * 64 * 4, stage = (size_t)64 * kChunks * 16;
+        return scratch > stage ? scratch : stage;
+    }
 
     __device__ __forceinline__ HybridEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
         tb.mds = consts + d.mds_offset;

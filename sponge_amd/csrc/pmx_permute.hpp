@@ -126,21 +126,28 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
 // loop needs dynamic indexing, which goes through `Scratch` (one LDS slot array per lane on the device):
 //   sc.set(i, x) / sc.get(i)   i may be a run-time value
 // Matrix rows accumulate term by term into explicit 64-bit columns (only one 9-limb constant live at a time),
-// re-compressed every 3 terms.  The sparse partial rounds are fully unrolled and never touch the scratch.
+// re-compressed every 5 terms.  The sparse partial rounds are fully unrolled and never touch the scratch.
+// The scratch holds elements 0..T-2 only: the last element / matrix row is peeled off the rolled loops and handled
+// with a static index, which keeps the array at 2.25 (T-1) KiB - at t = 9 that is what lets 8 waves (2 per SIMD)
+// share a CU's 160 KiB of LDS instead of 7.
+template <int T>
+PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
+    Cols acc;
+    cols_zero(acc);
+    static_for<0, T>([&](auto j) {   // operands are norm here: 5 terms (45 products < 2^58) per compression
+        cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
+        if ((j % 5 == 4 && j + 1 < T) || j == T - 1) cols_compress(acc);
+    });
+    return cols_redc(acc, f);
+}
+
 template <int T, class Scratch>
 PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (uint32_t i = 0; i < (uint32_t)T; ++i) {
-        const uint32_t *row = mat + (size_t)i * T * kFeStride;
-        Cols acc;
-        cols_zero(acc);
-        static_for<0, T>([&](auto j) {   // operands are norm here: 5 terms (45 products < 2^58) per compression
-            cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
-            if ((j % 5 == 4 && j + 1 < T) || j == T - 1) cols_compress(acc);
-        });
-        sc.set(i, cols_redc(acc, f));
-    }
-    static_for<0, T>([&](auto i) { s[i] = sc.get(i); });
+    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, matrix_row<T>(s, mat + (size_t)i * T * kFeStride, f));
+    const Fe last = matrix_row<T>(s, mat + (size_t)(T - 1) * T * kFeStride, f);
+    static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
+    s[T - 1] = last;
 }
 
 template <int T, int ALPHA, class Scratch>
@@ -150,11 +157,12 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
         if (r < first_partial || r > last_partial) {            // full round
-            static_for<0, T>([&](auto i) { sc.set(i, s[i]); });
+            static_for<0, T - 1>([&](auto i) { sc.set(i, s[i]); });
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (uint32_t i = 0; i < (uint32_t)T; ++i)
+            for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i)
                 sc.set(i, fe_sbox<ALPHA>(fe_add_lazy(sc.get(i), fe_const(rk + i * kFeStride)), c.alpha, one, f));
-            static_for<0, T>([&](auto i) { s[i] = sc.get(i); });
+            s[T - 1] = fe_sbox<ALPHA>(fe_add_lazy(s[T - 1], fe_const(rk + (T - 1) * kFeStride)), c.alpha, one, f);
+            static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
             matrix_rows_rolled<T>(s, sc, tb.mds, f);
             continue;
         }
@@ -162,14 +170,8 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
         s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         if (r < last_partial) {
             const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
-            Cols acc;
-            cols_zero(acc);
-            static_for<0, T>([&](auto j) {
-                cols_mul_acc(acc, s[j], fe_const(sp + j * kFeStride));
-                if ((j % 5 == 4 && j + 1 < T) || j == T - 1) cols_compress(acc);
-            });
             const Fe z0 = s[0];
-            s[0] = cols_redc(acc, f);
+            s[0] = matrix_row<T>(s, sp, f);
             static_for<1, T>([&](auto i) {
                 PMX_SCHED_FENCE();
                 s[i] = fe_add_weak(s[i], mont_mul(z0, fe_const(sp + (T + i - 1) * kFeStride), f), f);

@@ -64,8 +64,9 @@ extern "C" int hc_permute_coop(const pmx_config *cfg, uint64_t *states, size_t n
     return PMX_OK;
 }
 
+template <int T>
 struct HostScratch {
-    Fe slot[PMX_MAX_WIDTH];
+    Fe slot[T - 1];   // the engines give the scratch T-1 slots: index T-1 must never be used (ASan checks it)
     Fe get(uint32_t i) const { return slot[i]; }
     void set(uint32_t i, const Fe &x) { slot[i] = x; }
 };
@@ -79,7 +80,7 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
     tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
-        HostScratch sc;
+        HostScratch<T> sc;
         for (int i = 0; i < T; ++i) s[i] = fe_from_abi(load_abi(states + (k * T + i) * 4), pp.f);
         if (pp.c.alpha == 5) permute_hybrid<T, 5>(s, sc, tb, pp.c, pp.one, pp.f);
         else if (pp.c.alpha == 17) permute_hybrid<T, 17>(s, sc, tb, pp.c, pp.one, pp.f);
