@@ -38,7 +38,11 @@ WORKLOADS = {
     # 2-to-1 Merkle compression: every rank reduces its own 2^21-leaf subtree level by level (2^21 - 1
     # permutations), the subtree roots are all-gathered and the top log2(N) levels finished on every rank
     "c5": ("bls12_381_fr", 2, 5, 8, 31, 21, 0x5EED0005, "bls12_381_fr t=3 alpha=5 2-to-1 Merkle tree, 2^21 leaves/GPU"),
+    # the absorb/squeeze batch driver (pmx_hash_batch_dev): per row new; absorb(L); squeeze_native(1)
+    "h3": ("bls12_381_fr", 2, 5, 8, 31, 20, 0x5EED0006, "bls12_381_fr t=3 alpha=5 hash of 4 elements -> 1 (2 permutations/row), 2^20 rows/GPU"),
+    "h9": ("bn254_fr", 8, 5, 8, 57, 18, 0x5EED0007, "bn254_fr t=9 alpha=5 hash of 8 elements -> 1 (1 permutation/row), 2^18 rows/GPU"),
 }
+HASH_SHAPES = {"h3": (4, 1, 2), "h9": (8, 1, 1)}     # workload -> (in_len, out_len, permutations per row)
 
 
 def mads_per_permutation(t, alpha, rf, rp, optimised):
@@ -143,7 +147,23 @@ def main():
 
     stream = torch.cuda.current_stream()
     merkle = args.workload == "c5"
-    if merkle:
+    hashing = args.workload in HASH_SHAPES
+    if hashing:
+        in_len, out_len, perms_per_row = HASH_SHAPES[args.workload]
+        host = synth.random_elements(field, n * in_len, seed, offset=rank * n * in_len)
+        d_in = torch.from_numpy(host.view(np.int64).copy()).to(dev)
+        d_out = torch.zeros((n, out_len, 4), dtype=torch.int64, device=dev)
+        units_per_step = float(world) * n * perms_per_row
+
+        def step(i):
+            ctx.hash_batch_dev(d_in.data_ptr(), in_len, d_out.data_ptr(), out_len, n, stream.cuda_stream)
+
+        def drain():
+            pass
+
+        def final_gather():
+            pass
+    elif merkle:
         # leaves of this rank's subtree, resident in the first n rows of the node array [2n-1][4]
         host = synth.random_elements(field, n, seed, offset=rank * n)
         nodes = torch.zeros((2 * n - 1, 4), dtype=torch.int64, device=dev)
@@ -230,6 +250,8 @@ def main():
         kernel_s = dev_s / args.steps
         per_gpu_units = units_per_step / world
         bytes_per_unit = 96 if merkle else 2 * t * 32       # 2*t*32 B per permutation; 64 in + 32 out per 2-to-1
+        if hashing:
+            bytes_per_unit = (in_len + out_len) * 32 / perms_per_row
         algo_bytes = bytes_per_unit * per_gpu_units
         achieved = algo_bytes / kernel_s / 1e9
         mads = mads_per_permutation(t, alpha, rf, rp, optimised=(t == 3 or (4 <= t <= 9 and alpha == 5))) + (3 if merkle else 2 * t) * 162   # + ABI conversions
@@ -244,7 +266,8 @@ def main():
                        "sharding": f"contiguous x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
-                         "kernel": "pmx::hash_kernel (per tree level)" if merkle else "pmx::permute_kernel",
+                         "kernel": "pmx::compress_kernel / compress_coop_kernel (per tree level)" if merkle else
+                                   ("pmx::hash_kernel" if hashing else "pmx::permute_kernel"),
                          "kernel_ms": 1e3 * kernel_s, "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer-VALU bound, not HBM bound (DESIGN.md): see int_valu"},
             "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": VALU_MAD_PEAK,

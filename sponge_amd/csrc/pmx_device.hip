@@ -443,19 +443,60 @@ __device__ __forceinline__ uint32_t squeeze_elements(Engine &e, uint64_t *row, s
     return idx;
 }
 
+// Fixed-shape hash: every row runs  new; absorb(in_len elements); squeeze_native(out_len)  with the same lengths,
+// so the whole state machine is wave-uniform.  It is written as ONE loop around ONE permutation call site (the
+// permutation is the bulk of the kernel's code; two inlined copies overflow the instruction cache at t = 9).
 template <class Engine>
 __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     hash_kernel(const DevConfig d, const uint32_t *__restrict__ consts, const uint64_t *__restrict__ in, size_t in_len,
                 uint64_t *__restrict__ out, size_t out_len, size_t n) {
     Engine e(d, consts);
+    const Rounds &c = e.c;
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
     e.zero();                                                  // CryptographicSponge::new, mod.rs:219-230
     const uint64_t *row_in = in + (active ? gid : 0) * in_len * 4;
     uint64_t *row_out = out + (active ? gid : 0) * out_len * 4;
-    (void)absorb_elements(e, row_in, in_len, 0, active);
-    // the sponge is Absorbing here, so the squeeze always permutes first (mod.rs:324-328)
-    (void)squeeze_elements(e, row_out, out_len, 0, true, active);
+    size_t k_in = 0, rem = out_len, pos = 0;
+    uint32_t idx = 0;
+    bool squeezing = false, need = false;
+    for (;;) {
+        if (need) {
+            e.permute();
+            need = false;
+        }
+        if (k_in < in_len) {                                   // absorb_internal, mod.rs:121-150
+            if (idx == c.rate) {                               // rate full and more input remains
+                need = true;
+                idx = 0;
+                continue;
+            }
+            Fe x = fe_zero();
+            if (active) x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row_in + 4 * k_in)), e.f);
+            const uint32_t at = c.capacity + idx;
+            e.set(at, fe_normalize(fe_add_lazy(e.get(at), x)));
+            ++idx;
+            ++k_in;
+            continue;
+        }
+        if (!squeezing) {                                      // Absorbing -> permute, squeeze from 0 (mod.rs:324-328)
+            squeezing = true;
+            need = true;
+            idx = 0;
+            continue;
+        }
+        const bool last = idx + rem <= c.rate;                 // squeeze_internal, mod.rs:153-182
+        const uint32_t take = last ? (uint32_t)rem : c.rate - idx;
+        for (uint32_t k = 0; k < take; ++k) {
+            const Abi v = fe_to_abi(e.get(c.capacity + idx + k), e.f);
+            if (active) abi_store(reinterpret_cast<uint32_t *>(row_out + 4 * (pos + k)), v);
+        }
+        if (last) break;
+        need = rem != c.rate;                                  // mod.rs:175, tested before the slice is advanced
+        rem -= take;
+        pos += take;
+        idx = 0;
+    }
 }
 
 // 2-to-1 compression, the Merkle-tree primitive:  out = (new; absorb([l, r]); squeeze_native(1))[0]

@@ -20,6 +20,8 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 
 timeout 600 python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 timeout 600 python bench.py --workload c3 --steps 5 --warmup 1 --cpu-seconds 6 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 timeout 600 python bench.py --workload c5 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+timeout 600 python bench.py --workload h3 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_h3.json 2> $OUT/bench_h3.err
+timeout 600 python bench.py --workload h9 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_h9.json 2> $OUT/bench_h9.err
 timeout 300 python tools/host_path_rate.py > $OUT/host_path.json 2> $OUT/host_path.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c2 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_c2.log 2>&1
@@ -31,4 +33,4 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c2 
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_c2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq_c2.log 2>&1
 cd $R
 python tools/extract_traffic.py $OUT/pmc_fetch_c2 $OUT/pmc_write_c2 permute_kernel c2 $OUT/hbm_traffic.json > $OUT/traffic.log 2>&1
-tail -3 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log; cat $OUT/bench_c2.json $OUT/bench_c3.json $OUT/bench_c5.json | cut -c1-420; cat $OUT/host_path.json; cat $OUT/traffic.log
+tail -3 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log; cat $OUT/bench_c2.json $OUT/bench_c3.json $OUT/bench_c5.json $OUT/bench_h3.json $OUT/bench_h9.json | cut -c1-420; cat $OUT/host_path.json; cat $OUT/traffic.log
