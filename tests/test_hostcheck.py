@@ -132,3 +132,34 @@ def test_permutation_templates_match_c_oracle_on_random_batch(hc):
     states = sy.random_elements(S.BN254_FR, 64 * 9, seed=78).reshape(64, 9, 4)
     want = cref.CRef(oracle_config("bn254_t9_a5_8_57")).permute_batch(states, threads=0)
     assert np.array_equal(run_permute(hc, "bn254_t9_a5_8_57", states, hybrid=True), want)
+
+
+PALLAS_FP = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001      # 255 bits, not a reference field
+SMALL_P = (1 << 230) + 0x1D                                                         # pseudo-modulus near the lower limit
+
+
+def _odd_modulus_config(p, bits, rate, alpha, rf, rp):
+    return O.make_config(p, bits, rate, alpha, rf, rp)
+
+
+@pytest.mark.parametrize("p", [PALLAS_FP])
+def test_other_255_bit_prime(hc, p):
+    """Nothing in the arithmetic is specific to the two benchmarked fields: a third 255-bit prime (Pallas base field),
+    constants from the same Grain-LFSR procedure, all four schedules against the big-integer oracle."""
+    from sponge_amd._lib import PmxConfig
+    cfg = O.make_config(p, 255, 2, 5, 8, 56)
+    rng = random.Random(99)
+    states = [[rng.randrange(p) for _ in range(3)] for _ in range(8)] + [[p - 1] * 3, [0, 0, 0]]
+    want = [x for st in states for x in O.permute(cfg, st)]
+    limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), 3, 4)
+    ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+    mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+    c = PmxConfig()
+    c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = 8, 56, 5, 2, 1
+    for i, l in enumerate(O.to_limbs(p)):
+        c.modulus[i] = l
+    c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+    for fn in (hc.hc_permute, hc.hc_permute_rt, hc.hc_permute_opt, hc.hc_permute_hybrid, hc.hc_permute_coop):
+        out = limbs.copy()
+        assert fn(ctypes.byref(c), out.ctypes.data, len(states)) == 0
+        assert cref.limbs_to_elems(out, p) == want, fn.__name__
