@@ -23,6 +23,8 @@ extern "C" {
     pub fn pmx_last_error() -> *const c_char;
     pub fn pmx_ctx_create(cfg: *const pmx_config, device: c_int, out: *mut *mut pmx_ctx) -> c_int;
     pub fn pmx_ctx_destroy(ctx: *mut pmx_ctx) -> c_int;
+    pub fn pmx_host_alloc(ptr: *mut *mut c_void, bytes: usize) -> c_int;
+    pub fn pmx_host_free(ptr: *mut c_void) -> c_int;
     pub fn pmx_permute_batch(ctx: *mut pmx_ctx, states: *mut u64, n: usize) -> c_int;
     pub fn pmx_permute_batch_dev(ctx: *mut pmx_ctx, d_states: *mut u64, n: usize, stream: *mut c_void) -> c_int;
     pub fn pmx_hash_batch(ctx: *mut pmx_ctx, input: *const u64, in_len: usize, out: *mut u64, out_len: usize, n: usize) -> c_int;

@@ -46,6 +46,8 @@ SIGNATURES = {
     "pmx_abi_version": (ctypes.c_int, []),
     "pmx_last_error": (ctypes.c_char_p, []),
     "pmx_device_count": (ctypes.c_int, []),
+    "pmx_host_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _sz]),
+    "pmx_host_free": (ctypes.c_int, [ctypes.c_void_p]),
     "pmx_find_poseidon_ark_and_mds": (ctypes.c_int, [_u64p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                                      ctypes.c_uint32, ctypes.c_uint32, _u64p, _u64p]),
     "pmx_mont_constants": (ctypes.c_int, [_u64p, _u64p, _u64p, _u64p]),

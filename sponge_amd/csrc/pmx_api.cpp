@@ -46,6 +46,7 @@ struct pmx_ctx {
     DevConfig dev;           // kernel-argument block (points at d_consts)
     uint32_t *d_consts;      // device: ark | mds as u32 limbs
     hipStream_t stream;      // used by the host-buffer entry points
+    hipStream_t stream2;     // second lane of the pinned-memory pipeline
     void *scratch[4];        // grow-only device staging for the host-buffer entry points
     size_t scratch_bytes[4];
 };
@@ -103,6 +104,7 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     e = hipMalloc((void **)&ctx->d_consts, bytes);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_consts, pp.consts.data(), bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     if (e != hipSuccess) {
         if (ctx->d_consts) (void)hipFree(ctx->d_consts);
         delete ctx;
@@ -127,9 +129,11 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
 extern "C" int pmx_ctx_destroy(pmx_ctx *ctx) {
     if (!ctx) return PMX_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
+    for (hipStream_t st : {ctx->stream, ctx->stream2}) {
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
     }
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
@@ -141,6 +145,35 @@ extern "C" int pmx_ctx_destroy(pmx_ctx *ctx) {
 extern "C" int pmx_ctx_width(const pmx_ctx *ctx) { return ctx ? (int)ctx->t : 0; }
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+// ---- pinned host memory ----------------------------------------------------------------------------
+extern "C" int pmx_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr) return set_error(PMX_ERR_ARG, "pmx_host_alloc: null pointer");
+    *ptr = nullptr;
+    PMX_HIP(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return PMX_OK;
+}
+
+extern "C" int pmx_host_free(void *ptr) {
+    if (ptr) PMX_HIP(hipHostFree(ptr));
+    return PMX_OK;
+}
+
+static bool is_pinned(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();   // an ordinary (unregistered) host pointer: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// chunks of a batch for the pinned pipeline: rows per chunk (multiple of 256), at most 8 chunks
+static size_t pipeline_rows(size_t n) {
+    if (n < ((size_t)1 << 16)) return n;
+    const size_t rows = (n + 7) / 8;
+    return (rows + 255) / 256 * 256;
+}
 
 // ---- permutation ---------------------------------------------------------------------------------
 extern "C" int pmx_permute_batch_dev(pmx_ctx *ctx, uint64_t *d_states, size_t n, void *stream) {
@@ -159,13 +192,21 @@ extern "C" int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n) {
     if (n == 0) return PMX_OK;
     int rc = ctx_bind(ctx);
     if (rc) return rc;
-    const size_t bytes = n * ctx->t * 32;
+    const size_t row = (size_t)ctx->t * 32, bytes = n * row;
     void *d = nullptr;
     if ((rc = ctx_scratch(ctx, 0, bytes, &d))) return rc;
-    PMX_HIP(hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = pmx_permute_batch_dev(ctx, (uint64_t *)d, n, ctx->stream))) return rc;
-    PMX_HIP(hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t step = is_pinned(states) ? pipeline_rows(n) : n;   // pinned: overlap H2D / kernel / D2H
+    int lane = 0;
+    for (size_t first = 0; first < n; first += step, lane ^= 1) {
+        const size_t cnt = n - first < step ? n - first : step;
+        hipStream_t st = lane ? ctx->stream2 : ctx->stream;
+        char *h = (char *)states + first * row, *dd = (char *)d + first * row;
+        PMX_HIP(hipMemcpyAsync(dd, h, cnt * row, hipMemcpyHostToDevice, st));
+        if ((rc = pmx_permute_batch_dev(ctx, (uint64_t *)dd, cnt, st))) return rc;
+        PMX_HIP(hipMemcpyAsync(h, dd, cnt * row, hipMemcpyDeviceToHost, st));
+    }
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream2));
     return PMX_OK;
 }
 
@@ -190,10 +231,20 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
     void *d_in = nullptr, *d_out = nullptr;
     if ((rc = ctx_scratch(ctx, 0, in_bytes, &d_in))) return rc;
     if ((rc = ctx_scratch(ctx, 1, out_bytes, &d_out))) return rc;
-    if (in_bytes) PMX_HIP(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = pmx_hash_batch_dev(ctx, (const uint64_t *)d_in, in_len, (uint64_t *)d_out, out_len, n, ctx->stream))) return rc;
-    if (out_bytes) PMX_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t in_row = in_len * 32, out_row = out_len * 32;
+    const size_t step = ((!in_bytes || is_pinned(in)) && (!out_bytes || is_pinned(out))) ? pipeline_rows(n) : n;
+    int lane = 0;
+    for (size_t first = 0; first < n; first += step, lane ^= 1) {
+        const size_t cnt = n - first < step ? n - first : step;
+        hipStream_t st = lane ? ctx->stream2 : ctx->stream;
+        const char *h_in = (const char *)in + first * in_row;
+        char *dd_in = (char *)d_in + first * in_row, *dd_out = (char *)d_out + first * out_row;
+        if (in_bytes) PMX_HIP(hipMemcpyAsync(dd_in, h_in, cnt * in_row, hipMemcpyHostToDevice, st));
+        if ((rc = pmx_hash_batch_dev(ctx, (const uint64_t *)dd_in, in_len, (uint64_t *)dd_out, out_len, cnt, st))) return rc;
+        if (out_bytes) PMX_HIP(hipMemcpyAsync((char *)out + first * out_row, dd_out, cnt * out_row, hipMemcpyDeviceToHost, st));
+    }
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream2));
     return PMX_OK;
 }
 

@@ -86,6 +86,26 @@ inline Fp fp_from_decimal(const Field &f, const std::string &dec) {
     return fp_from_bigint(f, acc);
 }
 
+// std::allocator-compatible allocator for page-locked host memory (pmx_host_alloc): with
+// std::vector<Fp, PinnedAllocator<Fp>> the host entry points pipeline the PCIe copies with the kernel.
+template <class T>
+struct PinnedAllocator {
+    using value_type = T;
+    PinnedAllocator() = default;
+    template <class U>
+    PinnedAllocator(const PinnedAllocator<U> &) {}
+    T *allocate(size_t n) {
+        void *p = nullptr;
+        check(pmx_host_alloc(&p, n * sizeof(T)));
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) noexcept { pmx_host_free(p); }
+    template <class U>
+    bool operator==(const PinnedAllocator<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const PinnedAllocator<U> &) const { return false; }
+};
+
 struct DuplexSpongeMode {
     enum Tag : uint32_t { kAbsorbing = PMX_MODE_ABSORBING, kSqueezing = PMX_MODE_SQUEEZING } tag;
     size_t index;   // next_absorb_index / next_squeeze_index

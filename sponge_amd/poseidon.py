@@ -126,6 +126,31 @@ def poseidon_config_from_lfsr(field: Field, rate: int, alpha: int, full_rounds: 
 
 
 # ---------------------------------------------------------------------------------------------------
+# Pinned host memory
+# ---------------------------------------------------------------------------------------------------
+class _PinnedOwner:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            _lib.lib().pmx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape) -> np.ndarray:
+    """uint64 array in page-locked host memory (pmx_host_alloc): the host-buffer entry points then pipeline the
+    PCIe copies with the kernel.  The memory lives as long as the returned array (or views of it)."""
+    n = int(np.prod(shape))
+    ptr = ctypes.c_void_p()
+    _lib.check(_lib.lib().pmx_host_alloc(ctypes.byref(ptr), max(n, 1) * 8))
+    buf = (ctypes.c_uint64 * max(n, 1)).from_address(ptr.value)
+    buf._pmx_owner = _PinnedOwner(ptr)          # freed when the last view of the buffer goes away
+    return np.frombuffer(buf, dtype=np.uint64, count=n).reshape(shape)
+
+
+# ---------------------------------------------------------------------------------------------------
 # Device context
 # ---------------------------------------------------------------------------------------------------
 def _ptr(a: Optional[np.ndarray]):
@@ -167,6 +192,12 @@ class Context:
         n = out.size // (self.cfg.t * 4)
         _lib.check(_lib.lib().pmx_permute_batch(self._h, _ptr(out), n))
         return out
+
+    def permute_batch_inplace(self, states: np.ndarray) -> None:
+        """pmx_permute_batch on the caller's buffer itself (C-contiguous uint64 [n][t][4]; pinned_empty() memory
+        takes the pipelined PCIe path)."""
+        assert states.dtype == np.uint64 and states.flags["C_CONTIGUOUS"]
+        _lib.check(_lib.lib().pmx_permute_batch(self._h, _ptr(states), states.size // (self.cfg.t * 4)))
 
     def hash_batch(self, msgs: np.ndarray, in_len: int, out_len: int, n: Optional[int] = None) -> np.ndarray:
         msgs = np.ascontiguousarray(msgs, dtype=np.uint64)

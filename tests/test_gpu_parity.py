@@ -253,3 +253,28 @@ def test_merkle_tree_paths():
     bad[2, 3, 0] ^= np.uint64(1)                      # corrupt one sibling of the third path
     assert list(S.verify_paths(cfg, leaves[idx], idx, bad, tree.root)) == [True, True, False, True]
     assert not S.verify_paths(cfg, leaves[[1, 0]], [0, 1], paths[:2], tree.root).any()   # wrong leaves
+
+
+def test_pinned_host_buffers_take_the_pipelined_path_and_agree():
+    """Page-locked host buffers (pmx_host_alloc) switch pmx_permute_batch / pmx_hash_batch to the chunked two-stream
+    pipeline; results must equal the pageable path and the oracle, also for batch sizes that do not divide evenly."""
+    import ctypes
+    from sponge_amd import _lib
+    cfg = product_config("bls_t3_a5_8_31")
+    ctx = cfg.context()
+    for n in (100, (1 << 16) + 77, 1 << 17):
+        states = synth.random_elements(cfg.field, n * 3, seed=n).reshape(n, 3, 4)
+        want = ctx.permute_batch(states)                       # pageable
+        pin = S.pinned_empty((n, 3, 4))
+        pin[:] = states
+        ctx.permute_batch_inplace(pin)
+        assert np.array_equal(pin, want), n
+    n = (1 << 16) + 5
+    msgs = synth.random_elements(cfg.field, n * 4, seed=3).reshape(n, 4, 4)
+    want = ctx.hash_batch(msgs, 4, 2)
+    pin_in, pin_out = S.pinned_empty((n, 4, 4)), S.pinned_empty((n, 2, 4))
+    pin_in[:] = msgs
+    _lib.check(_lib.lib().pmx_hash_batch(ctx._h, ctypes.c_void_p(pin_in.ctypes.data), 4, ctypes.c_void_p(pin_out.ctypes.data), 2, n))
+    assert np.array_equal(pin_out, want)
+    sample = np.arange(0, n, 997)
+    assert np.array_equal(want[sample], c_oracle("bls_t3_a5_8_31").hash_batch(np.ascontiguousarray(msgs[sample]), 4, 2, threads=0))

@@ -1,0 +1,48 @@
+// Probe for the PCIe-inclusive host path: (a) pmx_permute_batch as is (pageable copies), (b) hipHostRegister + one
+// async round trip, (c) registered memory, chunked over two streams so H2D / kernel / D2H overlap.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../include/poseidon_mi355x.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int main() {
+    const uint64_t bls[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+    std::vector<uint64_t> ark(39 * 3 * 4), mds(9 * 4);
+    if (pmx_find_poseidon_ark_and_mds(bls, 255, 2, 8, 31, 0, ark.data(), mds.data())) return 1;
+    pmx_config cfg{}; cfg.full_rounds = 8; cfg.partial_rounds = 31; cfg.alpha = 5; cfg.rate = 2; cfg.capacity = 1;
+    memcpy(cfg.modulus, bls, 32); cfg.ark = ark.data(); cfg.mds = mds.data();
+    pmx_ctx *ctx; if (pmx_ctx_create(&cfg, 0, &ctx)) { printf("%s\n", pmx_last_error()); return 1; }
+    const size_t n = 1 << 20, bytes = n * 96;
+    std::vector<uint64_t> host(n * 12);
+    for (size_t i = 0; i < host.size(); ++i) host[i] = (i % 4 == 3) ? 0x1234567 + i : 0x9e3779b97f4a7c15ull * (i + 1);
+    void *dev; CK(hipMalloc(&dev, bytes));
+    hipStream_t st[2]; CK(hipStreamCreate(&st[0])); CK(hipStreamCreate(&st[1]));
+    for (int rep = 0; rep < 3; ++rep) {
+        double t0 = now(); pmx_permute_batch(ctx, host.data(), n); double ta = now() - t0;
+        t0 = now(); CK(hipHostRegister(host.data(), bytes, hipHostRegisterDefault)); double treg = now() - t0;
+        t0 = now();
+        CK(hipMemcpyAsync(dev, host.data(), bytes, hipMemcpyHostToDevice, st[0]));
+        pmx_permute_batch_dev(ctx, (uint64_t *)dev, n, st[0]);
+        CK(hipMemcpyAsync(host.data(), dev, bytes, hipMemcpyDeviceToHost, st[0]));
+        CK(hipStreamSynchronize(st[0])); double tb = now() - t0;
+        for (int chunks : {4, 8, 16}) {
+            t0 = now();
+            const size_t cn = n / chunks;
+            for (int k = 0; k < chunks; ++k) {
+                hipStream_t s = st[k & 1];
+                char *h = (char *)host.data() + (size_t)k * cn * 96, *d = (char *)dev + (size_t)k * cn * 96;
+                CK(hipMemcpyAsync(d, h, cn * 96, hipMemcpyHostToDevice, s));
+                pmx_permute_batch_dev(ctx, (uint64_t *)d, cn, s);
+                CK(hipMemcpyAsync(h, d, cn * 96, hipMemcpyDeviceToHost, s));
+            }
+            CK(hipStreamSynchronize(st[0])); CK(hipStreamSynchronize(st[1]));
+            printf("rep %d chunks %2d: %.2f ms\n", rep, chunks, (now() - t0) * 1e3);
+        }
+        t0 = now(); CK(hipHostUnregister(host.data())); double tun = now() - t0;
+        printf("rep %d: pageable %.2f ms | register %.2f ms, one round trip %.2f ms, unregister %.2f ms\n", rep, ta * 1e3, treg * 1e3, tb * 1e3, tun * 1e3);
+    }
+    return 0;
+}
