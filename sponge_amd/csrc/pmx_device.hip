@@ -23,6 +23,13 @@
 #include "pmx_launch.hpp"
 #include "pmx_permute.hpp"
 
+// The file is compiled three times (Makefile, in parallel): PMX_TU = 0 holds the t = 3 engine, the run-time-width
+// engine, the cooperative kernel and the public launchers; PMX_TU = 1 / 2 hold the hybrid engines for alpha = 5 and
+// for the generic S-box (6 widths x 5 kernels each - by far the longest compile).
+#ifndef PMX_TU
+#define PMX_TU 0
+#endif
+
 #ifndef PMX_CONSTS_IN_LDS
 #define PMX_CONSTS_IN_LDS 1   // RegEngine: 1 = stage ARK/MDS in LDS (broadcast reads), 0 = scalar loads from global
 #endif
@@ -637,9 +644,60 @@ struct Launch {
     }
 };
 
+#if PMX_TU != 0
+// ---- hybrid family of this translation unit -------------------------------------------------------------------------
+#if PMX_TU == 1
+#define PMX_HYB_ALPHA 5
+#define PMX_HYB_NAME(op) hybrid5_##op
+#else
+#define PMX_HYB_ALPHA 0
+#define PMX_HYB_NAME(op) hybridg_##op
+#endif
+#define PMX_HYB_DISPATCH(CALL)                                             \
+    switch (t) {                                                           \
+        case 4: return Launch<HybridEngine<4, PMX_HYB_ALPHA>>::CALL;       \
+        case 5: return Launch<HybridEngine<5, PMX_HYB_ALPHA>>::CALL;       \
+        case 6: return Launch<HybridEngine<6, PMX_HYB_ALPHA>>::CALL;       \
+        case 7: return Launch<HybridEngine<7, PMX_HYB_ALPHA>>::CALL;       \
+        case 8: return Launch<HybridEngine<8, PMX_HYB_ALPHA>>::CALL;       \
+        case 9: return Launch<HybridEngine<9, PMX_HYB_ALPHA>>::CALL;       \
+        default: return hipErrorInvalidValue;                              \
+    }
+
+hipError_t PMX_HYB_NAME(permute)(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
+    PMX_HYB_DISPATCH(permute(c, t, states, n, st));
+}
+hipError_t PMX_HYB_NAME(hash)(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
+                              size_t n, hipStream_t st) {
+    PMX_HYB_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
+}
+hipError_t PMX_HYB_NAME(compress)(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
+    PMX_HYB_DISPATCH(compress(c, t, in, out, n, st));
+}
+hipError_t PMX_HYB_NAME(absorb)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
+                                const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {
+    PMX_HYB_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st));
+}
+hipError_t PMX_HYB_NAME(squeeze)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
+                                 uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
+    PMX_HYB_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
+}
+
+#else  // PMX_TU == 0
+// ---- public launchers -------------------------------------------------------------------------------------------------
+#define PMX_HYB_DECL(P)                                                                                                          \
+    hipError_t P##permute(const DevConfig &, uint32_t, uint64_t *, size_t, hipStream_t);                                         \
+    hipError_t P##hash(const DevConfig &, uint32_t, const uint64_t *, size_t, uint64_t *, size_t, size_t, hipStream_t);          \
+    hipError_t P##compress(const DevConfig &, uint32_t, const uint64_t *, uint64_t *, size_t, hipStream_t);                      \
+    hipError_t P##absorb(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, const uint64_t *, size_t, size_t, hipStream_t); \
+    hipError_t P##squeeze(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint64_t *, size_t, size_t, hipStream_t);
+PMX_HYB_DECL(hybrid5_)
+PMX_HYB_DECL(hybridg_)
+
 // Engine choice: width 3 runs from registers, on the optimised schedule whenever its tables exist (the dense
-// schedule remains for configs without a partial section); widths 4..9 with alpha = 5 (the reference's default
-// table, src/test.rs:14-22) run on the register/LDS hybrid; everything else uses the LDS-resident engine.
+// schedule remains for configs without a partial section); widths 4..9 (every rate of the reference's default
+// tables, src/test.rs:14-31) run on the register/LDS hybrid - alpha = 5 specialised, any other exponent on the
+// generic S-box; everything else uses the LDS-resident run-time-width engine.
 // alpha 5 and 17 have dedicated addition chains, other exponents share the generic S-box.
 #define PMX_DISPATCH(CALL)                                                                  \
     do {                                                                                    \
@@ -650,13 +708,9 @@ struct Launch {
             return Launch<RegEngine<3, 0, true>>::CALL;                                     \
         }                                                                                   \
         if (t == 3) return Launch<RegEngine<3, 0, false>>::CALL;                            \
-        if (c.has_opt && alpha == 5) {                                                      \
-            if (t == 4) return Launch<HybridEngine<4, 5>>::CALL;                            \
-            if (t == 5) return Launch<HybridEngine<5, 5>>::CALL;                            \
-            if (t == 6) return Launch<HybridEngine<6, 5>>::CALL;                            \
-            if (t == 7) return Launch<HybridEngine<7, 5>>::CALL;                            \
-            if (t == 8) return Launch<HybridEngine<8, 5>>::CALL;                            \
-            if (t == 9) return Launch<HybridEngine<9, 5>>::CALL;                            \
+        if (c.has_opt && t >= 4 && t <= 9) {                                                \
+            if (alpha == 5) return hybrid5_##CALL;                                          \
+            return hybridg_##CALL;                                                          \
         }                                                                                   \
         if (alpha == 5) return Launch<LdsEngine<5>>::CALL;                                  \
         if (alpha == 17) return Launch<LdsEngine<17>>::CALL;                                \
@@ -670,6 +724,7 @@ hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_
                        size_t n, hipStream_t st) {
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
+
 // Levels of at most this many compressions run on the cooperative kernel: up to here the one-lane-per-state kernel
 // has at most a quarter of a wave per SIMD and is bound by the 51k-multiply dependent chain of a single permutation.
 static constexpr size_t kCoopMaxUnits = 16384;
@@ -697,5 +752,6 @@ hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
 }
+#endif  // PMX_TU
 
 }  // namespace pmx
