@@ -209,10 +209,13 @@ def test_merkle_trees_vs_c_oracle(name):
         assert np.array_equal(root, want[-1])
 
 
-@pytest.mark.parametrize("rate,alpha,rf,rp", [(3, 257, 8, 13), (8, 257, 8, 13), (1, 5, 8, 56), (11, 5, 8, 57), (4, 17, 8, 30)])
+@pytest.mark.parametrize("rate,alpha,rf,rp", [(3, 257, 8, 13), (8, 257, 8, 13), (1, 5, 8, 56), (11, 5, 8, 57), (4, 17, 8, 30),
+                                               (2, 3, 8, 10), (4, 2, 4, 5), (2, 1, 2, 3), (1, 0, 2, 2), (2, 5, 8, 0), (2, 7, 0, 9),
+                                               (5, 0xFFFFFFFFFFFFFFFF, 2, 2)])
 def test_run_time_width_engine_vs_c_oracle(rate, alpha, rf, rp):
-    """Widths / exponents outside the specialised engines run on the LDS-resident run-time-width engine
-    (weights-optimised table alpha = 257, t = 2, t = 12, alpha = 17 at t = 5): dense schedule against the C port."""
+    """Widths, exponents and round splits off the beaten path: weights-optimised table (alpha = 257), t = 2 and t = 12
+    (run-time-width engine), alpha = 17 at t = 5, degenerate exponents 0..3 and 2^64-1, no partial rounds, no full rounds
+    (dense schedule) - all against the C port."""
     from oracle import cref
     from oracle import poseidon_oracle as O
     f = S.BLS12_381_FR
