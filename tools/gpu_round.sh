@@ -30,7 +30,13 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5
 # HBM traffic: counters in their own passes, one counter block per pass (no trace/stats domains mixed in)
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_c2.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_c2.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c3 -- python3 $R/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_c3.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c3 -- python3 $R/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_c3.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c5 -- python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_c5.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c5 -- python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_c5.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_c2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq_c2.log 2>&1
 cd $R
 python tools/extract_traffic.py $OUT/pmc_fetch_c2 $OUT/pmc_write_c2 permute_kernel c2 $OUT/hbm_traffic.json > $OUT/traffic.log 2>&1
+python tools/extract_traffic.py $OUT/pmc_fetch_c3 $OUT/pmc_write_c3 permute_kernel c3 $OUT/hbm_traffic.json >> $OUT/traffic.log 2>&1
+python tools/extract_traffic.py $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 compress c5 $OUT/hbm_traffic.json 21 >> $OUT/traffic.log 2>&1
 tail -3 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log; cat $OUT/bench_c2.json $OUT/bench_c3.json $OUT/bench_c5.json $OUT/bench_h3.json $OUT/bench_h9.json | cut -c1-420; cat $OUT/host_path.json; cat $OUT/traffic.log
