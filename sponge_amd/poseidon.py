@@ -351,6 +351,15 @@ class PoseidonSponge:
             return self.squeeze_native_field_elements(num_elements)
         return self.squeeze_field_elements_with_sizes([None] * num_elements, field2)
 
+    def squeeze_native_field_elements_with_sizes(self, sizes) -> List[int]:
+        """FieldBasedCryptographicSponge::squeeze_native_field_elements_with_sizes (src/lib.rs:166-182): all sizes
+        Full (None) -> the plain native squeeze; otherwise the bit-recomposition default with F = the native field.
+        Returned as canonical integers."""
+        f = self.parameters.field
+        if all(sz is None for sz in sizes):
+            return f.to_ints(self.squeeze_native_field_elements(len(sizes)))
+        return self.squeeze_field_elements_with_sizes(sizes, f)
+
     def squeeze_field_elements_with_sizes(self, sizes, field2: Field) -> List[int]:
         """Non-native default (src/lib.rs:61-100): every requested element takes MODULUS_BIT_SIZE(F2) - 1 bits
         (FieldElementSize::num_bits ignores the Truncated value, src/lib.rs:45-52), little-endian, reduced mod p2.

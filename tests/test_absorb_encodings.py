@@ -105,6 +105,15 @@ def test_absorb_objects_fork_and_nonnative_squeeze_on_gpu():
     bits = oforked.squeeze_bits(253 * 4, 255)
     want = [sum(b << i for i, b in enumerate(bits[k * 253:(k + 1) * 253])) % O.BN254_FR for k in range(4)]
     assert got == want
+    # native squeeze with sizes (src/lib.rs:166-182): all Full == plain squeeze; a Truncated entry switches to the
+    # bit recomposition, where every element still takes MODULUS_BIT_SIZE - 1 = 254 bits (src/lib.rs:45-52)
+    s1, s2, o1 = forked.clone(), forked.clone(), oforked.clone()
+    assert s1.squeeze_native_field_elements_with_sizes([None, None]) == o1.squeeze_native_field_elements(2)
+    obits = oforked.clone().squeeze_bits(254 * 2, 255)
+    assert s2.squeeze_native_field_elements_with_sizes([None, 100]) == \
+        [sum(b << i for i, b in enumerate(obits[k * 254:(k + 1) * 254])) % P for k in range(2)]
+    with pytest.raises(ValueError):
+        forked.clone().squeeze_native_field_elements_with_sizes([256])      # panic at src/lib.rs:48
     # single_field_element (tests.rs:26-33): elem and elem + 1 give different outputs
     a, b = S.PoseidonSponge.new(cfg), S.PoseidonSponge.new(cfg)
     a.absorb(A.Fp(987654321, F))
