@@ -257,11 +257,13 @@ def main():
         mads = mads_per_permutation(t, alpha, rf, rp, optimised=(t == 3 or (4 <= t <= 9 and alpha == 5))) + (3 if merkle else 2 * t) * 162   # + ABI conversions
         mad_rate = mads * per_gpu_units / kernel_s
         out = {
-            "metric": "Poseidon permutations/sec", "value": value, "unit": "permutations/s",
+            "metric": "Poseidon permutations/sec (%s, t=%d)" % ({"bls12_381_fr": "BLS12-381 Fr", "bn254_fr": "BN254 Fr"}[field_name], t),
+            "value": value, "unit": "permutations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 (9x29-bit limb Montgomery, 255-bit modular integers)", "data": "synthetic",
-            "config": {"workload": desc, "units_per_gpu": n, "permutations_per_step": units_per_step,
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": desc, "arithmetic": "255-bit modular integers as 9 x 29-bit limbs in u32, Montgomery form",
+                       "units_per_gpu": n, "permutations_per_step": units_per_step,
                        "gather": (args.gather if (world > 1 and not merkle) else ("roots" if merkle and world > 1 else "n/a")),
                        "sharding": f"contiguous x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
