@@ -72,6 +72,7 @@ def parse_args():
     ap.add_argument("--gather", default="final", choices=["final", "overlap", "serial", "none"],
                     help="N>1: 'final' = one RCCL all-gather of the result shards after the K steps (inside the timed "
                          "region); 'overlap'/'serial' = an all-gather after EVERY step (double-buffered / blocking)")
+    ap.add_argument("--spinup-seconds", type=float, default=0.25, help="untimed device spin-up before the W warmup steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -221,6 +222,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Device spin-up (untimed, not counted as steps): the shader clock ramps over the first ~25 ms of activity
+    # (per-launch time falls from 2.5 ms to 2.07 ms across the first dozen launches, profiles/r01), so the W warmup
+    # steps alone would leave short runs measuring the ramp instead of the kernel.
+    t_spin = time.perf_counter()
+    i_spin = 0
+    while time.perf_counter() - t_spin < args.spinup_seconds:
+        step(i_spin)
+        i_spin += 1
+        if i_spin % 4 == 0:
+            drain()
+            torch.cuda.synchronize()
+    drain()
     for i in range(args.warmup):
         step(i)
     drain()
