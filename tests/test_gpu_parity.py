@@ -281,3 +281,25 @@ def test_pinned_host_buffers_take_the_pipelined_path_and_agree():
     assert np.array_equal(pin_out, want)
     sample = np.arange(0, n, 997)
     assert np.array_equal(want[sample], c_oracle("bls_t3_a5_8_31").hash_batch(np.ascontiguousarray(msgs[sample]), 4, 2, threads=0))
+
+
+@pytest.mark.parametrize("rate,capacity", [(1, 2), (3, 0), (2, 1), (4, 5)])
+def test_other_rate_capacity_splits(rate, capacity):
+    """PoseidonConfig::new accepts any rate/capacity split of the width (mod.rs:187-213); the default tables only use
+    capacity 1.  Same constants, different split: absorb / squeeze against the Python oracle."""
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    t = rate + capacity
+    base = S.poseidon_config_from_lfsr(f, t - 1, 5, 8, 20)           # constants for this width
+    cfg = S.PoseidonConfig(f, 8, 20, 5, base.mds, base.ark, rate, capacity)
+    ob = O.make_config(O.BLS12_381_FR, 255, t - 1, 5, 8, 20)
+    ocfg = O.PoseidonConfig(ob.p, 8, 20, 5, ob.ark, ob.mds, rate, capacity)
+    msg = [7, 8, 9, 10, 11]
+    sponge, osp = S.PoseidonSponge.new(cfg), O.PoseidonSponge(ocfg)
+    sponge.absorb(f.from_ints(msg))
+    osp.absorb(msg)
+    assert f.to_ints(sponge.squeeze_native_field_elements(2 * rate + 1)) == osp.squeeze_native_field_elements(2 * rate + 1)
+    sponge.absorb(f.from_ints(msg[:2]))
+    osp.absorb(msg[:2])
+    assert f.to_ints(sponge.squeeze_native_field_elements(1)) == osp.squeeze_native_field_elements(1)
+    assert f.to_ints(sponge.state) == osp.state and (sponge.mode.tag, sponge.mode.index) == (osp.mode, osp.index)
