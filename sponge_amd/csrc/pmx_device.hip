@@ -5,11 +5,13 @@
 // 16-B-per-lane contiguous stream, whatever t is.  Round constants and the MDS matrix are wave-uniform.
 // Arithmetic: pmx_field.hpp (unsaturated 9 x 29-bit Montgomery form); round schedule: pmx_permute.hpp.
 //
-// Two engines implement the same interface:
-//   RegEngine<T, ALPHA>  state in VGPRs, element loops unrolled, ARK+MDS staged in LDS.            (t = 3)
-//   LdsEngine<ALPHA>     any width at run time: state kept in LDS as [element][limb][lane]
-//                        (conflict-free 4-byte accesses), element loops rolled, constants through the
-//                        scalar cache.
+// Engines (same interface: load_states / store_states / get / set / zero / permute):
+//   RegEngine<3, ALPHA, OPT>   t = 3: state in VGPRs, element loops unrolled, tables staged in LDS.
+//   HybridEngine<T, ALPHA>     t = 4..9 on the optimised schedule: state in VGPRs, the element loops of the full
+//                              rounds rolled through one LDS scratch array per wave, tables via the scalar cache.
+//   LdsEngine<ALPHA>           any width at run time (t = 2, 10..16, or no partial section): state kept in LDS as
+//                              [element][limb][lane] (conflict-free 4-byte accesses), element loops rolled.
+// plus compress_coop_kernel: 2-to-1 compression with one state per quad of lanes, for latency-bound tree levels.
 //
 // Reference semantics implemented here (file:line in /root/reference):
 //   permute        src/poseidon/mod.rs:95-118   (apply_ark :76-80, apply_s_box :63-74, apply_mds :82-93)
