@@ -38,14 +38,14 @@ typedef struct {
 
 typedef struct { uint64_t l[4]; } fe;
 
-static inline int geq(const uint64_t a[4], const uint64_t b[4]) {
+static inline __attribute__((always_inline)) int geq(const uint64_t a[4], const uint64_t b[4]) {
     for (int i = 3; i >= 0; --i) {
         if (a[i] != b[i]) return a[i] > b[i];
     }
     return 1;
 }
 
-static inline void sub_n(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+static inline __attribute__((always_inline)) void sub_n(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
     uint64_t borrow = 0;
     for (int i = 0; i < 4; ++i) {
         u128 d = (u128)a[i] - b[i] - borrow;
@@ -55,7 +55,7 @@ static inline void sub_n(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]
 }
 
 /* r = a + b mod p   (Fp::add_assign) */
-static inline void fe_add(fe *r, const fe *a, const fe *b, const uint64_t p[4]) {
+static inline __attribute__((always_inline)) void fe_add(fe *r, const fe *a, const fe *b, const uint64_t p[4]) {
     uint64_t s[4], carry = 0;
     for (int i = 0; i < 4; ++i) {
         u128 v = (u128)a->l[i] + b->l[i] + carry;
@@ -67,10 +67,12 @@ static inline void fe_add(fe *r, const fe *a, const fe *b, const uint64_t p[4]) 
 }
 
 /* r = a * b * 2^-256 mod p   (Fp::mul on Montgomery residues), CIOS */
-static inline void fe_mul(fe *r, const fe *a, const fe *b, const uint64_t p[4], uint64_t inv) {
+static inline __attribute__((always_inline)) void fe_mul(fe *r, const fe *a, const fe *b, const uint64_t p[4], uint64_t inv) {
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+#pragma GCC unroll 4
     for (int i = 0; i < 4; ++i) {
         uint64_t c = 0;
+#pragma GCC unroll 4
         for (int j = 0; j < 4; ++j) {
             u128 v = (u128)a->l[j] * b->l[i] + t[j] + c;
             t[j] = (uint64_t)v;
@@ -82,6 +84,7 @@ static inline void fe_mul(fe *r, const fe *a, const fe *b, const uint64_t p[4], 
         uint64_t m = t[0] * inv;
         v = (u128)m * p[0] + t[0];
         c = (uint64_t)(v >> 64);
+#pragma GCC unroll 4
         for (int j = 1; j < 4; ++j) {
             v = (u128)m * p[j] + t[j] + c;
             t[j - 1] = (uint64_t)v;
