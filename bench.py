@@ -78,26 +78,6 @@ def parse_args():
     return ap.parse_args()
 
 
-def usable_cpus():
-    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (cpu.max), if any."""
-    n = len(os.sched_getaffinity(0))
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.999)))
-            else:
-                quota = int(txt[0])
-                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if quota > 0:
-                    n = min(n, max(1, int(quota / period + 0.999)))
-            break
-        except Exception:
-            continue
-    return n
-
-
 def cpu_baseline(field_name, rate, alpha, rf, rp, seed, target_seconds):
     """C restatement of the reference permutation (oracle/poseidon_ref.c) on all host cores."""
     from oracle import cref
@@ -109,7 +89,7 @@ def cpu_baseline(field_name, rate, alpha, rf, rp, seed, target_seconds):
     ocfg = O.make_config(p, bits, rate, alpha, rf, rp)
     cr = cref.CRef(ocfg)
     t = rate + 1
-    threads = max(1, min(cref.max_threads(), usable_cpus()))
+    threads = cref.max_threads()      # affinity mask capped by the cgroup CPU quota
     field = S.FIELDS[field_name]
     probe = synth.random_elements(field, 4096 * t, seed).reshape(4096, t, 4)
     t0 = time.perf_counter()

@@ -89,7 +89,8 @@ class CRef:
         return ctypes.c_void_p(a.ctypes.data)
 
     def permute_batch(self, states: np.ndarray, threads: int = 1) -> np.ndarray:
-        """states [n][t][4] Montgomery limbs -> permuted copy."""
+        """states [n][t][4] Montgomery limbs -> permuted copy.  threads=0: every usable CPU."""
+        threads = threads or max_threads()
         out = np.ascontiguousarray(states, dtype=np.uint64).copy()
         n = out.size // (self.cfg.t * 4)
         rc = lib().pref_permute_batch(ctypes.byref(self._c), self._ptr(out), ctypes.c_size_t(n),
@@ -98,6 +99,7 @@ class CRef:
         return out
 
     def hash_batch(self, msgs: np.ndarray, L: int, k: int, threads: int = 1) -> np.ndarray:
+        threads = threads or max_threads()
         msgs = np.ascontiguousarray(msgs, dtype=np.uint64)
         n = msgs.size // (L * 4) if L else msgs.shape[0]
         out = np.zeros((n, k, 4), dtype=np.uint64)
@@ -109,6 +111,7 @@ class CRef:
 
     def merkle(self, leaves: np.ndarray, threads: int = 1) -> np.ndarray:
         """leaves [m][4] -> nodes [2m-1][4] (leaves, then each level, root last)."""
+        threads = threads or max_threads()
         leaves = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4)
         m = leaves.shape[0]
         nodes = np.zeros((2 * m - 1, 4), dtype=np.uint64)
@@ -135,5 +138,26 @@ class CRef:
         return state, m.value, i.value, out
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (cpu.max), if any."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.999)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.999)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def max_threads() -> int:
-    return int(lib().pref_max_threads())
+    """Threads worth using: OpenMP's maximum capped by the CPUs this process may actually use."""
+    return max(1, min(int(lib().pref_max_threads()), usable_cpus()))
