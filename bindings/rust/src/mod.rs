@@ -80,7 +80,7 @@ impl<F: PrimeField> CryptographicSponge for Mi355xPoseidonSponge<F> {
         self.set_mode(tag, idx);
     }
 
-    fn squeeze_bytes(&mut self, num_bytes: usize) -> Vec<u8> {           // src/poseidon/mod.rs:256-270 verbatim
+    fn squeeze_bytes(&mut self, num_bytes: usize) -> Vec<u8> {           // semantics of src/poseidon/mod.rs:256-270
         let usable_bytes = ((F::MODULUS_BIT_SIZE - 1) / 8) as usize;
         let num_elements = (num_bytes + usable_bytes - 1) / usable_bytes;
         let mut bytes = Vec::with_capacity(usable_bytes * num_elements);
@@ -91,7 +91,7 @@ impl<F: PrimeField> CryptographicSponge for Mi355xPoseidonSponge<F> {
         bytes
     }
 
-    fn squeeze_bits(&mut self, num_bits: usize) -> Vec<bool> {            // src/poseidon/mod.rs:272-286 verbatim
+    fn squeeze_bits(&mut self, num_bits: usize) -> Vec<bool> {            // semantics of src/poseidon/mod.rs:272-286
         let usable_bits = (F::MODULUS_BIT_SIZE - 1) as usize;
         let num_elements = (num_bits + usable_bits - 1) / usable_bits;
         let mut bits = Vec::with_capacity(usable_bits * num_elements);

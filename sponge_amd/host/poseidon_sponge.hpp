@@ -210,6 +210,21 @@ inline std::optional<PoseidonConfig> get_default_poseidon_parameters(const Field
     return std::nullopt;
 }
 
+// FieldElementSize (src/lib.rs:34-58): Full, or Truncated(num_bits)
+struct FieldElementSize {
+    bool truncated = false;
+    size_t bits = 0;
+    static FieldElementSize Full() { return {}; }
+    static FieldElementSize Truncated(size_t num_bits) { return {true, num_bits}; }
+    // num_bits::<F>() (src/lib.rs:45-52): panics when the request exceeds the field, and otherwise ALWAYS answers
+    // MODULUS_BIT_SIZE - 1 - the Truncated value does not shorten the element in the reference
+    size_t num_bits(const Field &f) const {
+        if (truncated && bits > f.modulus_bit_size()) throw Error(PMX_ERR_ARG, "num_bits is greater than the capacity of the field.");
+        return f.modulus_bit_size() - 1;
+    }
+    bool operator==(const FieldElementSize &o) const { return truncated == o.truncated && (!truncated || bits == o.bits); }
+};
+
 struct PoseidonSpongeState {   // src/poseidon/mod.rs:346-349
     std::vector<Fp> state;
     DuplexSpongeMode mode;
@@ -305,6 +320,27 @@ public:
         return bits;
     }
 
+    // squeeze_field_elements_with_sizes::<F2> (mod.rs:288-304).  Same characteristic: the native path below.
+    // Otherwise the default of src/lib.rs:61-100: one squeeze_bits call for all elements, num_bits::<F2>() bits each,
+    // little-endian, through from_le_bytes_mod_order (the value is < 2^(bits(p2)-1) <= p2, so nothing is reduced).
+    // Elements come back as residues of `f2`.
+    std::vector<Fp> squeeze_field_elements_with_sizes(const std::vector<FieldElementSize> &sizes, const Field &f2) {
+        if (f2 == parameters.field) return squeeze_native_field_elements_with_sizes(sizes);
+        return squeeze_with_sizes_default(sizes, f2);
+    }
+    // squeeze_field_elements::<F2> (mod.rs:306-317)
+    std::vector<Fp> squeeze_field_elements(size_t num_elements, const Field &f2) {
+        if (f2 == parameters.field) return squeeze_native_field_elements(num_elements);
+        return squeeze_field_elements_with_sizes(std::vector<FieldElementSize>(num_elements), f2);
+    }
+    // FieldBasedCryptographicSponge::squeeze_native_field_elements_with_sizes (src/lib.rs:166-182)
+    std::vector<Fp> squeeze_native_field_elements_with_sizes(const std::vector<FieldElementSize> &sizes) {
+        bool all_full = true;
+        for (const auto &sz : sizes) all_full = all_full && !sz.truncated;
+        if (all_full) return squeeze_native_field_elements(sizes.size());
+        return squeeze_with_sizes_default(sizes, parameters.field);
+    }
+
     // SpongeExt (src/lib.rs:188-195, mod.rs:351-367)
     PoseidonSpongeState into_state() && { return {std::move(state), mode}; }
     static PoseidonSponge from_state(PoseidonSpongeState st, const PoseidonConfig &params, int device = 0) {
@@ -315,6 +351,23 @@ public:
     }
 
 private:
+    std::vector<Fp> squeeze_with_sizes_default(const std::vector<FieldElementSize> &sizes, const Field &f2) {
+        std::vector<Fp> out;
+        if (sizes.empty()) return out;   // src/lib.rs:65-67: no squeeze at all
+        size_t total = 0;
+        for (const auto &sz : sizes) total += sz.num_bits(f2);
+        const std::vector<bool> bits = squeeze_bits(total);
+        size_t at = 0;
+        for (const auto &sz : sizes) {
+            const size_t nb = sz.num_bits(f2);
+            std::array<uint64_t, 4> v{0, 0, 0, 0};
+            for (size_t k = 0; k < nb; ++k)
+                if (bits[at + k]) v[k / 64] |= 1ull << (k % 64);
+            at += nb;
+            out.push_back(fp_from_bigint(f2, v));
+        }
+        return out;
+    }
     PoseidonSponge(PoseidonConfig p, std::vector<Fp> st, DuplexSpongeMode m, int dev)
         : parameters(std::move(p)), state(std::move(st)), mode(m), device_(dev) {}
     int device_;

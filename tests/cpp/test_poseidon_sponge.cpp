@@ -126,6 +126,45 @@ static void test_squeeze_cast_native_and_state_roundtrip() {
     }
 }
 
+static void test_squeeze_with_sizes() {
+    // src/lib.rs:45-100, 166-182 and mod.rs:288-317
+    const Field Fr = Field::bls12_381_fr(), Fq = Field::bn254_fr();
+    auto sponge_param = get_default_poseidon_parameters(Fr, 2, false).value();
+    auto base = PoseidonSponge::make(sponge_param);
+    base.absorb({fp_from_u64(Fr, 7), fp_from_u64(Fr, 8)});
+    // all-Full native sizes == plain native squeeze; the F2 == F case casts
+    auto a = base, b = base, c = base;
+    auto plain = a.squeeze_native_field_elements(3);
+    EXPECT(b.squeeze_native_field_elements_with_sizes(std::vector<FieldElementSize>(3)) == plain);
+    EXPECT(c.squeeze_field_elements(3, Fr) == plain);
+    // a Truncated size takes the bit path: 254 bits per element out of one squeeze_bits stream
+    auto d = base, e = base;
+    auto trunc = d.squeeze_native_field_elements_with_sizes({FieldElementSize::Truncated(128), FieldElementSize::Full()});
+    auto bits = e.squeeze_bits(2 * 254);
+    for (int k = 0; k < 2; ++k) {
+        std::array<uint64_t, 4> v{0, 0, 0, 0};
+        for (size_t i = 0; i < 254; ++i) if (bits[254 * k + i]) v[i / 64] |= 1ull << (i % 64);
+        EXPECT(trunc[k] == fp_from_bigint(Fr, v));
+    }
+    EXPECT(d.mode == e.mode && d.state == e.state);
+    // non-native: BN254 Fr elements take 253 bits each
+    auto f = base, g = base;
+    auto nn = f.squeeze_field_elements(3, Fq);
+    auto nbits = g.squeeze_bits(3 * 253);
+    for (int k = 0; k < 3; ++k) {
+        std::array<uint64_t, 4> v{0, 0, 0, 0};
+        for (size_t i = 0; i < 253; ++i) if (nbits[253 * k + i]) v[i / 64] |= 1ull << (i % 64);
+        EXPECT(fp_into_bigint(Fq, nn[k]) == v);
+    }
+    // empty request: no squeeze, the mode stays Absorbing
+    auto h = base;
+    EXPECT(h.squeeze_field_elements_with_sizes({}, Fq).empty() && h.mode == base.mode);
+    // oversize Truncated panics in the reference (src/lib.rs:48)
+    bool threw = false;
+    try { (void)h.squeeze_field_elements_with_sizes({FieldElementSize::Truncated(255)}, Fq); } catch (const Error &) { threw = true; }
+    EXPECT(threw);
+}
+
 int main(int argc, char **argv) {
     const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
     try {
@@ -135,6 +174,7 @@ int main(int argc, char **argv) {
             test_macros_and_fork_on_gpu();
             test_poseidon_sponge_consistency();
             test_squeeze_cast_native_and_state_roundtrip();
+            test_squeeze_with_sizes();
         } else {
             // without a device the data path must fail loudly, never fall back
             bool threw = false;
