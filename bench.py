@@ -129,11 +129,19 @@ def main():
     import sponge_amd as S
     from sponge_amd import synth
 
+    # PMX_BENCH_BACKEND=gloo is a single-GPU rehearsal of the N > 1 code path (tools/gpu_n2_rehearsal.sh): the ranks
+    # share the visible GPUs round-robin and the gathers are staged through the host.  Its numbers mean nothing.
+    backend = os.environ.get("PMX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     field_name, rate, alpha, rf, rp, log2n, seed, desc = WORKLOADS[args.workload]
     if args.states_per_gpu_log2 is not None:
@@ -218,6 +226,7 @@ def main():
                 D.all_gather_equal(bufs[0], out=gathered[0])
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -251,7 +260,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
 
-    times = torch.tensor([elapsed, dev_ms / 1e3], dtype=torch.float64, device=dev)
+    times = torch.tensor([elapsed, dev_ms / 1e3], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, dev_s = float(times[0]), float(times[1])
@@ -278,7 +287,8 @@ def main():
             "config": {"workload": desc, "arithmetic": "255-bit modular integers as 9 x 29-bit limbs in u32, Montgomery form",
                        "units_per_gpu": n, "permutations_per_step": units_per_step,
                        "gather": (args.gather if (world > 1 and not merkle) else ("roots" if merkle and world > 1 else "n/a")),
-                       "sharding": f"contiguous x{world}"},
+                       "sharding": f"contiguous x{world}",
+                       **({"rehearsal_backend": backend} if backend != "nccl" else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                          "kernel": "pmx::compress_kernel / compress_coop_kernel (per tree level)" if merkle else

@@ -23,8 +23,20 @@ def all_gather_equal(local: torch.Tensor, out: torch.Tensor | None = None, async
     world = dist.get_world_size()
     if out is None:
         out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), async_op=async_op)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal of the multi-GPU path on a box without RCCL peers: stage through the host (synchronous)
+        parts = [torch.empty_like(local, device="cpu") for _ in range(world)]
+        dist.all_gather(parts, local.cpu())
+        out.view(-1).copy_(torch.cat([p.reshape(-1) for p in parts]))
+        work = _Done()
+    else:
+        work = dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), async_op=async_op)
     return (out, work) if async_op else out
+
+
+class _Done:
+    def wait(self):
+        return True
 
 
 def merkle_root_sharded(leaves_local: torch.Tensor, subtree_root: Callable[[torch.Tensor], torch.Tensor],
