@@ -40,6 +40,14 @@
 #define PMX_FN inline
 #endif
 
+// Host-only instrumentation for tests/hostcheck (never defined in the product build): PMX_TRACK(tag, x, f) reports
+// an intermediate element so the test can record its largest limb and its magnitude value / p.
+#if defined(PMX_HOSTCHECK) && !defined(__HIPCC__)
+#define PMX_TRACK(tag, x, f) ::pmx::hostcheck_track(tag, x, f)
+#else
+#define PMX_TRACK(tag, x, f) ((void)0)
+#endif
+
 namespace pmx {
 
 constexpr int kW = 29;                       // bits per limb
@@ -65,7 +73,12 @@ struct FieldRt {
     Fe to_abi;          // 2^256 mod p, plain integer in 29-bit limbs: internal -> ABI
     uint32_t two_p[kN]; // 2p, 29-bit limbs (fe_add_weak)
     uint32_t two_p_thr; // two_p[8] + 2: top-limb threshold above which 2p is subtracted
+    uint32_t unit;      // 1, as a run-time value: x * unit + acc is a single v_mad_u64_u32 (mont_mul_add)
 };
+
+#if defined(PMX_HOSTCHECK) && !defined(__HIPCC__)
+void hostcheck_track(int tag, const Fe &x, const FieldRt &f);   // defined in tests/hostcheck/pmx_hostcheck.cpp
+#endif
 
 PMX_FN Fe fe_zero() {
     Fe z;
@@ -176,6 +189,38 @@ PMX_FN Fe mont_dot(const Fe *a, const Fe *b, const FieldRt &f) {
 }
 
 PMX_FN Fe mont_mul(const Fe &a, const Fe &b, const FieldRt &f) { return mont_dot<1>(&a, &b, f); }
+
+// a * b * 2^-261 + s  in one pass: the addend enters the upper columns of the product (as s * 2^261 before the
+// reduction), so the sum comes out with normalised limbs and no separate addition / magnitude-cap pass.
+// a lazy, b norm, s norm with value < 2^261 - 2p.  Result norm, B < Ba * Bb * p / 2^261 + Bs + 1: the accumulator
+// this is used for (identity lanes of the sparse partial rounds) grows by about one p per round; the number of
+// rounds is bounded by the host (pmx_prepare.hpp: opt_schedule_lane_headroom).
+PMX_FN Fe mont_mul_add(const Fe &a, const Fe &b, const Fe &s, const FieldRt &f) {
+    uint32_t m[kN];
+    Fe out;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * kN - 1; ++k) {
+        const int lo_i = k < kN ? 0 : k - (kN - 1);
+        const int hi_i = k < kN ? k : kN - 1;
+#pragma unroll
+        for (int i = lo_i; i <= hi_i; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int j = lo_i; j <= hi_i; ++j) {
+            if (j < k || k >= kN) acc += (uint64_t)m[j] * f.p[k - j];
+        }
+        if (k < kN) {
+            m[k] = ((uint32_t)acc * f.pinv) & kMask;
+            acc += (uint64_t)m[k] * f.p[0];
+        } else {
+            acc += (uint64_t)s.l[k - kN] * f.unit;   // one mad; a plain 64-bit add would first widen s.l[] into a register pair
+            out.l[k - kN] = (uint32_t)acc & kMask;
+        }
+        acc >>= kW;
+    }
+    out.l[kN - 1] = (uint32_t)acc + s.l[kN - 1];
+    return out;
+}
 
 // a^2 * 2^-261: cross products once against the doubled operand (45 limb products instead of 81)
 PMX_FN Fe mont_sqr(const Fe &a, const FieldRt &f) {

@@ -89,6 +89,13 @@ PMX_FN void full_round(Fe (&s)[T], const uint32_t *rk, const uint32_t *mat, cons
     });
 }
 
+// Identity lanes of the sparse partial rounds:  s_i <- s_i + w_i * z0  is one mont_mul_add, which leaves the
+// magnitude of s_i uncapped: it grows by less than (1 + 1.3 p / 2^261) p <= 1.0204 p per round from B < 2.2 at the
+// start of the partial section.  Nothing downstream depends on B being small - the lanes are only ever multiplied
+// by constants inside reductions that return  T / 2^261 + p  - except that s_i must stay below 2^261 (9 normalised
+// limbs).  pmx_prepare.hpp (opt_schedule_lane_headroom) evaluates that condition, and configs with more partial
+// rounds than it allows (61 to 66 for a 255-bit modulus, depending on 2^261 / p) run on the dense schedule instead.
+
 template <int T, int ALPHA>
 PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
@@ -98,7 +105,8 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
             full_round<T, ALPHA>(s, rk, tb.mds, c, one, f);
             continue;
         }
-        // partial round: lanes 1..T-1 stay norm with B < 2.1 (fe_add_weak); lane 0 is re-derived every round
+        // partial round: lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom); lane 0 is re-derived
+        // every round
         Fe z[T];
         z[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         static_for<1, T>([&](auto i) { z[i] = s[i]; });
@@ -107,9 +115,9 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
             Fe row[T];
             static_for<0, T>([&](auto j) { row[j] = fe_const(sp + j * kFeStride); });
             s[0] = mont_dot<T>(z, row, f);
-            static_for<1, T>([&](auto i) {
-                s[i] = fe_add_weak(s[i], mont_mul(z[0], fe_const(sp + (T + i - 1) * kFeStride), f), f);
-            });
+            PMX_TRACK(0, s[0], f);
+            static_for<1, T>([&](auto i) { s[i] = mont_mul_add(z[0], fe_const(sp + (T + i - 1) * kFeStride), s[i], f); });
+            static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else {   // last partial round: dense matrix B
             static_for<0, T>([&](auto i) {
                 Fe row[T];
@@ -166,17 +174,20 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             matrix_rows_rolled<T>(s, sc, tb.mds, f);
             continue;
         }
-        // partial round: lanes 1..T-1 stay norm with B < 2.1 (fe_add_weak); lane 0 is re-derived every round
+        // partial round: lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom); lane 0 is re-derived
+        // every round
         s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         if (r < last_partial) {
             const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
             const Fe z0 = s[0];
             s[0] = matrix_row<T>(s, sp, f);
+            PMX_TRACK(0, s[0], f);
             static_for<1, T>([&](auto i) {
                 PMX_SCHED_FENCE();
-                s[i] = fe_add_weak(s[i], mont_mul(z0, fe_const(sp + (T + i - 1) * kFeStride), f), f);
+                s[i] = mont_mul_add(z0, fe_const(sp + (T + i - 1) * kFeStride), s[i], f);
             });
             PMX_SCHED_FENCE();
+            static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else {
             matrix_rows_rolled<T>(s, sc, tb.bdense, f);         // last partial round: dense matrix B
         }

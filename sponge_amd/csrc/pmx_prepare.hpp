@@ -101,6 +101,14 @@ inline bool mat_inverse(const HostField &f, HostMat a, HostMat &inv) {
     return true;
 }
 
+// The optimised schedule updates its identity lanes without a magnitude cap (pmx_permute.hpp): worst case
+// B < 2.2 + 1.0204 (RP - 1) after the last sparse round, plus the dense round's own + p and a margin, must stay
+// below 2^261 / p.
+inline bool opt_schedule_lane_headroom(long double two_261_over_p, uint32_t partial_rounds) {
+    const long double worst = 2.2L + 1.0204L * (long double)(partial_rounds > 0 ? partial_rounds - 1 : 0) + 1.5L;
+    return worst < two_261_over_p;
+}
+
 // Derives the tables of the optimised schedule from (ark, mds).  Notation of pmx_permute.hpp / DESIGN.md:
 // basis change N_k = diag(1, Nh_k) on lanes 1..t-1, Nh_0 = I;  B_k = M N_k;  for k < RP-1: Nh_{k+1} = lower-right
 // block of B_k, sparse_k = N_{k+1}^-1 B_k = [[b00, bv],[Bh^-1 bw, I]].  Round constants of lanes 1.. are deferred
@@ -199,7 +207,12 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         HostMat M(t, std::vector<U256>(t));
         for (size_t i = 0; i < t; ++i)
             for (size_t j = 0; j < t; ++j) std::memcpy(M[i][j].l, cfg->mds + 4 * (i * t + j), 32);
-        out.has_opt = derive_opt_tables(hf, t, cfg->full_rounds / 2, cfg->partial_rounds, (uint32_t)rounds, ark, M,
+        long double pv = 0;
+        for (int i = 3; i >= 0; --i) pv = pv * 18446744073709551616.0L + (long double)hf.p.l[i];
+        long double two_261 = 1;
+        for (int i = 0; i < 261; ++i) two_261 *= 2;
+        out.has_opt = opt_schedule_lane_headroom(two_261 / pv, cfg->partial_rounds) &&
+                      derive_opt_tables(hf, t, cfg->full_rounds / 2, cfg->partial_rounds, (uint32_t)rounds, ark, M,
                                         ark_opt, sparse, bdense);
         out.opt_offset = out.consts.size();
         out.opt_sparse_offset = out.opt_bdense_offset = out.opt_offset;
@@ -257,6 +270,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         u256_add(two_p, hf.p, hf.p);   // p < 2^255: no carry
         to_limbs29(two_p, f.two_p);
         f.two_p_thr = f.two_p[kN - 1] + 2;
+        f.unit = 1;
     }
     to_limbs29(hf.p, f.p);
     f.pinv = (uint32_t)hf.inv & kMask;

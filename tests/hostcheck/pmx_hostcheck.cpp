@@ -8,9 +8,31 @@
 #include <cstring>
 #include <string>
 
+#define PMX_HOSTCHECK 1
 #include "pmx_prepare.hpp"
 
 using namespace pmx;
+
+// ---- bound tracker (PMX_TRACK in pmx_field.hpp / pmx_permute.hpp): largest limb and largest value / p seen per tag
+static uint32_t g_max_limb[4];
+static double g_max_b[4];
+void pmx::hostcheck_track(int tag, const Fe &x, const FieldRt &f) {
+    long double v = 0, pv = 0;
+    for (int i = kN - 1; i >= 0; --i) {
+        v = v * 536870912.0L + x.l[i];
+        pv = pv * 536870912.0L + f.p[i];
+        if (x.l[i] > g_max_limb[tag]) g_max_limb[tag] = x.l[i];
+    }
+    const double b = (double)(v / pv);
+    if (b > g_max_b[tag]) g_max_b[tag] = b;
+}
+extern "C" void hc_track_reset() {
+    for (int t = 0; t < 4; ++t) { g_max_limb[t] = 0; g_max_b[t] = 0; }
+}
+extern "C" void hc_track_get(int tag, uint32_t *max_limb, double *max_b) {
+    *max_limb = g_max_limb[tag];
+    *max_b = g_max_b[tag];
+}
 
 static Abi load_abi(const uint64_t *p) {
     Abi a;

@@ -211,11 +211,13 @@ def test_merkle_trees_vs_c_oracle(name):
 
 @pytest.mark.parametrize("rate,alpha,rf,rp", [(3, 257, 8, 13), (8, 257, 8, 13), (1, 5, 8, 56), (11, 5, 8, 57), (4, 17, 8, 30),
                                                (2, 3, 8, 10), (4, 2, 4, 5), (2, 1, 2, 3), (1, 0, 2, 2), (2, 5, 8, 0), (2, 7, 0, 9),
-                                               (5, 0xFFFFFFFFFFFFFFFF, 2, 2), (15, 5, 4, 6)])
+                                               (5, 0xFFFFFFFFFFFFFFFF, 2, 2), (15, 5, 4, 6),
+                                               (2, 5, 8, 66), (2, 5, 8, 90), (4, 5, 8, 67), (8, 5, 8, 64)])
 def test_run_time_width_engine_vs_c_oracle(rate, alpha, rf, rp):
     """Widths, exponents and round splits off the beaten path: weights-optimised table (alpha = 257), t = 2 and t = 12
     (run-time-width engine), alpha = 17 at t = 5, degenerate exponents 0..3 and 2^64-1, no partial rounds, no full rounds
-    (dense schedule) - all against the C port."""
+    (dense schedule), and partial sections at / beyond what the optimised schedule's uncapped identity lanes allow
+    for BLS12-381 Fr (66 rounds: still optimised; 67 and 90: dense schedule) - all against the C port."""
     from oracle import cref
     from oracle import poseidon_oracle as O
     f = S.BLS12_381_FR

@@ -134,6 +134,65 @@ def test_permutation_templates_match_c_oracle_on_random_batch(hc):
     assert np.array_equal(run_permute(hc, "bn254_t9_a5_8_57", states, hybrid=True), want)
 
 
+def test_identity_lane_magnitudes_stay_inside_their_bounds(hc):
+    """The identity lanes of the sparse partial rounds are updated without a magnitude cap (mont_mul_add): they grow
+    by at most 1.0204 p per round and must stay below 2^261 (normalised limbs).  The host build reports every lane and
+    every row-0 output of the partial section: limbs < 2^29, lanes inside the worst-case line pmx_prepare.hpp budgets
+    for, row 0 small."""
+    from sponge_amd import synth
+    import sponge_amd as S
+    hc.hc_track_reset.argtypes = []
+    hc.hc_track_get.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    worst = {}
+    for name, f, t, hybrid in [("bls_t3_a5_8_31", S.BLS12_381_FR, 3, False), ("bls_t4_a5_8_56", S.BLS12_381_FR, 4, True),
+                               ("bls_t9_a5_8_57", S.BLS12_381_FR, 9, True), ("bn254_t9_a5_8_57", S.BN254_FR, 9, True),
+                               ("bn254_t3_a5_8_57", S.BN254_FR, 3, False)]:
+        cfg = oracle_config(name)
+        states = synth.random_elements(f, 96 * t, seed=5).reshape(96, t, 4)
+        edge = cref.elems_to_limbs([cfg.p - 1] * t + [0] * t + [1] * t, cfg.p).reshape(3, t, 4)
+        states = np.concatenate([states, edge])
+        hc.hc_track_reset()
+        want = cref.CRef(cfg).permute_batch(states, threads=0)
+        assert np.array_equal(run_permute(hc, name, states, opt=not hybrid, hybrid=hybrid), want)
+        assert 2.2 + 1.0204 * (cfg.partial_rounds - 1) + 1.5 < (1 << 261) / cfg.p     # what prepare() checks
+        for tag, limit in [(0, 10.0), (1, 2.2 + 1.0204 * (cfg.partial_rounds - 1))]:
+            limb = np.zeros(1, dtype=np.uint32)
+            b = np.zeros(1, dtype=np.float64)
+            hc.hc_track_get(tag, limb.ctypes.data, b.ctypes.data)
+            assert 0 < int(limb[0]) < (1 << 29), (name, tag, int(limb[0]))
+            assert 0 < float(b[0]) < limit, (name, tag, float(b[0]))
+            worst[(name, tag)] = float(b[0])
+    # the lanes really do run uncapped for tens of rounds (the check above is not vacuous)
+    assert worst[("bls_t9_a5_8_57", 1)] > 8.0
+
+
+def test_long_partial_sections_leave_the_optimised_schedule(hc):
+    """prepare() keeps the optimised schedule only while the uncapped identity lanes provably stay below 2^261:
+    up to 66 partial rounds for BLS12-381 Fr (2^261 / p = 70.66), far more for the 254-bit BN254 Fr."""
+    rng = random.Random(3)
+    for p, bits, rp, expect_opt in [(O.BLS12_381_FR, 255, 66, True), (O.BLS12_381_FR, 255, 67, False),
+                                    (O.BN254_FR, 254, 120, True)]:
+        cfg = O.make_config(p, bits, 2, 5, 8, rp)
+        states = [[rng.randrange(p) for _ in range(3)] for _ in range(4)] + [[p - 1] * 3]
+        want = [x for st in states for x in O.permute(cfg, st)]
+        limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), 3, 4)
+        ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+        mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+        c = PmxConfig()
+        c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = 8, rp, 5, 2, 1
+        for i, l in enumerate(O.to_limbs(p)):
+            c.modulus[i] = l
+        c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+        out = limbs.copy()
+        rc = hc.hc_permute_opt(ctypes.byref(c), out.ctypes.data, len(states))
+        assert (rc == 0) == expect_opt, (bits, rp, rc)
+        if expect_opt:
+            assert cref.limbs_to_elems(out, p) == want
+        out = limbs.copy()
+        assert hc.hc_permute(ctypes.byref(c), out.ctypes.data, len(states)) == 0     # the dense schedule always works
+        assert cref.limbs_to_elems(out, p) == want
+
+
 PALLAS_FP = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001      # 255 bits, not a reference field
 SMALL_P = (1 << 230) + 0x1D                                                         # pseudo-modulus near the lower limit
 
