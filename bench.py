@@ -56,7 +56,8 @@ def mads_per_permutation(t, alpha, rf, rp, optimised):
     dot = 81 * t + 81
     full = t * chain + t * dot
     if optimised:
-        partial = (rp - 1) * (chain + dot + (t - 1) * mul) + (chain + t * dot)
+        # identity lanes: product + reduction + 9 multiply-by-one injections of the addend (mont_mul_add)
+        partial = (rp - 1) * (chain + dot + (t - 1) * (mul + 9)) + (chain + t * dot)
     else:
         partial = rp * (chain + t * dot)
     return rf * full + partial
