@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -59,13 +60,32 @@ static int ctx_bind(pmx_ctx *ctx) {
 static int ctx_scratch(pmx_ctx *ctx, int slot, size_t bytes, void **out) {
     if (bytes == 0) bytes = 16;
     if (ctx->scratch_bytes[slot] < bytes) {
-        if (ctx->scratch[slot]) PMX_HIP(hipFree(ctx->scratch[slot]));
+        void *old = ctx->scratch[slot];
         ctx->scratch[slot] = nullptr;
         ctx->scratch_bytes[slot] = 0;
+        if (old) PMX_HIP(hipFree(old));
         PMX_HIP(hipMalloc(&ctx->scratch[slot], bytes));
         ctx->scratch_bytes[slot] = bytes;
     }
     *out = ctx->scratch[slot];
+    return PMX_OK;
+}
+
+// Host-buffer entry points queue asynchronous copies that read and write the CALLER's memory: whatever way they
+// leave (including an error half way through), nothing may still be in flight on the context's streams.
+struct StreamDrain {
+    pmx_ctx *ctx;
+    ~StreamDrain() {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream2);
+    }
+};
+
+// n * elems_per_row * 32 bytes, or an error if that does not fit size_t / the launch grid
+static int batch_bytes(size_t n, size_t elems_per_row, size_t *bytes) {
+    if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
+    if (elems_per_row && n > (SIZE_MAX / 32) / elems_per_row) return set_error(PMX_ERR_ARG, "batch byte size overflows size_t");
+    *bytes = n * elems_per_row * 32;
     return PMX_OK;
 }
 
@@ -192,9 +212,12 @@ extern "C" int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n) {
     if (n == 0) return PMX_OK;
     int rc = ctx_bind(ctx);
     if (rc) return rc;
-    const size_t row = (size_t)ctx->t * 32, bytes = n * row;
+    const size_t row = (size_t)ctx->t * 32;
+    size_t bytes = 0;
+    if ((rc = batch_bytes(n, ctx->t, &bytes))) return rc;
     void *d = nullptr;
     if ((rc = ctx_scratch(ctx, 0, bytes, &d))) return rc;
+    StreamDrain drain{ctx};
     const size_t step = is_pinned(states) ? pipeline_rows(n) : n;   // pinned: overlap H2D / kernel / D2H
     int lane = 0;
     for (size_t first = 0; first < n; first += step, lane ^= 1) {
@@ -216,6 +239,7 @@ extern "C" int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_
     if (!ctx || (!d_in && n && in_len) || (!d_out && n && out_len)) return set_error(PMX_ERR_ARG, "pmx_hash_batch_dev: null pointer");
     if (n == 0) return PMX_OK;
     if (!aligned16(d_in) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
     int rc = ctx_bind(ctx);
     if (rc) return rc;
     PMX_HIP(launch_hash(ctx->dev, ctx->t, d_in, in_len, d_out, out_len, n, (hipStream_t)stream));
@@ -227,10 +251,12 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
     if (n == 0) return PMX_OK;
     int rc = ctx_bind(ctx);
     if (rc) return rc;
-    const size_t in_bytes = n * in_len * 32, out_bytes = n * out_len * 32;
+    size_t in_bytes = 0, out_bytes = 0;
+    if ((rc = batch_bytes(n, in_len, &in_bytes)) || (rc = batch_bytes(n, out_len, &out_bytes))) return rc;
     void *d_in = nullptr, *d_out = nullptr;
     if ((rc = ctx_scratch(ctx, 0, in_bytes, &d_in))) return rc;
     if ((rc = ctx_scratch(ctx, 1, out_bytes, &d_out))) return rc;
+    StreamDrain drain{ctx};
     const size_t in_row = in_len * 32, out_row = out_len * 32;
     const size_t step = ((!in_bytes || is_pinned(in)) && (!out_bytes || is_pinned(out))) ? pipeline_rows(n) : n;
     int lane = 0;
@@ -255,6 +281,7 @@ extern "C" int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uin
         return set_error(PMX_ERR_ARG, "pmx_sponge_absorb_batch_dev: null pointer");
     if (n == 0 || in_len == 0) return PMX_OK;  // absorbing an empty input changes nothing (mod.rs:234-236)
     if (!aligned16(d_states) || !aligned16(d_in)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
     int rc = ctx_bind(ctx);
     if (rc) return rc;
     PMX_HIP(launch_absorb(ctx->dev, ctx->t, d_states, d_tag, d_index, d_in, in_len, n, (hipStream_t)stream));
@@ -267,6 +294,7 @@ extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, ui
         return set_error(PMX_ERR_ARG, "pmx_sponge_squeeze_batch_dev: null pointer");
     if (n == 0) return PMX_OK;
     if (!aligned16(d_states) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
     int rc = ctx_bind(ctx);
     if (rc) return rc;
     PMX_HIP(launch_squeeze(ctx->dev, ctx->t, d_states, d_tag, d_index, d_out, out_len, n, (hipStream_t)stream));
@@ -290,12 +318,14 @@ static int sponge_host(pmx_ctx *ctx, uint64_t *states, uint32_t *tag, uint32_t *
     int rc = check_modes(ctx, tag, index, n);
     if (rc) return rc;
     if ((rc = ctx_bind(ctx))) return rc;
-    const size_t st_bytes = n * ctx->t * 32, io_bytes = n * len * 32;
+    size_t st_bytes = 0, io_bytes = 0;
+    if ((rc = batch_bytes(n, ctx->t, &st_bytes)) || (rc = batch_bytes(n, len, &io_bytes))) return rc;
     void *d_st = nullptr, *d_io = nullptr, *d_tag = nullptr, *d_idx = nullptr;
     if ((rc = ctx_scratch(ctx, 0, st_bytes, &d_st))) return rc;
     if ((rc = ctx_scratch(ctx, 1, io_bytes, &d_io))) return rc;
     if ((rc = ctx_scratch(ctx, 2, n * 4, &d_tag))) return rc;
     if ((rc = ctx_scratch(ctx, 3, n * 4, &d_idx))) return rc;
+    StreamDrain drain{ctx};
     PMX_HIP(hipMemcpyAsync(d_st, states, st_bytes, hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipMemcpyAsync(d_tag, tag, n * 4, hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipMemcpyAsync(d_idx, index, n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -349,9 +379,11 @@ extern "C" int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_le
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two");
     int rc = ctx_bind(ctx);
     if (rc) return rc;
+    if (n_leaves > SIZE_MAX / 64) return set_error(PMX_ERR_ARG, "tree byte size overflows size_t");
     const size_t n_nodes = 2 * n_leaves - 1;
     void *d = nullptr;
     if ((rc = ctx_scratch(ctx, 0, n_nodes * 32, &d))) return rc;
+    StreamDrain drain{ctx};
     PMX_HIP(hipMemcpyAsync(d, leaves, n_leaves * 32, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = pmx_merkle_2to1_dev(ctx, (uint64_t *)d, n_leaves, ctx->stream))) return rc;
     if (nodes) PMX_HIP(hipMemcpyAsync(nodes, d, n_nodes * 32, hipMemcpyDeviceToHost, ctx->stream));

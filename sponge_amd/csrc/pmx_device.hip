@@ -577,6 +577,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     e.load_states(states, n);
     uint32_t idx = 0;
     if (active) idx = (mode_tag[gid] == PMX_MODE_ABSORBING) ? mode_index[gid] : e.c.rate;
+    if (idx > e.c.rate) idx = e.c.rate;                        // device-resident mode words are not validated by the host
     idx = absorb_elements(e, in + (active ? gid : 0) * in_len * 4, in_len, idx, active);
     e.store_states(states, n);
     if (active) {
@@ -598,6 +599,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     bool need = true;                                          // Absorbing -> permute, start at 0 (mod.rs:324-328)
     if (active && mode_tag[gid] == PMX_MODE_SQUEEZING) {       // mod.rs:330-336
         idx = mode_index[gid];
+        if (idx > e.c.rate) idx = e.c.rate;                    // see absorb_kernel
         need = idx == e.c.rate;
         if (need) idx = 0;
     }

@@ -172,6 +172,16 @@ def test_bad_arguments_fail_loudly():
     b.mode_tag[0] = 9
     with pytest.raises(S.PmxError):
         b.absorb(np.zeros((2, 1, 4), dtype=np.uint64))
+    # sizes that cannot be real are refused before anything is allocated or launched
+    from sponge_amd import _lib
+    one = np.zeros((1, 4), dtype=np.uint64)
+    with pytest.raises(S.PmxError, match="overflows"):
+        _lib.check(_lib.lib().pmx_hash_batch(ctx._h, one.ctypes.data, 1 << 60, one.ctypes.data, 1, 1 << 20))
+    with pytest.raises(S.PmxError, match="too large"):
+        _lib.check(_lib.lib().pmx_permute_batch(ctx._h, one.ctypes.data, 1 << 40))
+    # the context is still usable afterwards
+    st = synth.random_elements(cfg.field, 3, seed=1).reshape(1, 3, 4)
+    assert np.array_equal(ctx.permute_batch(st), ctx.permute_batch(st.copy()))
 
 
 @pytest.mark.parametrize("rate", [3, 4, 5, 6, 7, 8])
