@@ -90,11 +90,12 @@ PMX_FN void full_round(Fe (&s)[T], const uint32_t *rk, const uint32_t *mat, cons
 }
 
 // Identity lanes of the sparse partial rounds:  s_i <- s_i + w_i * z0  is one mont_mul_add, which leaves the
-// magnitude of s_i uncapped: it grows by less than (1 + 1.3 p / 2^261) p <= 1.0204 p per round from B < 2.2 at the
-// start of the partial section.  Nothing downstream depends on B being small - the lanes are only ever multiplied
-// by constants inside reductions that return  T / 2^261 + p  - except that s_i must stay below 2^261 (9 normalised
-// limbs).  pmx_prepare.hpp (opt_schedule_lane_headroom) evaluates that condition, and configs with more partial
-// rounds than it allows (61 to 66 for a 255-bit modulus, depending on 2^261 / p) run on the dense schedule instead.
+// magnitude of s_i uncapped: it grows by at most (1 + B_z p / 2^261) p per round (1.02 p for the usual S-boxes) from
+// B < 2.2 at the start of the partial section.  Nothing downstream depends on B being small - the lanes are only
+// ever multiplied by constants inside reductions that return  T / 2^261 + p  - except that s_i must stay below
+// 2^261 (nine normalised limbs).  pmx_prepare.hpp (opt_schedule_lane_headroom) evaluates that condition per config,
+// and configs with more partial rounds than it allows (61 to 66 for a 255-bit modulus, depending on 2^261 / p)
+// run on the dense schedule instead.
 
 template <int T, int ALPHA>
 PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {

@@ -101,11 +101,19 @@ inline bool mat_inverse(const HostField &f, HostMat a, HostMat &inv) {
     return true;
 }
 
-// The optimised schedule updates its identity lanes without a magnitude cap (pmx_permute.hpp): worst case
-// B < 2.2 + 1.0204 (RP - 1) after the last sparse round, plus the dense round's own + p and a margin, must stay
-// below 2^261 / p.
-inline bool opt_schedule_lane_headroom(long double two_261_over_p, uint32_t partial_rounds) {
-    const long double worst = 2.2L + 1.0204L * (long double)(partial_rounds > 0 ? partial_rounds - 1 : 0) + 1.5L;
+// The optimised schedule updates its identity lanes without a magnitude cap (pmx_permute.hpp: mont_mul_add).
+// With Q = 2^261 / p (>= 64) and every lane below Q p (nine normalised limbs), row 0 of a partial round returns at
+// most ((t-1) Q + B_z) / Q + 1 <= 9.2 p for t <= 9, so the S-box input x = row0 + constant is below 10.2 p and the
+// S-box output z_0 below B_z p with
+//     alpha >= 4: the chain ends in a product with x of a value < 1.05 p  ->  B_z < 1.05 * 10.2 / 64 + 1 < 1.2
+//     alpha = 3: x^2 * x, x^2 < 2.7 p -> B_z < 1.5;   alpha = 2: B_z < 2.7;   alpha = 1: z_0 = x, B_z < 10.2;
+//     alpha = 0: z_0 = 1.
+// A lane then grows by at most (B_z / Q + 1) p per round from < 2.2 p at the start of the partial section; the
+// dense round after the last sparse one adds its own + p.  The schedule is used when all of that stays below Q.
+inline bool opt_schedule_lane_headroom(long double two_261_over_p, uint32_t partial_rounds, uint64_t alpha) {
+    const long double bz = alpha == 0 ? 1.0L : alpha == 1 ? 10.2L : alpha == 2 ? 2.7L : alpha == 3 ? 1.5L : 1.3L;
+    const long double growth = 1.0L + bz / two_261_over_p;
+    const long double worst = 2.2L + growth * (long double)(partial_rounds > 0 ? partial_rounds - 1 : 0) + 1.5L;
     return worst < two_261_over_p;
 }
 
@@ -211,7 +219,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         for (int i = 3; i >= 0; --i) pv = pv * 18446744073709551616.0L + (long double)hf.p.l[i];
         long double two_261 = 1;
         for (int i = 0; i < 261; ++i) two_261 *= 2;
-        out.has_opt = opt_schedule_lane_headroom(two_261 / pv, cfg->partial_rounds) &&
+        out.has_opt = opt_schedule_lane_headroom(two_261 / pv, cfg->partial_rounds, cfg->alpha) &&
                       derive_opt_tables(hf, t, cfg->full_rounds / 2, cfg->partial_rounds, (uint32_t)rounds, ark, M,
                                         ark_opt, sparse, bdense);
         out.opt_offset = out.consts.size();

@@ -154,7 +154,7 @@ def test_identity_lane_magnitudes_stay_inside_their_bounds(hc):
         hc.hc_track_reset()
         want = cref.CRef(cfg).permute_batch(states, threads=0)
         assert np.array_equal(run_permute(hc, name, states, opt=not hybrid, hybrid=hybrid), want)
-        assert 2.2 + 1.0204 * (cfg.partial_rounds - 1) + 1.5 < (1 << 261) / cfg.p     # what prepare() checks
+        assert 2.2 + (1 + 1.3 * cfg.p / (1 << 261)) * (cfg.partial_rounds - 1) + 1.5 < (1 << 261) / cfg.p     # what prepare() checks
         for tag, limit in [(0, 10.0), (1, 2.2 + 1.0204 * (cfg.partial_rounds - 1))]:
             limb = np.zeros(1, dtype=np.uint32)
             b = np.zeros(1, dtype=np.float64)
@@ -170,24 +170,34 @@ def test_long_partial_sections_leave_the_optimised_schedule(hc):
     """prepare() keeps the optimised schedule only while the uncapped identity lanes provably stay below 2^261:
     up to 66 partial rounds for BLS12-381 Fr (2^261 / p = 70.66), far more for the 254-bit BN254 Fr."""
     rng = random.Random(3)
-    for p, bits, rp, expect_opt in [(O.BLS12_381_FR, 255, 66, True), (O.BLS12_381_FR, 255, 67, False),
-                                    (O.BN254_FR, 254, 120, True)]:
-        cfg = O.make_config(p, bits, 2, 5, 8, rp)
+    hc.hc_track_reset.argtypes = []
+    hc.hc_track_get.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    # alpha = 1 and 2 are the S-boxes whose output is NOT small (z_0 up to ~10 p resp. 2.7 p): the lanes grow faster
+    # and prepare() allows fewer rounds
+    for p, bits, rp, alpha, expect_opt in [(O.BLS12_381_FR, 255, 66, 5, True), (O.BLS12_381_FR, 255, 67, 5, False),
+                                           (O.BN254_FR, 254, 120, 5, True), (O.BLS12_381_FR, 255, 58, 1, True),
+                                           (O.BLS12_381_FR, 255, 60, 1, False), (O.BLS12_381_FR, 255, 64, 2, True)]:
+        cfg = O.make_config(p, bits, 2, alpha, 8, rp)
         states = [[rng.randrange(p) for _ in range(3)] for _ in range(4)] + [[p - 1] * 3]
         want = [x for st in states for x in O.permute(cfg, st)]
         limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), 3, 4)
         ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
         mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
         c = PmxConfig()
-        c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = 8, rp, 5, 2, 1
+        c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = 8, rp, alpha, 2, 1
         for i, l in enumerate(O.to_limbs(p)):
             c.modulus[i] = l
         c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
         out = limbs.copy()
+        hc.hc_track_reset()
         rc = hc.hc_permute_opt(ctypes.byref(c), out.ctypes.data, len(states))
-        assert (rc == 0) == expect_opt, (bits, rp, rc)
+        assert (rc == 0) == expect_opt, (bits, rp, alpha, rc)
         if expect_opt:
             assert cref.limbs_to_elems(out, p) == want
+            limb = np.zeros(1, dtype=np.uint32)
+            b = np.zeros(1, dtype=np.float64)
+            hc.hc_track_get(1, limb.ctypes.data, b.ctypes.data)
+            assert int(limb[0]) < (1 << 29) and float(b[0]) < (1 << 261) / p - 1.5, (bits, rp, alpha, float(b[0]))
         out = limbs.copy()
         assert hc.hc_permute(ctypes.byref(c), out.ctypes.data, len(states)) == 0     # the dense schedule always works
         assert cref.limbs_to_elems(out, p) == want
