@@ -138,6 +138,9 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.opt_sparse_offset = (uint32_t)pp.opt_sparse_offset;
     d.opt_bdense_offset = (uint32_t)pp.opt_bdense_offset;
     d.coop_offset = (uint32_t)pp.coop_offset;
+    d.tab_mds_offset = (uint32_t)pp.tab_mds_offset;
+    d.tab_sparse_offset = (uint32_t)pp.tab_sparse_offset;
+    d.tab_bdense_offset = (uint32_t)pp.tab_bdense_offset;
     d.has_opt = pp.has_opt ? 1u : 0u;
     d.rounds = pp.c;
     d.field = pp.f;

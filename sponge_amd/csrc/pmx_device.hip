@@ -44,8 +44,9 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 // RegEngine: t known at compile time, state in registers (internal field form).
 // LDS: [constants: n_const_words u32, rounded up to 16 B][staging: kThreads * T * 2 uint4]
 // ------------------------------------------------------------------------------------------------
-template <int T, int ALPHA, bool OPT>
+template <int T, int ALPHA, bool OPT, bool TAB = false>
 struct RegEngine {
+    static_assert(OPT || !TAB, "shifted tables exist for the optimised schedule");
     static constexpr int kThreads = 256;
     static constexpr int kMinWaves = 1;
     static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
@@ -57,9 +58,10 @@ struct RegEngine {
     OptTables tb;         // constants (LDS or global)
     uint4 *stage;         // LDS staging for coalesced state I/O
 
-    // words of the constant table this engine uses: [mds | ark' | sparse | bdense] or [ark | mds]
-    __host__ __device__ __forceinline__ static uint32_t first_word(const DevConfig &d) { return OPT ? d.mds_offset : 0; }
-    __host__ __device__ __forceinline__ static uint32_t last_word(const DevConfig &d) { return OPT ? d.n_const_words : d.opt_offset; }
+    // words of the constant table staged in LDS: [mds | ark' | sparse | bdense] of the optimised schedule - only ark'
+    // when its matrices are shifted tables, which stream through the scalar cache - or [ark | mds] of the dense one
+    __host__ __device__ __forceinline__ static uint32_t first_word(const DevConfig &d) { return TAB ? d.opt_offset : OPT ? d.mds_offset : 0; }
+    __host__ __device__ __forceinline__ static uint32_t last_word(const DevConfig &d) { return TAB ? d.opt_sparse_offset : OPT ? d.coop_offset : d.opt_offset; }
 
     static size_t lds_bytes(const DevConfig &d, uint32_t /*t*/) {
         return (PMX_CONSTS_IN_LDS ? (size_t)((last_word(d) - first_word(d) + 3) / 4) * 16 : 0) + (size_t)kThreads * kChunks * 16;
@@ -79,6 +81,9 @@ struct RegEngine {
         stage = pmx_lds;
 #endif
         tb.mds = base + d.mds_offset;
+        tb.tab_mds = consts + d.tab_mds_offset;
+        tb.tab_sparse = consts + d.tab_sparse_offset;
+        tb.tab_bdense = consts + d.tab_bdense_offset;
         if constexpr (OPT) {
             tb.ark = base + d.opt_offset;
             tb.sparse = base + d.opt_sparse_offset;
@@ -156,7 +161,8 @@ struct RegEngine {
     }
 
     __device__ __forceinline__ void permute() {
-        if constexpr (OPT) permute_opt<T, ALPHA>(s, tb, c, one, f);
+        if constexpr (TAB) permute_opt_tab<T, ALPHA>(s, tb, c, one, f);
+        else if constexpr (OPT) permute_opt<T, ALPHA>(s, tb, c, one, f);
         else permute_dense<T, ALPHA>(s, tb.ark, tb.mds, c, one, f);
     }
 };
@@ -205,6 +211,9 @@ struct HybridEngine {
         tb.ark = consts + d.opt_offset;
         tb.sparse = consts + d.opt_sparse_offset;
         tb.bdense = consts + d.opt_bdense_offset;
+        tb.tab_mds = consts + d.tab_mds_offset;
+        tb.tab_sparse = consts + d.tab_sparse_offset;
+        tb.tab_bdense = consts + d.tab_bdense_offset;
         sc.base = reinterpret_cast<uint32_t *>(pmx_lds) + threadIdx.x;
     }
 
@@ -722,6 +731,10 @@ PMX_HYB_DECL(hybridg_)
     } while (0)
 
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
+    if (t == 3 && c.has_opt) {   // the plain permutation at t = 3 takes its matrices as shifted tables (permute_opt_tab)
+        if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, true>>::permute(c, t, states, n, st);
+        if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, true>>::permute(c, t, states, n, st);
+    }
     PMX_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,

@@ -263,6 +263,76 @@ PMX_FN Fe mont_sqr(const Fe &a, const FieldRt &f) {
     return out;
 }
 
+// ---- products by CONSTANTS: shifted tables -----------------------------------------------------------------------
+// For a constant C the host stores the nine residues  T_j = C * 2^(29 j + 58) mod p  (canonical, 9 limbs each) as
+// tab[k * 9 + j] = limb k of T_j  (kTabWords = 81 words).  Then for any element z (internal form, limbs z_j)
+//     U = sum_j z_j * T_j  =  z * C * 2^58   (mod p),        U < 9 * 2^29 * p,
+// is NINE columns of nine limb products, and two Montgomery steps (18 more multiplies) turn it into
+// z * C * 2^-261 * 2^261 - the same value mont_mul(z, C~) returns - with the result below (1 + 2^-20) p.  That is 99
+// multiplies for a product by a constant instead of 162, and 81 N + 18 for an N-term dot product instead of
+// 81 N + 81; the price is 9x the table size (pmx_prepare.hpp), streamed through the scalar cache.
+// Operands z must be norm (limbs < 2^29): a column then holds 9 products per term, at most 6 terms (+ 2 reduction
+// products + carry < 2^64) per accumulator; wider dots use two accumulators combined once per column.
+// ADD (N = 1 only): returns z * C + s, the addend entering two columns up (s * 2^58 before the two steps), as in
+// mont_mul_add; s norm, result norm with B < Bs + 1 + 2^-20.
+constexpr int kTabWords = kN * kN;
+constexpr int kTabSteps = 2;
+
+template <int N, bool ADD>
+PMX_FN Fe tab_dot(const Fe *z, const uint32_t *tab, const Fe &s, const FieldRt &f) {
+    static_assert(!ADD || N == 1, "the addend form exists for single products");
+    static_assert(N <= 12, "two accumulators");
+    constexpr int G = N <= 6 ? 1 : 2;
+    constexpr int kSplit = G == 1 ? N : (N + 1) / 2;   // terms [0, kSplit) -> acc[0], the rest -> acc[1]
+    uint32_t m[kTabSteps];
+    Fe out;
+    uint64_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0;
+#pragma unroll
+    for (int k = 0; k < kN + kTabSteps; ++k) {
+        if (k < kN) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+#pragma unroll
+                for (int j = 0; j < kN; ++j) acc[i < kSplit ? 0 : G - 1] += (uint64_t)z[i].l[j] * tab[i * kTabWords + k * kN + j];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kTabSteps; ++q) {
+            if (q < k && k - q < kN) acc[0] += (uint64_t)m[q] * f.p[k - q];
+        }
+        if constexpr (G == 1) {
+            if (k < kTabSteps) {
+                m[k] = mont_step(acc[0], f);
+            } else {
+                if constexpr (ADD) acc[0] += (uint64_t)s.l[k - kTabSteps] * f.unit;
+                if (k < kN + kTabSteps - 1) {
+                    out.l[k - kTabSteps] = (uint32_t)acc[0] & kMask;
+                    acc[0] >>= kW;
+                } else {
+                    out.l[k - kTabSteps] = (uint32_t)acc[0];
+                }
+            }
+        } else {
+            uint32_t low = ((uint32_t)acc[0] & kMask) + ((uint32_t)acc[1] & kMask);
+            uint64_t carry = (acc[0] >> kW) + (acc[1] >> kW);
+            acc[1] = 0;
+            if (k < kTabSteps) {
+                m[k] = (low * f.pinv) & kMask;
+                const uint64_t v = (uint64_t)m[k] * f.p[0] + low;   // low 29 bits are zero
+                acc[0] = carry + (v >> kW);
+            } else if (k < kN + kTabSteps - 1) {
+                out.l[k - kTabSteps] = low & kMask;
+                acc[0] = carry + (low >> kW);
+            } else {
+                out.l[k - kTabSteps] = (uint32_t)acc[0];   // top limb: no products this high, acc[1] is empty
+            }
+        }
+    }
+    return out;
+}
+
 // ---- run-time-width dot products: explicit column array ---------------------------------------------------------
 // 18 64-bit columns; terms are added with cols_mul_acc and the columns re-compressed at least every 3 terms.
 struct Cols {

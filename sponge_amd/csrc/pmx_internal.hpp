@@ -17,6 +17,7 @@ struct DevConfig {
     uint32_t n_const_words;   // words in consts
     uint32_t mds_offset;      // word offsets inside consts
     uint32_t opt_offset, opt_sparse_offset, opt_bdense_offset, coop_offset;
+    uint32_t tab_mds_offset, tab_sparse_offset, tab_bdense_offset;   // shifted tables (pmx_field.hpp: tab_dot)
     uint32_t has_opt;         // optimised schedule tables present (and, for t = 3, the cooperative table)
     Rounds rounds;
     FieldRt field;

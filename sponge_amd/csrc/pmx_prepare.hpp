@@ -47,7 +47,24 @@ struct Prepared {
     //   -- only when has_opt and t == 3 (pmx_permute.hpp: cooperative schedule) --
     //   coop_offset                coop     [rounds][3][4]
     size_t coop_offset;
+    //   -- only when has_opt: shifted tables (pmx_field.hpp: tab_dot), kTabWords words per constant --
+    //   tab_mds_offset             mds      [t][t]
+    //   tab_sparse_offset          sparse   [RP-1][2t-1]
+    //   tab_bdense_offset          bdense   [t][t]
+    size_t tab_mds_offset, tab_sparse_offset, tab_bdense_offset;
 };
+
+// shifted table of one constant (given as the ABI Montgomery residue C * 2^256): tab[k * 9 + j] = limb k of
+// C * 2^(29 j + 58) mod p
+inline void put_shifted_table(const HostField &hf, const U256 &c_mont, uint32_t *tab) {
+    U256 tj = times_pow2(hf, hf.from_mont(c_mont), 29 * 0 + 58);
+    for (int j = 0; j < kN; ++j) {
+        uint32_t limbs[kN];
+        to_limbs29(tj, limbs);
+        for (int k = 0; k < kN; ++k) tab[k * kN + j] = limbs[k];
+        tj = times_pow2(hf, tj, kW);
+    }
+}
 
 // ---- small dense linear algebra over the ABI Montgomery form (host only) ----------------------------------------
 typedef std::vector<std::vector<U256>> HostMat;
@@ -209,6 +226,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         to_limbs29(times_pow2(hf, v, 5), &out.consts[k * kFeStride]);   // x*2^256 -> x*2^261
     }
     // optimised schedule
+    std::vector<U256> tab_src_mds, tab_src_sparse, tab_src_bdense;
     {
         std::vector<U256> ark(n_ark), ark_opt, sparse, bdense;
         for (size_t k = 0; k < n_ark; ++k) std::memcpy(ark[k].l, cfg->ark + 4 * k, 32);
@@ -225,6 +243,10 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         out.opt_offset = out.consts.size();
         out.opt_sparse_offset = out.opt_bdense_offset = out.opt_offset;
         if (out.has_opt) {
+            for (size_t i = 0; i < t; ++i)
+                for (size_t j = 0; j < t; ++j) tab_src_mds.push_back(M[i][j]);
+            tab_src_sparse = sparse;
+            tab_src_bdense = bdense;
             out.opt_sparse_offset = out.opt_offset + n_ark * kFeStride;
             out.opt_bdense_offset = out.opt_sparse_offset + sparse.size() * kFeStride;
             out.consts.resize(out.opt_bdense_offset + bdense.size() * kFeStride, 0u);
@@ -271,6 +293,19 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
                 }
             }
         }
+    }
+    // shifted tables of every constant the optimised schedule multiplies by
+    out.tab_mds_offset = out.tab_sparse_offset = out.tab_bdense_offset = out.consts.size();
+    if (out.has_opt) {
+        out.tab_sparse_offset = out.tab_mds_offset + tab_src_mds.size() * kTabWords;
+        out.tab_bdense_offset = out.tab_sparse_offset + tab_src_sparse.size() * kTabWords;
+        out.consts.resize(out.tab_bdense_offset + tab_src_bdense.size() * kTabWords, 0u);
+        size_t w = out.tab_mds_offset;
+        for (const auto *vec : {&tab_src_mds, &tab_src_sparse, &tab_src_bdense})
+            for (const U256 &v : *vec) {
+                put_shifted_table(hf, v, &out.consts[w]);
+                w += kTabWords;
+            }
     }
     FieldRt &f = out.f;
     {

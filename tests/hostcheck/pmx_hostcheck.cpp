@@ -41,19 +41,28 @@ static Abi load_abi(const uint64_t *p) {
 }
 static void store_abi(uint64_t *p, const Abi &a) { std::memcpy(p, a.w, 32); }
 
-template <int T>
+template <int T, bool TAB = false>
 static void permute_opt_t(const Prepared &pp, uint64_t *states, size_t n) {
     OptTables tb;
     tb.ark = pp.consts.data() + pp.opt_offset;
     tb.mds = pp.consts.data() + pp.mds_offset;
     tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
     tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
+    tb.tab_mds = pp.consts.data() + pp.tab_mds_offset;
+    tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
+    tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
         for (int i = 0; i < T; ++i) s[i] = fe_from_abi(load_abi(states + (k * T + i) * 4), pp.f);
-        if (pp.c.alpha == 5) permute_opt<T, 5>(s, tb, pp.c, pp.one, pp.f);
-        else if (pp.c.alpha == 17) permute_opt<T, 17>(s, tb, pp.c, pp.one, pp.f);
-        else permute_opt<T, 0>(s, tb, pp.c, pp.one, pp.f);
+        if constexpr (TAB) {
+            if (pp.c.alpha == 5) permute_opt_tab<T, 5>(s, tb, pp.c, pp.one, pp.f);
+            else if (pp.c.alpha == 17) permute_opt_tab<T, 17>(s, tb, pp.c, pp.one, pp.f);
+            else permute_opt_tab<T, 0>(s, tb, pp.c, pp.one, pp.f);
+        } else {
+            if (pp.c.alpha == 5) permute_opt<T, 5>(s, tb, pp.c, pp.one, pp.f);
+            else if (pp.c.alpha == 17) permute_opt<T, 17>(s, tb, pp.c, pp.one, pp.f);
+            else permute_opt<T, 0>(s, tb, pp.c, pp.one, pp.f);
+        }
         for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi(s[i], pp.f));
     }
 }
@@ -100,6 +109,9 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
     tb.mds = pp.consts.data() + pp.mds_offset;
     tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
     tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
+    tb.tab_mds = pp.consts.data() + pp.tab_mds_offset;
+    tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
+    tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
         HostScratch<T> sc;
@@ -141,6 +153,24 @@ extern "C" int hc_permute_opt(const pmx_config *cfg, uint64_t *states, size_t n)
         case 4: permute_opt_t<4>(pp, states, n); break;
         case 5: permute_opt_t<5>(pp, states, n); break;
         case 9: permute_opt_t<9>(pp, states, n); break;
+        default: return PMX_ERR_UNSUPPORTED;
+    }
+    return PMX_OK;
+}
+
+// the same schedule on shifted tables (permute_opt_tab)
+extern "C" int hc_permute_opt_tab(const pmx_config *cfg, uint64_t *states, size_t n) {
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);
+    if (rc) return rc;
+    if (!pp.has_opt) return PMX_ERR_UNSUPPORTED;
+    switch (pp.t) {
+        case 2: permute_opt_t<2, true>(pp, states, n); break;
+        case 3: permute_opt_t<3, true>(pp, states, n); break;
+        case 4: permute_opt_t<4, true>(pp, states, n); break;
+        case 5: permute_opt_t<5, true>(pp, states, n); break;
+        case 9: permute_opt_t<9, true>(pp, states, n); break;
         default: return PMX_ERR_UNSUPPORTED;
     }
     return PMX_OK;

@@ -26,6 +26,7 @@ def hc():
     lib.hc_permute.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_rt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_opt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    lib.hc_permute_opt_tab.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_hybrid.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_coop.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_field_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -80,7 +81,7 @@ def test_column_accumulators_cannot_overflow(hc):
     assert int(hi[0]) == 0
 
 
-def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False):
+def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False, tab=False):
     cfg = oracle_config(name)
     p = cfg.p
     ark = mont_limbs([v for row in cfg.ark for v in row], p)
@@ -93,7 +94,8 @@ def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False)
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
     out = np.ascontiguousarray(states, dtype=np.uint64).copy()
     n = out.size // (cfg.t * 4)
-    fn = hc.hc_permute_coop if coop else hc.hc_permute_hybrid if hybrid else (hc.hc_permute_opt if opt else (hc.hc_permute_rt if rt else hc.hc_permute))
+    fn = hc.hc_permute_opt_tab if tab else hc.hc_permute_coop if coop else hc.hc_permute_hybrid if hybrid else (
+        hc.hc_permute_opt if opt else (hc.hc_permute_rt if rt else hc.hc_permute))
     assert fn(ctypes.byref(c), out.ctypes.data, n) == 0
     return out
 
@@ -111,6 +113,8 @@ def test_permutation_templates_match_golden(hc, name):
         assert cref.limbs_to_elems(out, cfg.p) == want, ("rt" if rt else "static")
     out = run_permute(hc, name, states, opt=True)     # optimised schedule (sparse partial rounds)
     assert cref.limbs_to_elems(out, cfg.p) == want, "opt"
+    out = run_permute(hc, name, states, tab=True)     # the same on shifted tables (tab_dot)
+    assert cref.limbs_to_elems(out, cfg.p) == want, "opt_tab"
     out = run_permute(hc, name, states, hybrid=True)  # register + scratch hybrid (HybridEngine)
     assert cref.limbs_to_elems(out, cfg.p) == want, "hybrid"
     if cfg.t == 3:
@@ -126,6 +130,7 @@ def test_permutation_templates_match_c_oracle_on_random_batch(hc):
         want = cref.CRef(oracle_config(name)).permute_batch(states, threads=0)
         assert np.array_equal(run_permute(hc, name, states), want)
         assert np.array_equal(run_permute(hc, name, states, opt=True), want)
+        assert np.array_equal(run_permute(hc, name, states, tab=True), want)
         assert np.array_equal(run_permute(hc, name, states, hybrid=True), want)
         assert np.array_equal(run_permute(hc, name, states, coop=True), want)
     from sponge_amd import synth as sy
@@ -154,6 +159,7 @@ def test_identity_lane_magnitudes_stay_inside_their_bounds(hc):
         hc.hc_track_reset()
         want = cref.CRef(cfg).permute_batch(states, threads=0)
         assert np.array_equal(run_permute(hc, name, states, opt=not hybrid, hybrid=hybrid), want)
+        assert np.array_equal(run_permute(hc, name, states, tab=True), want)       # the table form tracks the same tags
         assert 2.2 + (1 + 1.3 * cfg.p / (1 << 261)) * (cfg.partial_rounds - 1) + 1.5 < (1 << 261) / cfg.p     # what prepare() checks
         for tag, limit in [(0, 10.0), (1, 2.2 + 1.0204 * (cfg.partial_rounds - 1))]:
             limb = np.zeros(1, dtype=np.uint32)
@@ -192,8 +198,11 @@ def test_long_partial_sections_leave_the_optimised_schedule(hc):
         hc.hc_track_reset()
         rc = hc.hc_permute_opt(ctypes.byref(c), out.ctypes.data, len(states))
         assert (rc == 0) == expect_opt, (bits, rp, alpha, rc)
+        out_tab = limbs.copy()
+        assert (hc.hc_permute_opt_tab(ctypes.byref(c), out_tab.ctypes.data, len(states)) == 0) == expect_opt
         if expect_opt:
             assert cref.limbs_to_elems(out, p) == want
+            assert cref.limbs_to_elems(out_tab, p) == want
             limb = np.zeros(1, dtype=np.uint32)
             b = np.zeros(1, dtype=np.float64)
             hc.hc_track_get(1, limb.ctypes.data, b.ctypes.data)
@@ -228,7 +237,7 @@ def test_other_255_bit_prime(hc, p):
     for i, l in enumerate(O.to_limbs(p)):
         c.modulus[i] = l
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
-    for fn in (hc.hc_permute, hc.hc_permute_rt, hc.hc_permute_opt, hc.hc_permute_hybrid, hc.hc_permute_coop):
+    for fn in (hc.hc_permute, hc.hc_permute_rt, hc.hc_permute_opt, hc.hc_permute_opt_tab, hc.hc_permute_hybrid, hc.hc_permute_coop):
         out = limbs.copy()
         assert fn(ctypes.byref(c), out.ctypes.data, len(states)) == 0
         assert cref.limbs_to_elems(out, p) == want, fn.__name__
