@@ -141,9 +141,11 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.tab_mds_offset = (uint32_t)pp.tab_mds_offset;
     d.tab_sparse_offset = (uint32_t)pp.tab_sparse_offset;
     d.tab_bdense_offset = (uint32_t)pp.tab_bdense_offset;
+    d.io_offset = (uint32_t)pp.io_offset;
     d.has_opt = pp.has_opt ? 1u : 0u;
     d.rounds = pp.c;
     d.field = pp.f;
+    d.field.io = nullptr;   // engines point it at consts + io_offset on the device
     d.one = pp.one;
     *out = ctx;
     return PMX_OK;

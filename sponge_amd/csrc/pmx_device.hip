@@ -68,6 +68,7 @@ struct RegEngine {
     }
 
     __device__ __forceinline__ RegEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
+        f.io = consts + d.io_offset;
         const uint32_t w0 = first_word(d);
 #if PMX_CONSTS_IN_LDS
         const uint32_t const_chunks = (last_word(d) - w0 + 3) / 4;
@@ -207,6 +208,7 @@ struct HybridEngine {
     }
 
     __device__ __forceinline__ HybridEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
+        f.io = consts + d.io_offset;
         tb.mds = consts + d.mds_offset;
         tb.ark = consts + d.opt_offset;
         tb.sparse = consts + d.opt_sparse_offset;
@@ -303,6 +305,7 @@ struct LdsEngine {
     static size_t lds_bytes(const DevConfig & /*d*/, uint32_t t) { return (size_t)(kThreads / 64) * 2 * t * kN * 64 * 4; }
 
     __device__ __forceinline__ LdsEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
+        f.io = consts + d.io_offset;
         ark = consts;
         mds = consts + d.mds_offset;
         t = c.rate + c.capacity;
@@ -545,7 +548,8 @@ __global__ void __launch_bounds__(256, 2)
     compress_coop_kernel(const DevConfig d, const uint32_t *__restrict__ consts, const uint64_t *__restrict__ in,
                          uint64_t *__restrict__ out, size_t n) {
     const Rounds c(d.rounds);
-    const FieldRt f(d.field);
+    FieldRt f(d.field);
+    f.io = consts + d.io_offset;
     const Fe one(d.one);
     const uint32_t table_chunks = c.total_rounds * 3 * kCoopElems * kFeStride / 4;
     const uint4 *g4 = reinterpret_cast<const uint4 *>(consts + d.coop_offset);
@@ -707,8 +711,9 @@ hipError_t PMX_HYB_NAME(squeeze)(const DevConfig &c, uint32_t t, uint64_t *state
 PMX_HYB_DECL(hybrid5_)
 PMX_HYB_DECL(hybridg_)
 
-// Engine choice: width 3 runs from registers, on the optimised schedule whenever its tables exist (the dense
-// schedule remains for configs without a partial section); widths 4..9 (every rate of the reference's default
+// Engine choice: width 3 runs from registers, on the optimised schedule whenever its tables exist - with the matrices
+// as shifted tables (permute_opt_tab) for the two exponents that have a dedicated chain - (the dense schedule
+// remains for configs without a partial section); widths 4..9 (every rate of the reference's default
 // tables, src/test.rs:14-31) run on the register/LDS hybrid - alpha = 5 specialised, any other exponent on the
 // generic S-box; everything else uses the LDS-resident run-time-width engine.
 // alpha 5 and 17 have dedicated addition chains, other exponents share the generic S-box.
@@ -716,8 +721,8 @@ PMX_HYB_DECL(hybridg_)
     do {                                                                                    \
         const uint64_t alpha = c.rounds.alpha;                                              \
         if (t == 3 && c.has_opt) {                                                          \
-            if (alpha == 5) return Launch<RegEngine<3, 5, true>>::CALL;                     \
-            if (alpha == 17) return Launch<RegEngine<3, 17, true>>::CALL;                   \
+            if (alpha == 5) return Launch<RegEngine<3, 5, true, true>>::CALL;               \
+            if (alpha == 17) return Launch<RegEngine<3, 17, true, true>>::CALL;             \
             return Launch<RegEngine<3, 0, true>>::CALL;                                     \
         }                                                                                   \
         if (t == 3) return Launch<RegEngine<3, 0, false>>::CALL;                            \
@@ -731,10 +736,6 @@ PMX_HYB_DECL(hybridg_)
     } while (0)
 
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
-    if (t == 3 && c.has_opt) {   // the plain permutation at t = 3 takes its matrices as shifted tables (permute_opt_tab)
-        if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, true>>::permute(c, t, states, n, st);
-        if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, true>>::permute(c, t, states, n, st);
-    }
     PMX_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,

@@ -64,21 +64,28 @@ struct Abi {
     uint32_t w[8];
 };
 
-// Modulus view: wave-uniform run-time values (SGPRs on the device).
+// Modulus view: wave-uniform run-time values (SGPRs on the device).  Only what the arithmetic of every round needs
+// travels by value; the constants of the ABI conversions sit in the constant table behind `io` and are fetched
+// where a conversion happens, so they do not occupy SGPRs for the length of a permutation.
 struct FieldRt {
-    uint32_t p[kN];     // modulus, 29-bit limbs
-    uint32_t pinv;      // -p^-1 mod 2^29
-    uint32_t p32[8];    // modulus, 32-bit limbs (final exact reduction)
-    Fe to_int;          // 2^266 mod p, plain integer in 29-bit limbs: ABI -> internal
-    Fe to_abi;          // 2^256 mod p, plain integer in 29-bit limbs: internal -> ABI
-    uint32_t two_p[kN]; // 2p, 29-bit limbs (fe_add_weak)
-    uint32_t two_p_thr; // two_p[8] + 2: top-limb threshold above which 2p is subtracted
-    uint32_t unit;      // 1, as a run-time value: x * unit + acc is a single v_mad_u64_u32 (mont_mul_add)
+    uint32_t p[kN];       // modulus, 29-bit limbs
+    uint32_t pinv;        // -p^-1 mod 2^29
+    uint32_t unit;        // 1, as a run-time value: x * unit + acc is a single v_mad_u64_u32 (mont_mul_add, tab_dot)
+    const uint32_t *io;   // kIoWords words: [p as 8 x 32-bit limbs | 2^266 mod p | 2^256 mod p] (9 x 29-bit limbs each)
 };
+constexpr int kIoP32 = 0, kIoToInt = 8, kIoToAbi = 8 + kN, kIoWords = 28;
 
 #if defined(PMX_HOSTCHECK) && !defined(__HIPCC__)
 void hostcheck_track(int tag, const Fe &x, const FieldRt &f);   // defined in tests/hostcheck/pmx_hostcheck.cpp
 #endif
+
+// a stored constant: kFeStride words, 9 used (wave-uniform address -> scalar loads / LDS broadcast)
+PMX_FN Fe fe_const(const uint32_t *ptr) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < kN; ++i) r.l[i] = ptr[i];
+    return r;
+}
 
 PMX_FN Fe fe_zero() {
     Fe z;
@@ -105,27 +112,6 @@ PMX_FN Fe fe_add_lazy(const Fe &a, const Fe &b) {
 #pragma unroll
     for (int i = 0; i < kN; ++i) r.l[i] = a.l[i] + b.l[i];
     return r;
-}
-
-// u + r with a cheap magnitude cap, for accumulators that are never multiplied down (the identity lanes
-// of the sparse partial rounds).  u norm B < 2.75, r norm B < 1.3  ->  norm, B < 2.1.
-// The (un-normalised) top limb decides whether 2p is subtracted: top >= two_p_thr implies sum > 2p, and
-// otherwise sum < 2p + 3 * 2^232; signed carries then renormalise the limbs.
-PMX_FN Fe fe_add_weak(const Fe &u, const Fe &r, const FieldRt &f) {
-    const bool sub = (u.l[kN - 1] + r.l[kN - 1]) >= f.two_p_thr;
-    Fe out;
-    int32_t carry = 0;
-#pragma unroll
-    for (int i = 0; i < kN; ++i) {
-        const int32_t d = (int32_t)(u.l[i] + r.l[i]) - (int32_t)(sub ? f.two_p[i] : 0u) + carry;
-        if (i < kN - 1) {
-            out.l[i] = (uint32_t)d & kMask;
-            carry = d >> kW;   // arithmetic shift: borrows propagate as -1
-        } else {
-            out.l[i] = (uint32_t)d;
-        }
-    }
-    return out;
 }
 
 // carry propagation: any limbs < 2^32 (value < 2^261) -> norm
@@ -438,16 +424,16 @@ PMX_FN Abi limbs_29_to_32(const Fe &x) {
 }
 
 // x*2^256 (reduced) -> x*2^261 (norm, B < 1.02)
-PMX_FN Fe fe_from_abi(const Abi &x, const FieldRt &f) { return mont_mul(limbs_32_to_29(x), f.to_int, f); }
+PMX_FN Fe fe_from_abi(const Abi &x, const FieldRt &f) { return mont_mul(limbs_32_to_29(x), fe_const(f.io + kIoToInt), f); }
 
 // x*2^261 (norm or lazy, B <= 4) -> x*2^256 fully reduced to [0, p)
 PMX_FN Abi fe_to_abi(const Fe &x, const FieldRt &f) {
-    const Abi t = limbs_29_to_32(mont_mul(x, f.to_abi, f));   // B < 1.1: at most one subtraction
+    const Abi t = limbs_29_to_32(mont_mul(x, fe_const(f.io + kIoToAbi), f));   // B < 1.1: at most one subtraction
     uint32_t d[8];
     uint32_t borrow = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint64_t v = (uint64_t)t.w[i] - f.p32[i] - borrow;
+        const uint64_t v = (uint64_t)t.w[i] - f.io[kIoP32 + i] - borrow;
         d[i] = (uint32_t)v;
         borrow = (uint32_t)(v >> 32) & 1u;
     }
@@ -478,13 +464,5 @@ __device__ __forceinline__ void abi_store(uint32_t *ptr, const Abi &a) {
     q[1] = abi_hi(a);
 }
 #endif
-
-// a stored constant: kFeStride words, 9 used (wave-uniform address -> scalar loads / LDS broadcast)
-PMX_FN Fe fe_const(const uint32_t *ptr) {
-    Fe r;
-#pragma unroll
-    for (int i = 0; i < kN; ++i) r.l[i] = ptr[i];
-    return r;
-}
 
 }  // namespace pmx

@@ -134,8 +134,8 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
 // except the S-box are by constants, and a product by a constant whose nine residues C * 2^(29 j + 58) mod p are
 // precomputed needs 81 + 18 multiplies instead of 81 + 81 (an N-term row 81 N + 18 instead of 81 N + 81).  Per
 // permutation at t = 3: 44,361 multiplies instead of 51,498.  The tables are 9x larger (54 KiB at t = 3) and stream
-// through the scalar cache, 81 SGPR operands per product: this form is used where the register allocator keeps
-// that stream in SGPRs (the plain permutation kernel); the sponge-driver kernels stay on permute_opt.
+// through the scalar cache, 81 SGPR operands per product.  Used by every t = 3 kernel for alpha = 5 and 17; what
+// makes that stream fit the 100-odd SGPRs of a wave is that FieldRt carries only p, -p^-1 and `unit` by value.
 template <int T, int ALPHA>
 PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
@@ -241,7 +241,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
 // with row[r][q] = M[q] in full rounds, B[q] in the last partial round, and in the sparse partial rounds
 //     q = 0: (m00, v_1, v_2)      q = 1: (w_1, ONE, 0)      q = 2: (w_2, 0, ONE)
 // i.e. the identity lanes take "+ u_i" as a product with ONE = 2^261 mod p inside the same reduction, so their
-// magnitude is re-normalised every round (no fe_add_weak) and the code is uniform across lanes.
+// magnitude is re-normalised every round and the code is uniform across lanes.
 // Table (pmx_prepare.hpp): coop[r][q][0] = ark'[r][q], coop[r][q][1..3] = row[r][q][0..2].
 constexpr int kCoopElems = 4;   // elements per (round, lane)
 

@@ -52,6 +52,7 @@ struct Prepared {
     //   tab_sparse_offset          sparse   [RP-1][2t-1]
     //   tab_bdense_offset          bdense   [t][t]
     size_t tab_mds_offset, tab_sparse_offset, tab_bdense_offset;
+    size_t io_offset;   // kIoWords words behind FieldRt::io
 };
 
 // shifted table of one constant (given as the ABI Montgomery residue C * 2^256): tab[k * 9 + j] = limb k of
@@ -308,18 +309,16 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
             }
     }
     FieldRt &f = out.f;
-    {
-        U256 two_p;
-        u256_add(two_p, hf.p, hf.p);   // p < 2^255: no carry
-        to_limbs29(two_p, f.two_p);
-        f.two_p_thr = f.two_p[kN - 1] + 2;
-        f.unit = 1;
-    }
+    f.unit = 1;
     to_limbs29(hf.p, f.p);
     f.pinv = (uint32_t)hf.inv & kMask;
-    std::memcpy(f.p32, hf.p.l, 32);
-    to_limbs29(times_pow2(hf, hf.r, 10), f.to_int.l);   // 2^266 mod p
-    to_limbs29(hf.r, f.to_abi.l);                       // 2^256 mod p
+    // constants of the ABI conversions (FieldRt::io)
+    out.io_offset = out.consts.size();
+    out.consts.resize(out.io_offset + kIoWords, 0u);
+    std::memcpy(&out.consts[out.io_offset + kIoP32], hf.p.l, 32);
+    to_limbs29(times_pow2(hf, hf.r, 10), &out.consts[out.io_offset + kIoToInt]);   // 2^266 mod p
+    to_limbs29(hf.r, &out.consts[out.io_offset + kIoToAbi]);                       // 2^256 mod p
+    f.io = out.consts.data() + out.io_offset;   // host view; valid while `out` is neither copied nor resized
     to_limbs29(times_pow2(hf, hf.r, 5), out.one.l);     // 2^261 mod p
     out.c.rate = cfg->rate;
     out.c.capacity = cfg->capacity;

@@ -1,47 +1,11 @@
-// Feasibility probe for "shifted-constant tables": products by CONSTANTS computed as sum_j z_j * T_j with
-// T_j = C * 2^(29 j + 58) mod p precomputed (81 words per constant), followed by two Montgomery steps, against the
-// current product + full reduction.  Random table contents: timing only, no values are checked.
+// Timing probe for the shifted-constant tables (pmx_field.hpp: tab_dot): 31 partial rounds of the t = 3 schedule with
+// products by constants as sum_j z_j * T_j + two Montgomery steps, against product + full reduction.  Random table contents: timing only, no values are checked.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -opt-disable=reassociate -I sponge_amd/csrc tools/tab_microbench.hip -o tools/tab_microbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 #include "pmx_field.hpp"
 using namespace pmx;
-
-// sum_i z[i] * C_i * 2^-261 from shifted tables tab_i[k * 9 + j] = limb k of T_j(C_i); optional addend s
-template <int N, bool ADD>
-__device__ __forceinline__ Fe tab_dot(const Fe (&z)[N], const uint32_t *const (&tab)[N], const Fe &s, const FieldRt &f) {
-    constexpr int S = 2;
-    uint32_t m[S];
-    Fe out;
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < kN + S; ++k) {
-        if (k < kN) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-#pragma unroll
-                for (int j = 0; j < kN; ++j) acc += (uint64_t)z[i].l[j] * tab[i][k * kN + j];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < S; ++q) {
-            if (q < k && k - q < kN) acc += (uint64_t)m[q] * f.p[k - q];
-        }
-        if (k < S) {
-            m[k] = mont_step(acc, f);
-        } else {
-            if (ADD) acc += (uint64_t)s.l[k - S] * f.unit;
-            if (k < kN + S - 1) {
-                out.l[k - S] = (uint32_t)acc & kMask;
-                acc >>= kW;
-            } else {
-                out.l[k - S] = (uint32_t)acc;
-            }
-        }
-    }
-    return out;
-}
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k(uint32_t *o, const uint32_t *__restrict__ in, const uint32_t *__restrict__ tabs, FieldRt f, int rounds) {
@@ -62,14 +26,10 @@ __global__ void __launch_bounds__(256) k(uint32_t *o, const uint32_t *__restrict
             s[1] = mont_mul_add(z[0], fe_const(sp + 3 * kFeStride), s[1], f);
             s[2] = mont_mul_add(z[0], fe_const(sp + 4 * kFeStride), s[2], f);
         } else {
-            const uint32_t *sp = tabs + (size_t)r * 5 * 81;
-            const uint32_t *const t3[3] = {sp, sp + 81, sp + 162};
-            s[0] = tab_dot<3, false>(z, t3, z[0], f);
-            const Fe z0[1] = {z[0]};
-            const uint32_t *const t1[1] = {sp + 243};
-            const uint32_t *const t2[1] = {sp + 324};
-            s[1] = tab_dot<1, true>(z0, t1, s[1], f);
-            s[2] = tab_dot<1, true>(z0, t2, s[2], f);
+            const uint32_t *sp = tabs + (size_t)r * 5 * kTabWords;
+            s[0] = tab_dot<3, false>(z, sp, z[0], f);
+            s[1] = tab_dot<1, true>(z, sp + 3 * kTabWords, s[1], f);
+            s[2] = tab_dot<1, true>(z, sp + 4 * kTabWords, s[2], f);
         }
     }
     for (int e = 0; e < 3; ++e)
@@ -89,6 +49,7 @@ int main() {
     hipMemcpy(d_in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(d_t, t.data(), t.size() * 4, hipMemcpyHostToDevice);
     FieldRt f{};
+    f.io = nullptr;
     for (int i = 0; i < 9; ++i) f.p[i] = rnd() & kMask;
     f.p[0] |= 1; f.pinv = 0x12345677; f.unit = 1;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
