@@ -32,6 +32,7 @@
 // (tools/host_field_check.cpp); on the device `acc += (uint64_t)a * b` is exactly one v_mad_u64_u32.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -54,6 +55,40 @@ constexpr int kW = 29;                       // bits per limb
 constexpr int kN = 9;                        // limbs
 constexpr uint32_t kMask = (1u << kW) - 1;
 constexpr int kFeStride = 12;                // u32 words per stored constant (9 used; 48-byte aligned rows)
+
+// Scheduling fence (device only): nothing is moved across it by the machine scheduler.  Keeps the independent lane
+// updates of a wide state from being interleaved (t = 6, 8 spilled kilobytes to scratch without it) and bounds how
+// much of a constant stream is hoisted into SGPRs (tab_dot_stream).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PMX_SCHED_FENCE() ((void)0)
+#endif
+
+// Fence for a software-pipelined constant stream (tab_dot_stream): sched_barrier alone only orders instructions that
+// have side effects - instruction selection is free to place the multiplies of every chunk after the last barrier,
+// which it does.  Passing the accumulator through an empty volatile asm with a memory clobber pins the multiplies
+// that produce it before the fence and the constant loads that follow it after.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PMX_STREAM_FENCE(acc)                          \
+    do {                                               \
+        asm volatile("" : "+v"(acc) : : "memory");     \
+        __builtin_amdgcn_sched_barrier(0);             \
+    } while (0)
+#else
+#define PMX_STREAM_FENCE(acc) ((void)0)
+#endif
+
+// Guaranteed compile-time unrolling of the element loops (#pragma unroll gives up on bodies this large, and a
+// rolled loop would index the register-resident state dynamically, i.e. push it to scratch memory).
+template <int I, int N, class F>
+PMX_FN void static_for(F &&fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(fn);
+    }
+}
+
 
 struct Fe {
     uint32_t l[kN];
@@ -250,19 +285,70 @@ PMX_FN Fe mont_sqr(const Fe &a, const FieldRt &f) {
 }
 
 // ---- products by CONSTANTS: shifted tables -----------------------------------------------------------------------
-// For a constant C the host stores the nine residues  T_j = C * 2^(29 j + 58) mod p  (canonical, 9 limbs each) as
-// tab[k * 9 + j] = limb k of T_j  (kTabWords = 81 words).  Then for any element z (internal form, limbs z_j)
+// For a constant C the host stores the nine residues  T_j = C * 2^(29 j + 58) mod p  (canonical, 9 limbs each), a row
+// of N constants in consumption order (layout below).  Then for any element z (internal form, limbs z_j)
 //     U = sum_j z_j * T_j  =  z * C * 2^58   (mod p),        U < 9 * 2^29 * p,
 // is NINE columns of nine limb products, and two Montgomery steps (18 more multiplies) turn it into
 // z * C * 2^-261 * 2^261 - the same value mont_mul(z, C~) returns - with the result below (1 + 2^-20) p.  That is 99
 // multiplies for a product by a constant instead of 162, and 81 N + 18 for an N-term dot product instead of
-// 81 N + 81; the price is 9x the table size (pmx_prepare.hpp), streamed through the scalar cache.
+// 81 N + 81; the price is 10x the table size (pmx_prepare.hpp), streamed through the scalar cache.
 // Operands z must be norm (limbs < 2^29): a column then holds 9 products per term, at most 6 terms (+ 2 reduction
 // products + carry < 2^64) per accumulator; wider dots use two accumulators combined once per column.
 // ADD (N = 1 only): returns z * C + s, the addend entering two columns up (s * 2^58 before the two steps), as in
 // mont_mul_add; s norm, result norm with B < Bs + 1 + 2^-20.
-constexpr int kTabWords = kN * kN;
 constexpr int kTabSteps = 2;
+// Table layout (pmx_prepare.hpp: put_shifted_row).  The words are grouped into CHUNKS of 27 padded to 32, in the
+// order the products consume them, so that the scalar loads of one chunk never straddle the next (the compiler merges
+// contiguous scalar loads up to 16 dwords, and a load that covers two chunks keeps the second one's SGPRs alive):
+//   row of N >= 2 constants:  chunk (k, g) = column k of terms 3g .. 3g+2   at word (k * ceil(N/3) + g) * 32,
+//                             inside it limb k of T_j(C_i) at (i - 3g) * 9 + j
+//   single constant:          chunk h = columns 3h .. 3h+2                   at word h * 32,  inside it (k - 3h) * 9 + j
+constexpr int kTabChunk = 3;
+constexpr int kTabChunkWords = 32;
+constexpr int kTabOneWords = (kN / kTabChunk) * kTabChunkWords;   // 96
+PMX_FN constexpr int tab_row_words(int n) { return n == 1 ? kTabOneWords : kN * ((n + kTabChunk - 1) / kTabChunk) * kTabChunkWords; }
+template <int N>
+PMX_FN constexpr int tab_index(int i, int k, int j) {
+    return N == 1 ? (k / kTabChunk) * kTabChunkWords + (k % kTabChunk) * kN + j
+                  : (k * ((N + kTabChunk - 1) / kTabChunk) + i / kTabChunk) * kTabChunkWords + (i % kTabChunk) * kN + j;
+}
+
+// end of column k of a table product: the two reduction chains reach up to here, then either a Montgomery step
+// (k < 2) or a result limb (with the addend of the ADD form entering first)
+template <int G, bool ADD>
+PMX_FN void tab_col_end(int k, uint64_t (&acc)[G], uint32_t (&m)[kTabSteps], Fe &out, const Fe &s, const FieldRt &f) {
+#pragma unroll
+    for (int q = 0; q < kTabSteps; ++q) {
+        if (q < k && k - q < kN) acc[0] += (uint64_t)m[q] * f.p[k - q];
+    }
+    if constexpr (G == 1) {
+        if (k < kTabSteps) {
+            m[k] = mont_step(acc[0], f);
+        } else {
+            if constexpr (ADD) acc[0] += (uint64_t)s.l[k - kTabSteps] * f.unit;
+            if (k < kN + kTabSteps - 1) {
+                out.l[k - kTabSteps] = (uint32_t)acc[0] & kMask;
+                acc[0] >>= kW;
+            } else {
+                out.l[k - kTabSteps] = (uint32_t)acc[0];
+            }
+        }
+    } else {
+        const uint32_t low = ((uint32_t)acc[0] & kMask) + ((uint32_t)acc[1] & kMask);
+        const uint64_t carry = (acc[0] >> kW) + (acc[1] >> kW);
+        acc[1] = 0;
+        if (k < kTabSteps) {
+            m[k] = (low * f.pinv) & kMask;
+            const uint64_t v = (uint64_t)m[k] * f.p[0] + low;   // low 29 bits are zero
+            acc[0] = carry + (v >> kW);
+        } else if (k < kN + kTabSteps - 1) {
+            out.l[k - kTabSteps] = low & kMask;
+            acc[0] = carry + (low >> kW);
+        } else {
+            out.l[k - kTabSteps] = (uint32_t)acc[0];   // top limb: no products this high, acc[1] is empty
+        }
+    }
+}
 
 template <int N, bool ADD>
 PMX_FN Fe tab_dot(const Fe *z, const uint32_t *tab, const Fe &s, const FieldRt &f) {
@@ -281,42 +367,96 @@ PMX_FN Fe tab_dot(const Fe *z, const uint32_t *tab, const Fe &s, const FieldRt &
 #pragma unroll
             for (int i = 0; i < N; ++i) {
 #pragma unroll
-                for (int j = 0; j < kN; ++j) acc[i < kSplit ? 0 : G - 1] += (uint64_t)z[i].l[j] * tab[i * kTabWords + k * kN + j];
+                for (int j = 0; j < kN; ++j) acc[i < kSplit ? 0 : G - 1] += (uint64_t)z[i].l[j] * tab[tab_index<N>(i, k, j)];
             }
         }
-#pragma unroll
-        for (int q = 0; q < kTabSteps; ++q) {
-            if (q < k && k - q < kN) acc[0] += (uint64_t)m[q] * f.p[k - q];
-        }
-        if constexpr (G == 1) {
-            if (k < kTabSteps) {
-                m[k] = mont_step(acc[0], f);
-            } else {
-                if constexpr (ADD) acc[0] += (uint64_t)s.l[k - kTabSteps] * f.unit;
-                if (k < kN + kTabSteps - 1) {
-                    out.l[k - kTabSteps] = (uint32_t)acc[0] & kMask;
-                    acc[0] >>= kW;
-                } else {
-                    out.l[k - kTabSteps] = (uint32_t)acc[0];
-                }
-            }
-        } else {
-            uint32_t low = ((uint32_t)acc[0] & kMask) + ((uint32_t)acc[1] & kMask);
-            uint64_t carry = (acc[0] >> kW) + (acc[1] >> kW);
-            acc[1] = 0;
-            if (k < kTabSteps) {
-                m[k] = (low * f.pinv) & kMask;
-                const uint64_t v = (uint64_t)m[k] * f.p[0] + low;   // low 29 bits are zero
-                acc[0] = carry + (v >> kW);
-            } else if (k < kN + kTabSteps - 1) {
-                out.l[k - kTabSteps] = low & kMask;
-                acc[0] = carry + (low >> kW);
-            } else {
-                out.l[k - kTabSteps] = (uint32_t)acc[0];   // top limb: no products this high, acc[1] is empty
-            }
-        }
+        tab_col_end<G, ADD>(k, acc, m, out, s, f);
     }
     return out;
+}
+
+// ---- the same products with the constant stream software-pipelined (wide states, 2-3 waves per SIMD) -----------
+// An N-term row consumes 81 N SGPR operands, one per multiply.  Left alone the compiler hoists as much of that
+// stream as it can and spills SGPRs to VGPR lanes by the thousand (v_readlane / v_writelane are VALU instructions).
+// Here the stream is cut into chunks of at most 27 words - three terms of one column of a row, or three columns of
+// a single product; the rows are laid out so that a chunk is contiguous - chunk c + 1 is loaded while chunk c is
+// multiplied, and a scheduling fence after every chunk stops anything else from moving up.
+#ifndef PMX_TAB_PREFETCH
+#define PMX_TAB_PREFETCH 1
+#endif
+
+template <int N>
+PMX_FN Fe tab_dot_stream(const Fe *z, const uint32_t *tab, const FieldRt &f) {
+    constexpr int NG = (N + kTabChunk - 1) / kTabChunk;   // term groups per column
+    constexpr int G = N <= 6 ? 1 : 2;                     // groups 0, 1 -> acc[0] (<= 54 + 2 products), the rest -> acc[1]
+    static_assert(N <= 9, "two accumulators");
+    constexpr int kChunks = kN * NG;
+    uint32_t m[kTabSteps];
+    Fe out;
+    uint64_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0;
+    uint32_t buf[2][kTabChunk * kN];
+    auto load = [&](auto cc, uint32_t *b) {
+        constexpr int c = decltype(cc)::value, k = c / NG, g = c % NG;
+        constexpr int cnt = (N - kTabChunk * g) < kTabChunk ? (N - kTabChunk * g) : kTabChunk;
+#pragma unroll
+        for (int w = 0; w < cnt * kN; ++w) b[w] = tab[(k * NG + g) * kTabChunkWords + w];
+    };
+    if constexpr (PMX_TAB_PREFETCH) load(std::integral_constant<int, 0>{}, buf[0]);
+    static_for<0, kChunks>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, k = c / NG, g = c % NG;
+        constexpr int cnt = (N - kTabChunk * g) < kTabChunk ? (N - kTabChunk * g) : kTabChunk;
+        if constexpr (!PMX_TAB_PREFETCH) load(cc, buf[c & 1]);
+        else if constexpr (c + 1 < kChunks) load(std::integral_constant<int, c + 1>{}, buf[(c + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+            for (int j = 0; j < kN; ++j) acc[(G == 2 && g >= 2) ? 1 : 0] += (uint64_t)z[kTabChunk * g + i].l[j] * buf[c & 1][i * kN + j];
+        }
+        if constexpr (g == NG - 1) tab_col_end<G, false>(k, acc, m, out, out, f);
+        if constexpr (G == 2) PMX_STREAM_FENCE(acc[1]);
+        PMX_STREAM_FENCE(acc[0]);
+    });
+#pragma unroll
+    for (int k = kN; k < kN + kTabSteps; ++k) tab_col_end<G, false>(k, acc, m, out, out, f);
+    return out;
+}
+
+// s[l] <- s[l] + z0 * w_l for L single constants whose tables follow each other (the identity lanes of one sparse
+// round), as ONE stream: three columns per chunk, the next lane's first chunk in flight during the last of this one
+template <int L>
+PMX_FN void tab_lanes_stream(const Fe &z0, const uint32_t *tab, Fe *s, const FieldRt &f) {
+    constexpr int kParts = kN / kTabChunk;   // chunks per lane
+    constexpr int kChunks = L * kParts;
+    uint32_t m[kTabSteps];
+    Fe out;
+    uint64_t acc[1] = {0};
+    uint32_t buf[2][kTabChunk * kN];
+    auto load = [&](auto cc, uint32_t *b) {
+        constexpr int c = decltype(cc)::value;
+#pragma unroll
+        for (int w = 0; w < kTabChunk * kN; ++w) b[w] = tab[(c / kParts) * kTabOneWords + (c % kParts) * kTabChunkWords + w];
+    };
+    if constexpr (PMX_TAB_PREFETCH) load(std::integral_constant<int, 0>{}, buf[0]);
+    static_for<0, kChunks>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, l = c / kParts, h = c % kParts;
+        if constexpr (!PMX_TAB_PREFETCH) load(cc, buf[c & 1]);
+        else if constexpr (c + 1 < kChunks) load(std::integral_constant<int, c + 1>{}, buf[(c + 1) & 1]);
+#pragma unroll
+        for (int kk = 0; kk < kTabChunk; ++kk) {
+#pragma unroll
+            for (int j = 0; j < kN; ++j) acc[0] += (uint64_t)z0.l[j] * buf[c & 1][kk * kN + j];
+            tab_col_end<1, true>(kTabChunk * h + kk, acc, m, out, s[l], f);
+        }
+        if constexpr (h == kParts - 1) {
+#pragma unroll
+            for (int k = kN; k < kN + kTabSteps; ++k) tab_col_end<1, true>(k, acc, m, out, s[l], f);
+            s[l] = out;
+            acc[0] = 0;
+        }
+        PMX_STREAM_FENCE(acc[0]);
+    });
 }
 
 // ---- run-time-width dot products: explicit column array ---------------------------------------------------------

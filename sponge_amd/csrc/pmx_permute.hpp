@@ -7,27 +7,7 @@
 #pragma once
 #include "pmx_field.hpp"
 
-#include <type_traits>
-
 namespace pmx {
-
-// Scheduling fence (device only): keeps the machine scheduler from interleaving the independent lane updates of
-// a wide state, which otherwise blows the register budget (t = 6, 8 spilled kilobytes to scratch without it).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define PMX_SCHED_FENCE() ((void)0)
-#endif
-
-// Guaranteed compile-time unrolling of the element loops (#pragma unroll gives up on bodies this large, and a
-// rolled loop would index the register-resident state dynamically, i.e. push it to scratch memory).
-template <int I, int N, class F>
-PMX_FN void static_for(F &&fn) {
-    if constexpr (I < N) {
-        fn(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(fn);
-    }
-}
 
 // Wave-uniform scalars of a config (by value: SGPRs).
 struct Rounds {
@@ -73,7 +53,7 @@ PMX_FN void permute_dense(Fe (&s)[T], const uint32_t *ark, const uint32_t *mds, 
 // Outputs are identical mod p to the dense schedule.
 struct OptTables {
     const uint32_t *ark, *mds, *sparse, *bdense;         // elements, kFeStride words each
-    const uint32_t *tab_mds, *tab_sparse, *tab_bdense;   // the same matrices as shifted tables (permute_opt_tab)
+    const uint32_t *tab_mds, *tab_sparse, *tab_bdense;   // the same matrices as shifted tables (pmx_prepare.hpp layout)
 };
 
 template <int T, int ALPHA>
@@ -136,6 +116,14 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
 // permutation at t = 3: 44,361 multiplies instead of 51,498.  The tables are 9x larger (54 KiB at t = 3) and stream
 // through the scalar cache, 81 SGPR operands per product.  Used by every t = 3 kernel for alpha = 5 and 17; what
 // makes that stream fit the 100-odd SGPRs of a wave is that FieldRt carries only p, -p^-1 and `unit` by value.
+#ifndef PMX_OPT_TAB_STREAM
+#define PMX_OPT_TAB_STREAM 0   // 1: permute_opt_tab consumes its tables through the explicitly pipelined stream forms
+#endif
+#if PMX_OPT_TAB_STREAM
+#define PMX_OPT_TAB_ROW(z, tab) tab_dot_stream<T>(z, tab, f)
+#else
+#define PMX_OPT_TAB_ROW(z, tab) tab_dot<T, false>(z, tab, (z)[0], f)
+#endif
 template <int T, int ALPHA>
 PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
@@ -146,20 +134,24 @@ PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, co
             static_for<0, T>([&](auto i) {
                 y[i] = fe_sbox<ALPHA>(fe_add_lazy(s[i], fe_const(rk + i * kFeStride)), c.alpha, one, f);
             });
-            static_for<0, T>([&](auto i) { s[i] = tab_dot<T, false>(y, tb.tab_mds + (size_t)i * T * kTabWords, y[0], f); });
+            static_for<0, T>([&](auto i) { s[i] = PMX_OPT_TAB_ROW(y, tb.tab_mds + (size_t)i * tab_row_words(T)); });
             continue;
         }
         Fe z[T];
         z[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         static_for<1, T>([&](auto i) { z[i] = s[i]; });
         if (r < last_partial) {
-            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * (2 * T - 1) * kTabWords;
-            s[0] = tab_dot<T, false>(z, sp, z[0], f);
+            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
+            s[0] = PMX_OPT_TAB_ROW(z, sp);
             PMX_TRACK(0, s[0], f);
-            static_for<1, T>([&](auto i) { s[i] = tab_dot<1, true>(z, sp + (T + i - 1) * kTabWords, s[i], f); });
+#if PMX_OPT_TAB_STREAM
+            tab_lanes_stream<T - 1>(z[0], sp + tab_row_words(T), &s[1], f);
+#else
+            static_for<1, T>([&](auto i) { s[i] = tab_dot<1, true>(z, sp + tab_row_words(T) + (i - 1) * kTabOneWords, s[i], f); });
+#endif
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else {   // last partial round: dense matrix B
-            static_for<0, T>([&](auto i) { s[i] = tab_dot<T, false>(z, tb.tab_bdense + (size_t)i * T * kTabWords, z[0], f); });
+            static_for<0, T>([&](auto i) { s[i] = PMX_OPT_TAB_ROW(z, tb.tab_bdense + (size_t)i * tab_row_words(T)); });
         }
     }
 }
@@ -185,6 +177,23 @@ PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
     return cols_redc(acc, f);
 }
 
+// Widths whose hybrid engine takes its matrices as shifted tables (streamed, pmx_field.hpp: tab_dot_stream).  Measured
+// on the default tables: t = 4 +10 %, t = 5 +3 %, t = 6 +-0, t = 7..9 -6..-10 % - at 2 waves per SIMD the latency of a
+// 400 KiB table that misses the 16 KiB scalar cache on every load is no longer covered by a one-chunk look-ahead
+// (the SGPR file has no room for a deeper one), so wide states stay on the element tables.
+#ifndef PMX_HYBRID_TAB_MAX_T
+#define PMX_HYBRID_TAB_MAX_T 5
+#endif
+
+template <int T, class Scratch>
+PMX_FN void matrix_rows_rolled_tab(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, tab_dot_stream<T>(s, mat + (size_t)i * tab_row_words(T), f));
+    const Fe last = tab_dot_stream<T>(s, mat + (size_t)(T - 1) * tab_row_words(T), f);
+    static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
+    s[T - 1] = last;
+}
+
 template <int T, class Scratch>
 PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
@@ -207,13 +216,22 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                 sc.set(i, fe_sbox<ALPHA>(fe_add_lazy(sc.get(i), fe_const(rk + i * kFeStride)), c.alpha, one, f));
             s[T - 1] = fe_sbox<ALPHA>(fe_add_lazy(s[T - 1], fe_const(rk + (T - 1) * kFeStride)), c.alpha, one, f);
             static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
-            matrix_rows_rolled<T>(s, sc, tb.mds, f);
+            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) matrix_rows_rolled_tab<T>(s, sc, tb.tab_mds, f);
+            else matrix_rows_rolled<T>(s, sc, tb.mds, f);
             continue;
         }
         // partial round: lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom); lane 0 is re-derived
         // every round
         s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
-        if (r < last_partial) {
+        if (r < last_partial && T <= PMX_HYBRID_TAB_MAX_T) {
+            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
+            const Fe z0 = s[0];
+            PMX_SCHED_FENCE();
+            s[0] = tab_dot_stream<T>(s, sp, f);
+            PMX_TRACK(0, s[0], f);
+            tab_lanes_stream<T - 1>(z0, sp + tab_row_words(T), &s[1], f);
+            static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
+        } else if (r < last_partial) {
             const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
             const Fe z0 = s[0];
             s[0] = matrix_row<T>(s, sp, f);
@@ -225,7 +243,9 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             PMX_SCHED_FENCE();
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else {
-            matrix_rows_rolled<T>(s, sc, tb.bdense, f);         // last partial round: dense matrix B
+            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) matrix_rows_rolled_tab<T>(s, sc, tb.tab_bdense, f);
+            else
+                matrix_rows_rolled<T>(s, sc, tb.bdense, f);         // last partial round: dense matrix B
         }
     }
 }

@@ -47,23 +47,30 @@ struct Prepared {
     //   -- only when has_opt and t == 3 (pmx_permute.hpp: cooperative schedule) --
     //   coop_offset                coop     [rounds][3][4]
     size_t coop_offset;
-    //   -- only when has_opt: shifted tables (pmx_field.hpp: tab_dot), kTabWords words per constant --
-    //   tab_mds_offset             mds      [t][t]
-    //   tab_sparse_offset          sparse   [RP-1][2t-1]
-    //   tab_bdense_offset          bdense   [t][t]
+    //   -- only when has_opt: shifted tables (pmx_field.hpp: tab_dot); R = tab_row_words(t) --
+    //   tab_mds_offset             mds      [t] rows of R words
+    //   tab_sparse_offset          sparse   [RP-1] x (row 0: R words, then t-1 single constants of kTabOneWords)
+    //   tab_bdense_offset          bdense   [t] rows of R words
     size_t tab_mds_offset, tab_sparse_offset, tab_bdense_offset;
     size_t io_offset;   // kIoWords words behind FieldRt::io
 };
 
-// shifted table of one constant (given as the ABI Montgomery residue C * 2^256): tab[k * 9 + j] = limb k of
-// C * 2^(29 j + 58) mod p
-inline void put_shifted_table(const HostField &hf, const U256 &c_mont, uint32_t *tab) {
-    U256 tj = times_pow2(hf, hf.from_mont(c_mont), 29 * 0 + 58);
-    for (int j = 0; j < kN; ++j) {
-        uint32_t limbs[kN];
-        to_limbs29(tj, limbs);
-        for (int k = 0; k < kN; ++k) tab[k * kN + j] = limbs[k];
-        tj = times_pow2(hf, tj, kW);
+// shifted table of a ROW of n constants (given as ABI Montgomery residues C_i * 2^256) in the chunked layout of
+// pmx_field.hpp (tab_index): limb k of C_i * 2^(29 j + 58) mod p; tab_row_words(n) words, padding left 0
+inline void put_shifted_row(const HostField &hf, const U256 *c_mont, size_t n, uint32_t *tab) {
+    for (size_t i = 0; i < n; ++i) {
+        U256 tj = times_pow2(hf, hf.from_mont(c_mont[i]), 58);
+        for (int j = 0; j < kN; ++j) {
+            uint32_t limbs[kN];
+            to_limbs29(tj, limbs);
+            for (int k = 0; k < kN; ++k) {
+                const size_t ng = (n + kTabChunk - 1) / kTabChunk;
+                const size_t at = n == 1 ? (size_t)(k / kTabChunk) * kTabChunkWords + (k % kTabChunk) * kN + j
+                                         : ((size_t)k * ng + i / kTabChunk) * kTabChunkWords + (i % kTabChunk) * kN + j;
+                tab[at] = limbs[k];
+            }
+            tj = times_pow2(hf, tj, kW);
+        }
     }
 }
 
@@ -295,18 +302,22 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
             }
         }
     }
-    // shifted tables of every constant the optimised schedule multiplies by
+    // shifted tables of every constant the optimised schedule multiplies by: every matrix row is one t-term dot
+    // product; a sparse round is its row 0 (t terms) followed by t-1 single products
     out.tab_mds_offset = out.tab_sparse_offset = out.tab_bdense_offset = out.consts.size();
     if (out.has_opt) {
-        out.tab_sparse_offset = out.tab_mds_offset + tab_src_mds.size() * kTabWords;
-        out.tab_bdense_offset = out.tab_sparse_offset + tab_src_sparse.size() * kTabWords;
-        out.consts.resize(out.tab_bdense_offset + tab_src_bdense.size() * kTabWords, 0u);
-        size_t w = out.tab_mds_offset;
-        for (const auto *vec : {&tab_src_mds, &tab_src_sparse, &tab_src_bdense})
-            for (const U256 &v : *vec) {
-                put_shifted_table(hf, v, &out.consts[w]);
-                w += kTabWords;
-            }
+        const size_t row = (size_t)tab_row_words((int)t), per_round = row + (t - 1) * kTabOneWords, src_per_round = 2 * t - 1;
+        const size_t n_sparse = tab_src_sparse.size() / src_per_round;
+        out.tab_sparse_offset = out.tab_mds_offset + t * row;
+        out.tab_bdense_offset = out.tab_sparse_offset + n_sparse * per_round;
+        out.consts.resize(out.tab_bdense_offset + t * row, 0u);
+        for (size_t i = 0; i < t; ++i) put_shifted_row(hf, &tab_src_mds[i * t], t, &out.consts[out.tab_mds_offset + i * row]);
+        for (size_t i = 0; i < t; ++i) put_shifted_row(hf, &tab_src_bdense[i * t], t, &out.consts[out.tab_bdense_offset + i * row]);
+        for (size_t r = 0; r < n_sparse; ++r) {
+            uint32_t *dst = &out.consts[out.tab_sparse_offset + r * per_round];
+            put_shifted_row(hf, &tab_src_sparse[r * src_per_round], t, dst);
+            for (size_t l = 0; l + 1 < t; ++l) put_shifted_row(hf, &tab_src_sparse[r * src_per_round + t + l], 1, dst + row + l * kTabOneWords);
+        }
     }
     FieldRt &f = out.f;
     f.unit = 1;

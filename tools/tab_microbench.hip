@@ -26,10 +26,10 @@ __global__ void __launch_bounds__(256) k(uint32_t *o, const uint32_t *__restrict
             s[1] = mont_mul_add(z[0], fe_const(sp + 3 * kFeStride), s[1], f);
             s[2] = mont_mul_add(z[0], fe_const(sp + 4 * kFeStride), s[2], f);
         } else {
-            const uint32_t *sp = tabs + (size_t)r * 5 * kTabWords;
+            const uint32_t *sp = tabs + (size_t)r * (tab_row_words(3) + 2 * kTabOneWords);
             s[0] = tab_dot<3, false>(z, sp, z[0], f);
-            s[1] = tab_dot<1, true>(z, sp + 3 * kTabWords, s[1], f);
-            s[2] = tab_dot<1, true>(z, sp + 4 * kTabWords, s[2], f);
+            s[1] = tab_dot<1, true>(z, sp + tab_row_words(3), s[1], f);
+            s[2] = tab_dot<1, true>(z, sp + tab_row_words(3) + kTabOneWords, s[2], f);
         }
     }
     for (int e = 0; e < 3; ++e)
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *o, const uint32_t *__restrict
 int main() {
     const size_t n = 1 << 20;
     const int rounds = 31;
-    std::vector<uint32_t> h(n * 27), t(rounds * 5 * 81);
+    std::vector<uint32_t> h(n * 27), t(rounds * 5 * 96);
     uint64_t x = 88172645463325252ull;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 20); };
     for (auto &v : h) v = rnd();
