@@ -177,12 +177,18 @@ PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
     return cols_redc(acc, f);
 }
 
-// Widths whose hybrid engine takes its matrices as shifted tables (streamed, pmx_field.hpp: tab_dot_stream).  Measured
-// on the default tables: t = 4 +10 %, t = 5 +3 %, t = 6 +-0, t = 7..9 -6..-10 % - at 2 waves per SIMD the latency of a
-// 400 KiB table that misses the 16 KiB scalar cache on every load is no longer covered by a one-chunk look-ahead
-// (the SGPR file has no room for a deeper one), so wide states stay on the element tables.
+// Which products of the hybrid engines take shifted tables (streamed, pmx_field.hpp: tab_dot_stream / tab_lanes_stream).
+// Measured on the default tables: with every matrix as tables t = 4 gains 10 % and t = 5 3 %, t = 6 nothing, and
+// t = 7..9 LOSE 6-10 % - at 2 waves per SIMD the latency of a 400 KiB table that misses the 16 KiB scalar cache on
+// every load is not covered by a one-chunk look-ahead, and the SGPR file has no room for a deeper one.  So up to
+// PMX_HYBRID_TAB_MAX_T everything is tables; above it only the identity lanes are (171 -> 108 multiplies each, half
+// the stream of the whole round), while the t-term rows, where one reduction is already shared by t products and a
+// table would save 63 of 810 multiplies, stay on the element form: +3..7 % at t = 6..9.
 #ifndef PMX_HYBRID_TAB_MAX_T
 #define PMX_HYBRID_TAB_MAX_T 5
+#endif
+#ifndef PMX_HYBRID_WIDE_LANES_TAB
+#define PMX_HYBRID_WIDE_LANES_TAB 1
 #endif
 
 template <int T, class Scratch>
@@ -236,11 +242,18 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             const Fe z0 = s[0];
             s[0] = matrix_row<T>(s, sp, f);
             PMX_TRACK(0, s[0], f);
-            static_for<1, T>([&](auto i) {
+            if constexpr (PMX_HYBRID_WIDE_LANES_TAB) {
+                // wide states: only the identity lanes take tables - that is where they pay (108 instead of 171 multiplies
+                // each); a 9-term row saves 63 of 810 and would double the constant stream
                 PMX_SCHED_FENCE();
-                s[i] = mont_mul_add(z0, fe_const(sp + (T + i - 1) * kFeStride), s[i], f);
-            });
-            PMX_SCHED_FENCE();
+                tab_lanes_stream<T - 1>(z0, tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords) + tab_row_words(T), &s[1], f);
+            } else {
+                static_for<1, T>([&](auto i) {
+                    PMX_SCHED_FENCE();
+                    s[i] = mont_mul_add(z0, fe_const(sp + (T + i - 1) * kFeStride), s[i], f);
+                });
+                PMX_SCHED_FENCE();
+            }
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else {
             if constexpr (T <= PMX_HYBRID_TAB_MAX_T) matrix_rows_rolled_tab<T>(s, sc, tb.tab_bdense, f);
