@@ -723,7 +723,7 @@ PMX_HYB_DECL(hybridg_)
         if (t == 3 && c.has_opt) {                                                          \
             if (alpha == 5) return Launch<RegEngine<3, 5, true, true>>::CALL;               \
             if (alpha == 17) return Launch<RegEngine<3, 17, true, true>>::CALL;             \
-            return Launch<RegEngine<3, 0, true>>::CALL;                                     \
+            return Launch<RegEngine<3, 0, true, true>>::CALL;                               \
         }                                                                                   \
         if (t == 3) return Launch<RegEngine<3, 0, false>>::CALL;                            \
         if (c.has_opt && t >= 4 && t <= 9) {                                                \
