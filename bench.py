@@ -45,17 +45,18 @@ WORKLOADS = {
 HASH_SHAPES = {"h3": (4, 1, 2), "h9": (8, 1, 1)}     # workload -> (in_len, out_len, permutations per row)
 
 
-def mads_per_permutation(t, alpha, rf, rp, optimised, tables=False):
+def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tables=False):
     """v_mad_u64_u32 count of one permutation as implemented (pmx_field.hpp): product 81, square 45, reduction 81 limb
-    products; one reduction per S-box step and per matrix row.  `tables`: the matrices are shifted tables (tab_dot): a
-    row of N constants costs 81 N + 18, an identity-lane update 81 + 18 + 9."""
+    products; one reduction per S-box step and per matrix row.  With shifted tables (tab_dot) a row of N constants
+    costs 81 N + 18 instead of 81 N + 81 (`row_tables`) and an identity-lane update 81 + 18 + 9 instead of 162 + 9
+    (`lane_tables`)."""
     sqr, mul = 45 + 81, 81 + 81
     chain = {5: 2 * sqr + mul, 17: 4 * sqr + mul}.get(alpha)
     if chain is None:
         bits = bin(alpha)[3:]
         chain = len(bits) * sqr + bits.count("1") * mul
-    dot = 81 * t + (18 if tables else 81)
-    lane = (81 + 18 + 9) if tables else (mul + 9)     # + 9 multiply-by-one injections of the addend
+    dot = 81 * t + (18 if row_tables else 81)
+    lane = (81 + 18 + 9) if lane_tables else (mul + 9)     # + 9 multiply-by-one injections of the addend
     full = t * chain + t * dot
     if optimised:
         partial = (rp - 1) * (chain + dot + (t - 1) * lane) + (chain + t * dot)
@@ -278,8 +279,10 @@ def main():
             bytes_per_unit = (in_len + out_len) * 32 / perms_per_row
         algo_bytes = bytes_per_unit * per_gpu_units
         achieved = algo_bytes / kernel_s / 1e9
-        mads = mads_per_permutation(t, alpha, rf, rp, optimised=(t == 3 or (4 <= t <= 9 and alpha == 5)),
-                                    tables=(t == 3 and alpha in (5, 17))) + (3 if merkle else 2 * t) * 162   # + ABI conversions
+        # engines as dispatched (pmx_device.hip): t = 3..9 run the optimised schedule, with every matrix as shifted tables up
+        # to t = 5 and the identity lanes only above
+        mads = mads_per_permutation(t, alpha, rf, rp, optimised=3 <= t <= 9, row_tables=3 <= t <= 5, lane_tables=3 <= t <= 9) \
+            + (3 if merkle else 2 * t) * 162   # + ABI conversions
         mad_rate = mads * per_gpu_units / kernel_s
         out = {
             "metric": "Poseidon permutations/sec (%s, t=%d)" % ({"bls12_381_fr": "BLS12-381 Fr", "bn254_fr": "BN254 Fr"}[field_name], t),
