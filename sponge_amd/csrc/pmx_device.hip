@@ -6,9 +6,11 @@
 // Arithmetic: pmx_field.hpp (unsaturated 9 x 29-bit Montgomery form); round schedule: pmx_permute.hpp.
 //
 // Engines (same interface: load_states / store_states / get / set / zero / permute):
-//   RegEngine<3, ALPHA, OPT>   t = 3: state in VGPRs, element loops unrolled, tables staged in LDS.
+//   RegEngine<3, ALPHA, OPT, TAB>  t = 3: state in VGPRs, element loops unrolled; round constants staged in LDS, the
+//                              matrices of the optimised schedule as shifted tables through the scalar cache (TAB).
 //   HybridEngine<T, ALPHA>     t = 4..9 on the optimised schedule: state in VGPRs, the element loops of the full
-//                              rounds rolled through one LDS scratch array per wave, tables via the scalar cache.
+//                              rounds rolled through one LDS scratch array per wave, tables via the scalar cache
+//                              (shifted tables for everything at t <= 5, for the identity lanes above).
 //   LdsEngine<ALPHA>           any width at run time (t = 2, 10..16, or no partial section): state kept in LDS as
 //                              [element][limb][lane] (conflict-free 4-byte accesses), element loops rolled.
 // plus compress_coop_kernel: 2-to-1 compression with one state per quad of lanes, for latency-bound tree levels.
