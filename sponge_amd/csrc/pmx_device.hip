@@ -737,7 +737,16 @@ PMX_HYB_DECL(hybridg_)
         return Launch<LdsEngine<0>>::CALL;                                                  \
     } while (0)
 
+// The shifted tables trade multiplies for a constant stream, and a stream needs a second wave on the SIMD to hide
+// behind: measured per launch at t = 3, the table form wins from 2^17 states up (permute; 2^18 for compress), below
+// that - fewer than two waves per SIMD - the element form is 7-25 % faster (lone-wave latency 0.145 vs 0.16 ms).
+static constexpr size_t kTabMinPermute = (size_t)1 << 17, kTabMinCompress = (size_t)1 << 18;
+
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
+    if (t == 3 && c.has_opt && n < kTabMinPermute) {
+        if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, false>>::permute(c, t, states, n, st);
+        if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, false>>::permute(c, t, states, n, st);
+    }
     PMX_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
@@ -761,6 +770,10 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
         if (c.rounds.alpha == 5) return launch_compress_coop<5>(c, in, out, n, st);
         if (c.rounds.alpha == 17) return launch_compress_coop<17>(c, in, out, n, st);
         return launch_compress_coop<0>(c, in, out, n, st);
+    }
+    if (t == 3 && c.has_opt && n < kTabMinCompress) {
+        if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, false>>::compress(c, t, in, out, n, st);
+        if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, false>>::compress(c, t, in, out, n, st);
     }
     PMX_DISPATCH(compress(c, t, in, out, n, st));
 }
