@@ -742,15 +742,22 @@ PMX_HYB_DECL(hybridg_)
 // that - fewer than two waves per SIMD - the element form is 7-25 % faster (lone-wave latency 0.145 vs 0.16 ms).
 static constexpr size_t kTabMinPermute = (size_t)1 << 17, kTabMinCompress = (size_t)1 << 18;
 
+// t = 3, alpha 5 / 17, fewer than `limit` units: the element-form engine
+#define PMX_SMALL_BATCH(LIMIT, CALL)                                                                 \
+    do {                                                                                             \
+        if (t == 3 && c.has_opt && n < (LIMIT)) {                                                    \
+            if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, false>>::CALL;              \
+            if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, false>>::CALL;            \
+        }                                                                                            \
+    } while (0)
+
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
-    if (t == 3 && c.has_opt && n < kTabMinPermute) {
-        if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, false>>::permute(c, t, states, n, st);
-        if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, false>>::permute(c, t, states, n, st);
-    }
+    PMX_SMALL_BATCH(kTabMinPermute, permute(c, t, states, n, st));
     PMX_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                        size_t n, hipStream_t st) {
+    PMX_SMALL_BATCH(kTabMinPermute, hash(c, t, in, in_len, out, out_len, n, st));
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
 
@@ -771,18 +778,17 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
         if (c.rounds.alpha == 17) return launch_compress_coop<17>(c, in, out, n, st);
         return launch_compress_coop<0>(c, in, out, n, st);
     }
-    if (t == 3 && c.has_opt && n < kTabMinCompress) {
-        if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, false>>::compress(c, t, in, out, n, st);
-        if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, false>>::compress(c, t, in, out, n, st);
-    }
+    PMX_SMALL_BATCH(kTabMinCompress, compress(c, t, in, out, n, st));
     PMX_DISPATCH(compress(c, t, in, out, n, st));
 }
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {
+    PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st));
     PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st));
 }
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
+    PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st));
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
 }
 #endif  // PMX_TU
