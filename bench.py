@@ -239,7 +239,9 @@ def main():
     # steps alone would leave short runs measuring the ramp instead of the kernel.
     t_spin = time.perf_counter()
     i_spin = 0
-    while time.perf_counter() - t_spin < args.spinup_seconds:
+    # a step that contains a collective must run the same number of times on every rank: fixed count instead of a clock
+    collective_in_step = world > 1 and (merkle or args.gather in ("overlap", "serial"))
+    while (i_spin < 64) if collective_in_step else (time.perf_counter() - t_spin < args.spinup_seconds):
         step(i_spin)
         i_spin += 1
         if i_spin % 4 == 0:
