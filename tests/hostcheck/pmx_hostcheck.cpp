@@ -263,6 +263,81 @@ extern "C" int hc_field_op(const uint64_t modulus[4], int op, const uint64_t *a,
     return PMX_OK;
 }
 
+// Products by constants through shifted tables (pmx_field.hpp: tab_dot and the streamed forms), checked one
+// operation at a time.  a: n variable elements, c: n constants (both ABI Montgomery), s: addend.
+//   form 0: tab_dot<n, false>          sum_i a_i * c_i            n in {1, 3, 6, 9}
+//   form 1: tab_dot<1, true>           a_0 * c_0 + s
+//   form 2: tab_dot_stream<n>          sum_i a_i * c_i            n in {3, 4, 9}
+//   form 3: tab_lanes_stream<n>        out_i = s_i + a_0 * c_i    n in {2, 8}   (s, out: n elements)
+template <int N>
+static void tab_case(const Prepared &pp, const HostField &hf, int form, const uint64_t *a, const uint64_t *c, const uint64_t *s, uint64_t *out) {
+    const FieldRt &f = pp.f;
+    Fe z[N], add[N];
+    U256 cm[N];
+    for (int i = 0; i < N; ++i) {
+        z[i] = fe_from_abi(load_abi(a + 4 * (form == 3 ? 0 : i)), f);
+        add[i] = fe_from_abi(load_abi(s + 4 * (form == 3 ? i : 0)), f);
+        std::memcpy(cm[i].l, c + 4 * i, 32);
+    }
+    if (form == 3) {
+        std::vector<uint32_t> tab((size_t)N * kTabOneWords, 0u);
+        for (int i = 0; i < N; ++i) put_shifted_row(hf, &cm[i], 1, &tab[(size_t)i * kTabOneWords]);
+        tab_lanes_stream<N>(z[0], tab.data(), add, f);
+        for (int i = 0; i < N; ++i) store_abi(out + 4 * i, fe_to_abi(add[i], f));
+        return;
+    }
+    std::vector<uint32_t> tab((size_t)tab_row_words(N), 0u);
+    put_shifted_row(hf, cm, N, tab.data());
+    Fe r;
+    if (form == 0) r = tab_dot<N, false>(z, tab.data(), add[0], f);
+    else if (form == 2) r = tab_dot_stream<N>(z, tab.data(), f);
+    else r = fe_zero();
+    store_abi(out, fe_to_abi(r, f));
+}
+
+extern "C" int hc_tab_op(const uint64_t modulus[4], int form, int n, const uint64_t *a, const uint64_t *c, const uint64_t *s, uint64_t *out) {
+    pmx_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    std::memcpy(cfg.modulus, modulus, 32);
+    cfg.full_rounds = 2; cfg.partial_rounds = 0; cfg.rate = 1; cfg.capacity = 0; cfg.alpha = 5;
+    uint64_t zeros[8] = {0};
+    cfg.ark = zeros; cfg.mds = zeros;
+    Prepared pp;
+    std::string err;
+    int rc = prepare(&cfg, pp, err);
+    if (rc) return rc;
+    const HostField &hf = pp.hf;
+    if (form == 1 && n == 1) {
+        U256 cm;
+        std::memcpy(cm.l, c, 32);
+        std::vector<uint32_t> tab(kTabOneWords, 0u);
+        put_shifted_row(hf, &cm, 1, tab.data());
+        const Fe z = fe_from_abi(load_abi(a), pp.f), add = fe_from_abi(load_abi(s), pp.f);
+        store_abi(out, fe_to_abi(tab_dot<1, true>(&z, tab.data(), add, pp.f), pp.f));
+        return PMX_OK;
+    }
+#define PMX_TAB_CASE(F, N) if (form == (F) && n == (N)) { tab_case<N>(pp, hf, form, a, c, s, out); return PMX_OK; }
+    PMX_TAB_CASE(0, 1) PMX_TAB_CASE(0, 3) PMX_TAB_CASE(0, 6) PMX_TAB_CASE(0, 9)
+    PMX_TAB_CASE(2, 3) PMX_TAB_CASE(2, 4) PMX_TAB_CASE(2, 9)
+    PMX_TAB_CASE(3, 2) PMX_TAB_CASE(3, 8)
+#undef PMX_TAB_CASE
+    return PMX_ERR_ARG;
+}
+
+// Largest value a column accumulator of a table product can reach: `terms` terms of nine products each (every column
+// of a table product is full), operand limbs `zmax`, table words < 2^29, plus the two reduction products and the carry.
+extern "C" void hc_worst_tab_column(int terms, uint32_t zmax, uint64_t *hi, uint64_t *lo) {
+    unsigned __int128 worst = 0, acc = 0;
+    for (int k = 0; k < kN + kTabSteps; ++k) {
+        if (k < kN) acc += (unsigned __int128)terms * kN * zmax * kMask;
+        acc += (unsigned __int128)kTabSteps * kMask * kMask + kMask;   // reduction products (+ the addend of the ADD form)
+        if (acc > worst) worst = acc;
+        acc >>= kW;
+    }
+    *hi = (uint64_t)(worst >> 64);
+    *lo = (uint64_t)worst;
+}
+
 // Largest value any 64-bit column accumulator can reach in mont_dot<T> when every a-limb is `amax`,
 // every b-limb `bmax` (worst case over all inputs, ignoring field semantics).  Returned as hi:lo.
 extern "C" void hc_worst_column(int terms, uint32_t amax, uint32_t bmax, uint64_t *hi, uint64_t *lo) {

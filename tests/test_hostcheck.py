@@ -32,6 +32,8 @@ def hc():
     lib.hc_field_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_sqr_column.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.hc_worst_tab_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.hc_tab_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
 
@@ -79,6 +81,47 @@ def test_column_accumulators_cannot_overflow(hc):
         assert (int(hi[0]) == 0) == ok, (terms, amax, bmax, int(hi[0]), int(lo[0]))
     hc.hc_worst_sqr_column((1 << 30) - 1, hi.ctypes.data, lo.ctypes.data)     # squaring a lazily added operand
     assert int(hi[0]) == 0
+
+
+@pytest.mark.parametrize("p", [O.BLS12_381_FR, O.BN254_FR, (1 << 230) + 0x1D])
+def test_shifted_table_products_match_bigint(hc, p):
+    """tab_dot / tab_dot_stream / tab_lanes_stream one operation at a time: a product by a constant through its nine
+    shifted residues plus two Montgomery steps is the same field element as the full product, for every form and
+    width the kernels instantiate, on edge operands (0, 1, p-1, values with all-ones limbs) and random ones."""
+    rng = random.Random(17)
+    mod = np.array(O.to_limbs(p), dtype=np.uint64)
+    edge = [0, 1, p - 1, p - 2, ((1 << 29) - 1) * sum(1 << (29 * i) for i in range(8)) % p, (1 << 229) - 1]
+
+    def pick():
+        return rng.choice(edge) if rng.random() < 0.4 else rng.randrange(p)
+
+    def run(form, n, a, c, s, n_out):
+        out = np.zeros(4 * n_out, dtype=np.uint64)
+        la, lc, ls = (mont_limbs(v, p) for v in (a, c, s))
+        assert hc.hc_tab_op(mod.ctypes.data, form, n, la.ctypes.data, lc.ctypes.data, ls.ctypes.data, out.ctypes.data) == 0
+        return cref.limbs_to_elems(out, p)
+
+    for _ in range(60):
+        for form, n in [(0, 1), (0, 3), (0, 6), (0, 9), (2, 3), (2, 4), (2, 9)]:
+            a, c = [pick() for _ in range(n)], [pick() for _ in range(n)]
+            assert run(form, n, a, c, [0], 1) == [sum(x * y for x, y in zip(a, c)) % p], (form, n)
+        a, c, s = pick(), pick(), pick()
+        assert run(1, 1, [a], [c], [s], 1) == [(a * c + s) % p]
+        for n in (2, 8):
+            a, c, s = pick(), [pick() for _ in range(n)], [pick() for _ in range(n)]
+            assert run(3, n, [a], c, s, n) == [(a * ci + si) % p for ci, si in zip(c, s)], n
+
+
+def test_table_column_accumulators_cannot_overflow(hc):
+    """Every column of a table product holds nine products per term: six normalised terms (+ 2 reduction products, the
+    addend, the carry) fit 64 bits, seven do not - tab_dot splits wider rows over two accumulators; a lazily added
+    operand (limbs < 2^30) would fit three terms only, which is why the operands must be normalised."""
+    hi = np.zeros(1, dtype=np.uint64)
+    lo = np.zeros(1, dtype=np.uint64)
+    for terms, zmax, ok in [(6, (1 << 29) - 1, True), (7, (1 << 29) - 1, False), (5, (1 << 29) - 1, True),
+                            (3, (1 << 30) - 1, True), (4, (1 << 30) - 1, False)]:
+        hc.hc_worst_tab_column(terms, zmax, hi.ctypes.data, lo.ctypes.data)
+        assert (int(hi[0]) == 0) == ok, (terms, zmax, int(hi[0]))
 
 
 def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False, tab=False):
