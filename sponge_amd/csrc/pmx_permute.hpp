@@ -177,8 +177,8 @@ PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
     return cols_redc(acc, f);
 }
 
-// Which products of the hybrid engines take shifted tables (streamed, pmx_field.hpp: tab_dot_stream / tab_lanes_stream).
-// Measured on the default tables: with every matrix as tables t = 4 gains 10 % and t = 5 3 %, t = 6 nothing, and
+// Which products of the hybrid engines take shifted tables (pmx_field.hpp: tab_dot, or streamed: tab_dot_stream /
+// tab_lanes_stream).  Measured on the default tables: with every matrix as tables t = 4 gains 10 % and t = 5 3-9 %, t = 6 nothing, and
 // t = 7..9 LOSE 6-10 % - at 2 waves per SIMD the latency of a 400 KiB table that misses the 16 KiB scalar cache on
 // every load is not covered by a one-chunk look-ahead, and the SGPR file has no room for a deeper one.  So up to
 // PMX_HYBRID_TAB_MAX_T everything is tables; above it only the identity lanes are (171 -> 108 multiplies each, half
@@ -187,6 +187,9 @@ PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
 #ifndef PMX_HYBRID_TAB_MAX_T
 #define PMX_HYBRID_TAB_MAX_T 5
 #endif
+#ifndef PMX_HYBRID_TAB_AUTO
+#define PMX_HYBRID_TAB_AUTO 1   // t <= PMX_HYBRID_TAB_MAX_T: 1 = compiler-scheduled tab_dot (t = 4 +1 %, t = 5 +6 % over 0 = the streamed forms)
+#endif
 #ifndef PMX_HYBRID_WIDE_LANES_TAB
 #define PMX_HYBRID_WIDE_LANES_TAB 1
 #endif
@@ -194,8 +197,13 @@ PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
 template <int T, class Scratch>
 PMX_FN void matrix_rows_rolled_tab(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+#if PMX_HYBRID_TAB_AUTO
+    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, tab_dot<T, false>(s, mat + (size_t)i * tab_row_words(T), s[0], f));
+    const Fe last = tab_dot<T, false>(s, mat + (size_t)(T - 1) * tab_row_words(T), s[0], f);
+#else
     for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, tab_dot_stream<T>(s, mat + (size_t)i * tab_row_words(T), f));
     const Fe last = tab_dot_stream<T>(s, mat + (size_t)(T - 1) * tab_row_words(T), f);
+#endif
     static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
     s[T - 1] = last;
 }
@@ -233,9 +241,19 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
             const Fe z0 = s[0];
             PMX_SCHED_FENCE();
+#if PMX_HYBRID_TAB_AUTO
+            s[0] = tab_dot<T, false>(s, sp, z0, f);
+            PMX_TRACK(0, s[0], f);
+            static_for<1, T>([&](auto i) {
+                PMX_SCHED_FENCE();
+                s[i] = tab_dot<1, true>(&z0, sp + tab_row_words(T) + (i - 1) * kTabOneWords, s[i], f);
+            });
+            PMX_SCHED_FENCE();
+#else
             s[0] = tab_dot_stream<T>(s, sp, f);
             PMX_TRACK(0, s[0], f);
             tab_lanes_stream<T - 1>(z0, sp + tab_row_words(T), &s[1], f);
+#endif
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else if (r < last_partial) {
             const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
