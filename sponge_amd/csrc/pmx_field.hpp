@@ -12,7 +12,11 @@
 //   * p < 2^255 leaves >= 6 spare bits: Montgomery outputs are < 1.3 p without any conditional
 //     subtraction, additions are plain limb-wise adds, and nothing is compared against p until the final
 //     conversion back to the ABI form;
-//   * multiplication and reduction are interleaved column by column (one live accumulator).
+//   * multiplication and reduction are interleaved column by column (one live accumulator), the chain of a
+//     column seeded with the carry of the previous one (the build disables LLVM's Reassociate pass, which would
+//     undo that - csrc/Makefile);
+//   * products by CONSTANTS (every multiplication of the permutation except the S-box) go through shifted
+//     tables - nine precomputed residues per constant, 81 + 18 multiplies instead of 81 + 81 (tab_dot below).
 //
 // ABI form (4 x u64 = 8 x u32 limbs, x * 2^256 mod p, fully reduced - ark-ff's Fp<MontBackend<_,4>,4>)
 // is converted on load (x2^256 -> x2^261: one Montgomery product with 2^266 mod p) and on store (one
@@ -25,11 +29,13 @@
 // Bounds (B = value / p; "norm" = every limb < 2^29, "lazy" = every limb < 2^30):
 //   redc output      norm, B < T / (p * 2^261) + 1            (T = the reduced integer)
 //   fe_add_lazy      inputs norm -> output lazy, B = Ba + Bb
-//   column sums      <= 27 products (one side lazy) + 9 reduction products + carry  < 2^64  (see field_check)
+//   column sums      <= 27 products (one side lazy) + 9 reduction products + carry  < 2^64;  table products: <= 6
+//                    normalised terms of 9 products + 2 reduction products + carry      (tests/test_hostcheck.py)
+//   tab_dot output   norm, B < 1 + 2^-20 (+ Bs with an addend)
 // p < 2^255  =>  p / 2^261 < 2^-6: with every operand B <= 4, T <= 3 * 16 p^2 gives outputs B < 1.75.
 //
 // The same source compiles for the host so the algorithms are unit-tested on CPU against the oracle
-// (tools/host_field_check.cpp); on the device `acc += (uint64_t)a * b` is exactly one v_mad_u64_u32.
+// (tests/hostcheck/); on the device `acc += (uint64_t)a * b` is exactly one v_mad_u64_u32.
 #pragma once
 #include <cstdint>
 #include <type_traits>

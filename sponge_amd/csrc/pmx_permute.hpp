@@ -1,5 +1,5 @@
 // The Poseidon permutation on the internal field form, shared by the device engines and the host-side
-// algorithm check (tools/host_field_check.cpp).
+// algorithm check (tests/hostcheck/pmx_hostcheck.cpp).
 //
 // Reference: PoseidonSponge::permute, src/poseidon/mod.rs:95-118 - every round is
 //   apply_ark (:76-80)  ->  apply_s_box (:63-74; partial rounds touch state[0] only)  ->  apply_mds (:82-93),
