@@ -116,6 +116,27 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
 // permutation at t = 3: 44,361 multiplies instead of 51,498.  The tables are 9x larger (54 KiB at t = 3) and stream
 // through the scalar cache, 81 SGPR operands per product.  Used by every t = 3 kernel for alpha = 5 and 17; what
 // makes that stream fit the 100-odd SGPRs of a wave is that FieldRt carries only p, -p^-1 and `unit` by value.
+// Scalar-cache warm-up for a table that is about to be streamed: one word of every 64-byte line is loaded (scalar
+// loads, no VALU work) and folded into a value the caller keeps alive, so the loads are real and are issued here -
+// a whole S-box ahead of the products that consume the table, which then find their lines in the scalar cache
+// instead of paying an L2 round trip per chunk with only two waves per SIMD to hide it.
+#ifndef PMX_HYBRID_TOUCH
+#define PMX_HYBRID_TOUCH 1   // +1..4 % at t = 4..9
+#endif
+#ifndef PMX_HYBRID_WIDE_ROW0_TAB
+#define PMX_HYBRID_WIDE_ROW0_TAB 0
+#endif
+template <int WORDS>
+PMX_FN uint32_t table_touch(const uint32_t *tab) {
+    uint32_t x = 0;
+#pragma unroll
+    for (int w = 0; w < WORDS; w += 16) x ^= tab[w];
+    return x;
+}
+
+#ifndef PMX_OPT_TAB_TOUCH
+#define PMX_OPT_TAB_TOUCH 0   // the same warm-up for t = 3: C2 -0.5 %, hash +0.8 % - four waves per SIMD already hide the misses
+#endif
 #ifndef PMX_OPT_TAB_STREAM
 #define PMX_OPT_TAB_STREAM 0   // 1: permute_opt_tab consumes its tables through the explicitly pipelined stream forms
 #endif
@@ -127,6 +148,7 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
 template <int T, int ALPHA>
 PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
+    uint32_t guard = 0;   // keeps table_touch's loads alive
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
         if (r < first_partial || r > last_partial) {
@@ -138,6 +160,10 @@ PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, co
             continue;
         }
         Fe z[T];
+        if constexpr (PMX_OPT_TAB_TOUCH) {
+            if (r < last_partial)
+                guard ^= table_touch<tab_row_words(T) + (T - 1) * kTabOneWords>(tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords));
+        }
         z[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         static_for<1, T>([&](auto i) { z[i] = s[i]; });
         if (r < last_partial) {
@@ -154,6 +180,7 @@ PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, co
             static_for<0, T>([&](auto i) { s[i] = PMX_OPT_TAB_ROW(z, tb.tab_bdense + (size_t)i * tab_row_words(T)); });
         }
     }
+    if (PMX_OPT_TAB_TOUCH && guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -221,6 +248,7 @@ template <int T, int ALPHA, class Scratch>
 PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
                            const FieldRt &f) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
+    uint32_t guard = 0;   // keeps table_touch's loads alive (see the end of the function)
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
         if (r < first_partial || r > last_partial) {            // full round
@@ -236,6 +264,13 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
         }
         // partial round: lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom); lane 0 is re-derived
         // every round
+        if constexpr (PMX_HYBRID_TOUCH) {
+            if (r < last_partial) {
+                const uint32_t *rt = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
+                if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB) guard ^= table_touch<tab_row_words(T)>(rt);
+                if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB) guard ^= table_touch<(T - 1) * kTabOneWords>(rt + tab_row_words(T));
+            }
+        }
         s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         if (r < last_partial && T <= PMX_HYBRID_TAB_MAX_T) {
             const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
@@ -258,7 +293,13 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
         } else if (r < last_partial) {
             const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
             const Fe z0 = s[0];
-            s[0] = matrix_row<T>(s, sp, f);
+            if constexpr (PMX_HYBRID_WIDE_ROW0_TAB) {
+                PMX_SCHED_FENCE();
+                s[0] = tab_dot<T, false>(s, tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords), z0, f);
+                PMX_SCHED_FENCE();
+            } else {
+                s[0] = matrix_row<T>(s, sp, f);
+            }
             PMX_TRACK(0, s[0], f);
             if constexpr (PMX_HYBRID_WIDE_LANES_TAB) {
                 // wide states: only the identity lanes take tables - that is where they pay (108 instead of 171 multiplies
@@ -279,6 +320,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                 matrix_rows_rolled<T>(s, sc, tb.bdense, f);         // last partial round: dense matrix B
         }
     }
+    if (PMX_HYBRID_TOUCH && guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1): the compiler cannot know
 }
 
 // ------------------------------------------------------------------------------------------------------------
