@@ -131,7 +131,7 @@ PMX_FN uint32_t table_touch(const uint32_t *tab) {
     uint32_t x = 0;
 #pragma unroll
     for (int w = 0; w < WORDS; w += 16) x ^= tab[w];
-    return x;
+    return x ^ tab[WORDS - 1];   // the table need not start on a line boundary: its last words may sit in one more line
 }
 
 #ifndef PMX_OPT_TAB_TOUCH
