@@ -740,7 +740,13 @@ PMX_HYB_DECL(hybridg_)
 // The shifted tables trade multiplies for a constant stream, and a stream needs a second wave on the SIMD to hide
 // behind: measured per launch at t = 3, the table form wins from 2^17 states up (permute; 2^18 for compress), below
 // that - fewer than two waves per SIMD - the element form is 7-25 % faster (lone-wave latency 0.145 vs 0.16 ms).
-static constexpr size_t kTabMinPermute = (size_t)1 << 17, kTabMinCompress = (size_t)1 << 18;
+#ifndef PMX_TAB_MIN_PERMUTE
+#define PMX_TAB_MIN_PERMUTE ((size_t)1 << 17)
+#endif
+#ifndef PMX_TAB_MIN_COMPRESS
+#define PMX_TAB_MIN_COMPRESS ((size_t)1 << 18)
+#endif
+static constexpr size_t kTabMinPermute = PMX_TAB_MIN_PERMUTE, kTabMinCompress = PMX_TAB_MIN_COMPRESS;
 
 // t = 3, alpha 5 / 17, fewer than `limit` units: the element-form engine
 #define PMX_SMALL_BATCH(LIMIT, CALL)                                                                 \
