@@ -35,4 +35,18 @@ extern "C" {
     pub fn pmx_merkle_2to1(ctx: *mut pmx_ctx, leaves: *const u64, n_leaves: usize, nodes: *mut u64, root: *mut u64) -> c_int;
     pub fn pmx_find_poseidon_ark_and_mds(modulus: *const u64, prime_bits: u64, rate: u32, full_rounds: u32,
                                          partial_rounds: u32, skip_matrices: u32, ark_out: *mut u64, mds_out: *mut u64) -> c_int;
+    // the rest of the header: not needed by the trait shim in mod.rs, declared so that the binding is complete
+    pub fn pmx_abi_version() -> c_int;
+    pub fn pmx_device_count() -> c_int;
+    pub fn pmx_ctx_width(ctx: *const pmx_ctx) -> c_int;
+    pub fn pmx_mont_constants(modulus: *const u64, inv: *mut u64, r: *mut u64, r2: *mut u64) -> c_int;
+    pub fn pmx_to_mont(modulus: *const u64, elems: *mut u64, n: usize) -> c_int;
+    pub fn pmx_from_mont(modulus: *const u64, elems: *mut u64, n: usize) -> c_int;
+    pub fn pmx_hash_batch_dev(ctx: *mut pmx_ctx, d_in: *const u64, in_len: usize, d_out: *mut u64, out_len: usize, n: usize,
+                              stream: *mut c_void) -> c_int;
+    pub fn pmx_sponge_absorb_batch_dev(ctx: *mut pmx_ctx, d_states: *mut u64, d_mode_tag: *mut u32, d_mode_index: *mut u32,
+                                       d_in: *const u64, in_len: usize, n: usize, stream: *mut c_void) -> c_int;
+    pub fn pmx_sponge_squeeze_batch_dev(ctx: *mut pmx_ctx, d_states: *mut u64, d_mode_tag: *mut u32, d_mode_index: *mut u32,
+                                        d_out: *mut u64, out_len: usize, n: usize, stream: *mut c_void) -> c_int;
+    pub fn pmx_merkle_2to1_dev(ctx: *mut pmx_ctx, d_nodes: *mut u64, n_leaves: usize, stream: *mut c_void) -> c_int;
 }
