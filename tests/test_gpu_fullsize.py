@@ -98,3 +98,40 @@ def test_wide_and_narrow_compression_kernels_agree_at_the_switch():
     nodes, root = cfg.context().merkle_2to1(leaves)
     want = c_oracle(name).merkle(leaves, threads=0)
     assert np.array_equal(nodes, want)
+
+
+@pytest.mark.parametrize("alpha,rf,rp", [(5, 8, 31), (17, 8, 31), (257, 8, 13)])
+def test_every_large_batch_kernel_of_t3_vs_c_oracle(alpha, rf, rp):
+    """t = 3 launches of 2^17 units and more run the shifted-table form of the kernels (pmx_device.hip: kTabMinPermute /
+    kTabMinCompress), smaller ones the element form; the small-batch tests therefore never reach the table kernels.
+    Here every entry point is driven at the switch-over size, for the two exponents with a dedicated chain and a
+    generic one, against the C port: permute, hash, mid-stream absorb + squeeze with mixed modes, and a Merkle tree
+    whose widest level (2^18 compressions) is a table launch."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    cfg = S.poseidon_config_from_lfsr(f, 2, alpha, rf, rp)
+    cr = cref.CRef(O.make_config(O.BLS12_381_FR, 255, 2, alpha, rf, rp))
+    ctx = cfg.context()
+    n = (1 << 17) + 77                                   # ragged on purpose
+    states = synth.random_elements(f, n * 3, seed=alpha).reshape(n, 3, 4)
+    assert np.array_equal(ctx.permute_batch(states), cr.permute_batch(states, threads=0))
+    msgs = synth.random_elements(f, n * 3, seed=alpha + 1).reshape(n, 3, 4)
+    assert np.array_equal(ctx.hash_batch(msgs, 3, 2), cr.hash_batch(msgs, 3, 2, threads=0))
+    # mid-stream driver: every sponge absorbs 3 elements, then squeezes 3; the first half starts mid-absorb
+    b = S.BatchPoseidonSponge.new(cfg, n)
+    b.state[:] = states
+    b.mode_index[: n // 2] = 1
+    b.mode_tag[n // 2:: 3] = 1                           # PMX_MODE_SQUEEZING (index 0)
+    st0, tag0, idx0 = b.state.copy(), b.mode_tag.copy(), b.mode_index.copy()
+    b.absorb(msgs)
+    got = b.squeeze_native_field_elements(3)
+    picks = np.concatenate([np.arange(0, 4096), np.arange(n // 2 - 2048, n // 2 + 2048), np.arange(n - 4096, n)])
+    for i in picks[:: 7]:
+        s, m, x = cr.sponge_absorb(st0[i], int(tag0[i]), int(idx0[i]), msgs[i])
+        s, m, x, out = cr.sponge_squeeze(s, m, x, 3)
+        assert np.array_equal(got[i], out) and np.array_equal(b.state[i], s) and (int(b.mode_tag[i]), int(b.mode_index[i])) == (m, x), i
+    leaves = synth.random_elements(f, 1 << 19, seed=alpha + 2)
+    nodes, root = ctx.merkle_2to1(leaves)
+    want = cr.merkle(leaves, threads=0)
+    assert np.array_equal(nodes, want) and np.array_equal(root, want[-1])
