@@ -3,18 +3,27 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one pass of the hot path (pmx_permute_batch_dev: PoseidonSponge::permute on every state,
-reference src/poseidon/mod.rs:95-118) over one device-resident batch of synthetic random states.
-Workload at N=1: BASELINE.json configs[1] -- 2^20 independent states, BLS12-381 Fr, t=3, alpha=5, 8+31
-rounds.  For N>1 (launched by torch.distributed.run, one rank per GPU) every rank permutes its own
-2^20-state shard (weak scaling, NO collective on the data path); after the K steps the result shards are
-all-gathered once over RCCL inside the timed region (the "final gather"; --gather overlap|serial gathers after
-every step instead).
+A "step" is one pass of the hot path (PoseidonSponge::permute on every state, reference
+src/poseidon/mod.rs:95-118) over one device-resident batch of synthetic random states.
+
+  N = 1   BASELINE.json configs[1] (C2): 2^20 independent states, BLS12-381 Fr, t=3, alpha=5, 8+31 rounds;
+          step = one pmx_permute_batch_dev launch.
+  N > 1   (launched by torch.distributed.run, one rank per GPU) BASELINE.json configs[3] (C4): 2^24 states in
+          all, sharded contiguously - 2^24 / N per GPU, strong scaling, NO collective on the data path; after the
+          K steps the result shards are all-gathered once over RCCL inside the timed region (the "final gather").
+          Every rank drives its shard through the C ABI's device group (pmx_mgpu_create_rank: ncclCommInitRank,
+          pmx_mgpu_permute_shards_dev, pmx_mgpu_all_gather_dev); torch.distributed only carries the communicator
+          id to the ranks and does the barrier / max-over-ranks of the timing contract.
+  --workload c5   BASELINE.json configs[4]: 2-to-1 Merkle tree of 2^24 leaves in all (2^24 / N per GPU; subtree per
+          rank, all-gather of the N 32-byte subtree roots, top log2 N levels on every rank).
+  --workload c3 / h3 / h9   wide states (BN254 Fr, t=9, 2^18 per GPU) and the absorb/squeeze hash driver.
 
 Rank 0 prints ONE JSON line.  `value` = permutations per second over all ranks, inputs already in HBM.
-`roofline` prices the permutation kernel against HBM (algorithmic 2*t*32 bytes per permutation);
-`cpu_baseline` times the C restatement of the reference algorithm (oracle/, kind "port") on the host
-cores for a bounded sample of the same workload (rank 0, N=1 only).
+`roofline` prices the dominant kernel against HBM (algorithmic 2*t*32 bytes per permutation); `int_valu` against
+the v_mad_u64_u32 issue rate measured on this device in this run (pmx_diag_int_valu_peak), which is what binds it;
+`cpu_baseline` times the C restatement of the reference algorithm (oracle/, kind "port") on the host cores for a
+bounded sample of the same workload (rank 0, N=1 only).  After the timed region one extra untimed pass over a fresh
+copy of the seeded batch is compared with the C restatement on a sample ("verified"); a mismatch exits non-zero.
 """
 import argparse
 import json
@@ -29,20 +38,19 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
-VALU_MAD_PEAK = 3.19e13       # v_mad_u64_u32 lane-instructions/s, measured (profiles/r01/valu_microbench.txt)
-
 WORKLOADS = {
-    # name: (field, rate, alpha, RF, RP, log2 units per GPU, seed, description)
-    "c2": ("bls12_381_fr", 2, 5, 8, 31, 20, 0x5EED0002, "bls12_381_fr t=3 alpha=5 RF=8 RP=31, 2^20 states/GPU"),
-    "c3": ("bn254_fr", 8, 5, 8, 57, 18, 0x5EED0003, "bn254_fr t=9 alpha=5 RF=8 RP=57, 2^18 states/GPU"),
-    # 2-to-1 Merkle compression: every rank reduces its own 2^21-leaf subtree level by level (2^21 - 1
-    # permutations), the subtree roots are all-gathered and the top log2(N) levels finished on every rank
-    "c5": ("bls12_381_fr", 2, 5, 8, 31, 21, 0x5EED0005, "bls12_381_fr t=3 alpha=5 2-to-1 Merkle tree, 2^21 leaves/GPU"),
+    # name: (field, rate, alpha, RF, RP, log2 units at N=1, log2 TOTAL units at N>1 (None: N=1 size per GPU), seed, description)
+    "c2": ("bls12_381_fr", 2, 5, 8, 31, 20, 24, 0x5EED0002, "bls12_381_fr t=3 alpha=5 RF=8 RP=31 permutation batch"),
+    "c3": ("bn254_fr", 8, 5, 8, 57, 18, None, 0x5EED0003, "bn254_fr t=9 alpha=5 RF=8 RP=57 permutation batch"),
+    "c5": ("bls12_381_fr", 2, 5, 8, 31, 24, 24, 0x5EED0005, "bls12_381_fr t=3 alpha=5 2-to-1 Merkle tree"),
     # the absorb/squeeze batch driver (pmx_hash_batch_dev): per row new; absorb(L); squeeze_native(1)
-    "h3": ("bls12_381_fr", 2, 5, 8, 31, 20, 0x5EED0006, "bls12_381_fr t=3 alpha=5 hash of 4 elements -> 1 (2 permutations/row), 2^20 rows/GPU"),
-    "h9": ("bn254_fr", 8, 5, 8, 57, 18, 0x5EED0007, "bn254_fr t=9 alpha=5 hash of 8 elements -> 1 (1 permutation/row), 2^18 rows/GPU"),
+    "h3": ("bls12_381_fr", 2, 5, 8, 31, 20, None, 0x5EED0006, "bls12_381_fr t=3 alpha=5 hash of 4 elements -> 1 (2 permutations/row)"),
+    "h9": ("bn254_fr", 8, 5, 8, 57, 18, None, 0x5EED0007, "bn254_fr t=9 alpha=5 hash of 8 elements -> 1 (1 permutation/row)"),
 }
 HASH_SHAPES = {"h3": (4, 1, 2), "h9": (8, 1, 1)}     # workload -> (in_len, out_len, permutations per row)
+BASELINE_CONFIG = {("c2", False): "BASELINE.json configs[1] (C2)", ("c2", True): "BASELINE.json configs[3] (C4)",
+                   ("c3", False): "BASELINE.json configs[2] (C3)", ("c5", False): "BASELINE.json configs[4] (C5) on one GPU",
+                   ("c5", True): "BASELINE.json configs[4] (C5)"}
 
 
 def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tables=False):
@@ -71,46 +79,72 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--states-per-gpu-log2", type=int, default=None)
-    ap.add_argument("--gather", default="final", choices=["final", "overlap", "serial", "none"],
-                    help="N>1: 'final' = one RCCL all-gather of the result shards after the K steps (inside the timed "
-                         "region); 'overlap'/'serial' = an all-gather after EVERY step (double-buffered / blocking)")
+    ap.add_argument("--total-log2", type=int, default=None, help="log2 of the units (states / leaves / rows) over ALL ranks")
+    ap.add_argument("--states-per-gpu-log2", type=int, default=None, help="log2 of the units PER rank (weak scaling)")
+    ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
+                    help="N>1 permutation batches: 'final' = one RCCL all-gather of the result shards after the K steps (inside "
+                         "the timed region); 'step' = an all-gather after EVERY step")
     ap.add_argument("--spinup-seconds", type=float, default=0.25, help="untimed device spin-up before the W warmup steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the all-cores cpu_baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(field_name, rate, alpha, rf, rp, seed, target_seconds):
-    """C restatement of the reference permutation (oracle/poseidon_ref.c) on all host cores."""
+# ----------------------------------------------------------------------------------------------------------------------
+# the checker (oracle/): cpu_baseline and the post-run verification - never inside the timed region
+# ----------------------------------------------------------------------------------------------------------------------
+def oracle_engine(field_name, rate, alpha, rf, rp):
     from oracle import cref
     from oracle import poseidon_oracle as O
+    p, bits = {"bls12_381_fr": (O.BLS12_381_FR, 255), "bn254_fr": (O.BN254_FR, 254)}[field_name]
+    return cref.CRef(O.make_config(p, bits, rate, alpha, rf, rp))
+
+
+def cpu_baseline(field_name, rate, alpha, rf, rp, seed, target_seconds):
+    """C restatement of the reference permutation (oracle/poseidon_ref.c): on all host cores, and on ONE thread - the
+    reference itself is single-threaded (src/poseidon/mod.rs:95-118)."""
+    from oracle import cref
     import sponge_amd as S
     from sponge_amd import synth
 
-    p, bits = {"bls12_381_fr": (O.BLS12_381_FR, 255), "bn254_fr": (O.BN254_FR, 254)}[field_name]
-    ocfg = O.make_config(p, bits, rate, alpha, rf, rp)
-    cr = cref.CRef(ocfg)
+    cr = oracle_engine(field_name, rate, alpha, rf, rp)
     t = rate + 1
     threads = cref.max_threads()      # affinity mask capped by the cgroup CPU quota
     field = S.FIELDS[field_name]
-    probe = synth.random_elements(field, 4096 * t, seed).reshape(4096, t, 4)
-    t0 = time.perf_counter()
-    cr.permute_batch(probe, threads=threads)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    n = int(min(1 << 22, max(4096, 4096 * target_seconds / dt)))
-    n = 1 << (n.bit_length() - 1)
-    batch = synth.random_elements(field, n * t, seed).reshape(n, t, 4)
-    t0 = time.perf_counter()
-    cr.permute_batch(batch, threads=threads)
-    dt = time.perf_counter() - t0
+
+    def timed(n_threads, seconds):
+        probe = synth.random_elements(field, 1024 * t, seed).reshape(1024, t, 4)
+        t0 = time.perf_counter()
+        cr.permute_batch(probe, threads=n_threads)
+        dt = max(time.perf_counter() - t0, 1e-6)
+        n = int(min(1 << 22, max(1024, 1024 * seconds / dt)))
+        n = 1 << (n.bit_length() - 1)
+        batch = synth.random_elements(field, n * t, seed).reshape(n, t, 4)
+        t0 = time.perf_counter()
+        cr.permute_batch(batch, threads=n_threads)
+        return n, time.perf_counter() - t0
+
+    n, dt = timed(threads, target_seconds)
+    n1, dt1 = timed(1, min(6.0, target_seconds / 2))
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
+    what = "C restatement of mod.rs:63-118 (dense MDS, square-and-multiply pow)"
     return {"value": n / dt, "unit": "permutations/s", "cores": threads, "kind": "port",
-            "sample": f"first {n} states of the same seeded batch, C restatement of mod.rs:63-118 "
-                      f"(dense MDS, square-and-multiply pow), OpenMP x{threads}, {dt:.2f} s, CPU: {model}"}
+            "sample": f"first {n} states of the same seeded batch, {what}, OpenMP x{threads}, {dt:.2f} s, CPU: {model}",
+            "single_thread": {"value": n1 / dt1, "unit": "permutations/s", "cores": 1, "kind": "port",
+                              "sample": f"first {n1} states of the same seeded batch, {what}, 1 thread (the reference's own "
+                                        f"threading), {dt1:.2f} s"}}
+
+
+def sample_indices(n, k):
+    """k indices spread over [0, n): both ends and a stride in between."""
+    if n <= k:
+        return np.arange(n)
+    return np.unique(np.concatenate([np.arange(0, min(n, k // 4)), np.arange(n - k // 4, n),
+                                     np.linspace(0, n - 1, k // 2).astype(np.int64)]))
 
 
 def main():
@@ -130,103 +164,130 @@ def main():
 
     import torch.distributed as dist
     import sponge_amd as S
-    from sponge_amd import synth
+    from sponge_amd import _lib, mgpu, synth
 
-    # PMX_BENCH_BACKEND=gloo is a single-GPU rehearsal of the N > 1 code path (tools/gpu_n2_rehearsal.sh): the ranks
-    # share the visible GPUs round-robin and the gathers are staged through the host.  Its numbers mean nothing.
-    backend = os.environ.get("PMX_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    field_name, rate, alpha, rf, rp, log2n, seed, desc = WORKLOADS[args.workload]
-    if args.states_per_gpu_log2 is not None:
-        log2n = args.states_per_gpu_log2
-    n = 1 << log2n
+    field_name, rate, alpha, rf, rp, log2_one, log2_total_multi, seed, desc = WORKLOADS[args.workload]
     t = rate + 1
-    field = S.FIELDS[field_name]
-    cfg = S.poseidon_config_from_lfsr(field, rate, alpha, rf, rp)
-    ctx = cfg.context(local_rank)
-
-    from sponge_amd import distributed as D
-
-    stream = torch.cuda.current_stream()
     merkle = args.workload == "c5"
     hashing = args.workload in HASH_SHAPES
+    # ---- sizes: the BASELINE configuration of this (workload, N), unless overridden -----------------------------------
+    if args.total_log2 is not None:
+        n_total, scaling, baseline_cfg = 1 << args.total_log2, "strong", None
+    elif args.states_per_gpu_log2 is not None:
+        n_total, scaling, baseline_cfg = world << args.states_per_gpu_log2, "weak", None
+    elif world > 1 and log2_total_multi is not None:
+        n_total, scaling = 1 << log2_total_multi, "strong"
+        baseline_cfg = BASELINE_CONFIG.get((args.workload, True))
+    else:
+        n_total, scaling = world << log2_one, ("strong" if world == 1 else "weak")
+        baseline_cfg = BASELINE_CONFIG.get((args.workload, False)) if world == 1 else None
+    start, n = mgpu.shard_bounds(n_total, world, rank)       # this rank's contiguous shard
+    if merkle and (n_total % world or n & (n - 1) or world & (world - 1)):
+        raise SystemExit("the Merkle workload needs power-of-two leaves and ranks")
+    field = S.FIELDS[field_name]
+    cfg = S.poseidon_config_from_lfsr(field, rate, alpha, rf, rp)
+
+    # ---- per-run integer-VALU roofline of THIS device, before anything is timed -----------------------------------------
+    peak = _lib.PmxValuPeak()
+    _lib.check(_lib.lib().pmx_diag_int_valu_peak(local_rank, 0.05, peak))
+
+    # ---- the engine: one context at N = 1, the C ABI's device group (RCCL) at N > 1 -------------------------------------
+    group, group_error, rccl = None, None, None
+    if world > 1:
+        uid = [mgpu.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0, device=dev)
+        try:
+            group = mgpu.DeviceGroup.one_rank(cfg, local_rank, rank, world, uid[0])
+            info = group.info()
+            rccl = {"ranks": info["comm_ranks"], "version": info["rccl_version_str"], "rank0_is": info["comm_first_rank"],
+                    "via": "pmx_mgpu_create_rank (ncclCommInitRank); gather = pmx_mgpu_all_gather_dev (ncclAllGather)"}
+        except S.PmxError as e:          # still RCCL on the GPUs, through torch.distributed, and said so in the line
+            group_error = str(e)
+            rccl = {"ranks": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                    "via": "torch.distributed (the C ABI's device group failed: %s)" % group_error}
+        ok = torch.tensor([1 if group is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok) == 0 and group is not None:      # all ranks take the same path
+            group.close()
+            group = None
+    ctx = cfg.context(local_rank)
+    if group is not None:
+        stream = torch.cuda.ExternalStream(group.stream(0), device=dev)     # the library's stream of this device
+    else:
+        stream = torch.cuda.current_stream()
+
+    def torch_all_gather(local, out):
+        dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
+
+    def fresh_inputs():
+        """this rank's shard of the global seeded input, uploaded (used for the timed buffers and again for the check)"""
+        if hashing:
+            host = synth.random_elements(field, n * in_len, seed, offset=start * in_len)
+        elif merkle:
+            host = synth.random_elements(field, n, seed, offset=start)
+        else:
+            host = synth.random_elements(field, n * t, seed, offset=start * t)
+        return host, torch.from_numpy(host.view(np.int64).copy()).to(dev)
+
     if hashing:
         in_len, out_len, perms_per_row = HASH_SHAPES[args.workload]
-        host = synth.random_elements(field, n * in_len, seed, offset=rank * n * in_len)
-        d_in = torch.from_numpy(host.view(np.int64).copy()).to(dev)
+        host_in, d_in = fresh_inputs()
         d_out = torch.zeros((n, out_len, 4), dtype=torch.int64, device=dev)
-        units_per_step = float(world) * n * perms_per_row
+        units_per_step = float(n_total) * perms_per_row
 
         def step(i):
             ctx.hash_batch_dev(d_in.data_ptr(), in_len, d_out.data_ptr(), out_len, n, stream.cuda_stream)
-
-        def drain():
-            pass
 
         def final_gather():
             pass
     elif merkle:
         # leaves of this rank's subtree, resident in the first n rows of the node array [2n-1][4]
-        host = synth.random_elements(field, n, seed, offset=rank * n)
+        host_in, d_leaves = fresh_inputs()
         nodes = torch.zeros((2 * n - 1, 4), dtype=torch.int64, device=dev)
-        nodes[:n] = torch.from_numpy(host.view(np.int64).copy()).to(dev)
-        top = torch.zeros((2 * world - 1, 4), dtype=torch.int64, device=dev)
-        units_per_step = float(world) * (n - 1) + (world - 1)          # permutations per step, all ranks
+        nodes[:n] = d_leaves.reshape(n, 4)
+        top = torch.zeros((max(2 * world - 1, 1), 4), dtype=torch.int64, device=dev)
+        units_per_step = float(n_total - 1)                             # compressions per step, all ranks
 
         def step(i):
-            ctx.merkle_2to1_dev(nodes.data_ptr(), n, stream.cuda_stream)
-            if world > 1:
-                top[:world] = D.all_gather_equal(nodes[2 * n - 2:2 * n - 1])   # 32-byte subtree roots
-                ctx.merkle_2to1_dev(top.data_ptr(), world, stream.cuda_stream)
-
-        def drain():
-            pass
+            if group is not None:
+                group.merkle_2to1_dev([nodes.data_ptr()], [top.data_ptr()], n_total)
+            else:
+                ctx.merkle_2to1_dev(nodes.data_ptr(), n, stream.cuda_stream)
+                if world > 1:
+                    torch_all_gather(nodes[2 * n - 2:2 * n - 1], top[:world])          # 32-byte subtree roots
+                    ctx.merkle_2to1_dev(top.data_ptr(), world, stream.cuda_stream)
 
         def final_gather():
             pass
     else:
-        # this rank's shard of the global seeded batch [world*n][t][4]
-        host = synth.random_elements(field, n * t, seed, offset=rank * n * t)
-        per_step = world > 1 and args.gather in ("overlap", "serial")
-        n_buf = 2 if (world > 1 and args.gather == "overlap") else 1
-        bufs = [torch.from_numpy(host.view(np.int64).copy()).to(dev).reshape(n, t, 4) for _ in range(n_buf)]
-        gathered = [torch.empty((world * n, t, 4), dtype=torch.int64, device=dev) for _ in range(n_buf)] \
-            if (world > 1 and args.gather != "none") else None
-        pending = [None] * n_buf
-        units_per_step = float(world) * n
+        host_in, buf = fresh_inputs()
+        buf = buf.reshape(n, t, 4)
+        gathered = torch.empty((n_total, t, 4), dtype=torch.int64, device=dev) if (world > 1 and args.gather != "none") else None
+        units_per_step = float(n_total)
+
+        def gather_now(src):
+            if group is not None:
+                group.all_gather_dev([src.data_ptr()], [gathered.data_ptr()], n_total, t)
+            else:
+                torch_all_gather(src, gathered)
 
         def step(i):
-            b = i % n_buf
-            if pending[b] is not None:           # the gather that still reads this buffer
-                pending[b].wait()
-                pending[b] = None
-            ctx.permute_batch_dev(bufs[b].data_ptr(), n, stream.cuda_stream)   # no collective on the data path
-            if per_step:
-                _, work = D.all_gather_equal(bufs[b], out=gathered[b], async_op=True)
-                if args.gather == "serial":
-                    work.wait()
-                else:
-                    pending[b] = work
-
-        def drain():
-            for b in range(n_buf):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
+            if group is not None:
+                group.permute_shards_dev([buf.data_ptr()], n_total)        # no collective on the data path
+            else:
+                ctx.permute_batch_dev(buf.data_ptr(), n, stream.cuda_stream)
+            if world > 1 and args.gather == "step":
+                gather_now(buf)
 
         def final_gather():                      # the job's epilogue: every rank ends with the whole result
             if world > 1 and args.gather == "final":
-                D.all_gather_equal(bufs[0], out=gathered[0])
+                gather_now(buf)
 
     def barrier():
         torch.cuda.synchronize()
@@ -234,23 +295,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()
     # Device spin-up (untimed, not counted as steps): the shader clock ramps over the first ~25 ms of activity
-    # (per-launch time falls from 2.5 ms to 2.07 ms across the first dozen launches, profiles/r01), so the W warmup
-    # steps alone would leave short runs measuring the ramp instead of the kernel.
-    t_spin = time.perf_counter()
-    i_spin = 0
-    # a step that contains a collective must run the same number of times on every rank: fixed count instead of a clock
-    collective_in_step = world > 1 and (merkle or args.gather in ("overlap", "serial"))
-    while (i_spin < 64) if collective_in_step else (time.perf_counter() - t_spin < args.spinup_seconds):
+    # (per-launch time falls from 2.5 ms to the steady value across the first dozen launches), so the W warmup steps alone
+    # would leave short runs measuring the ramp instead of the kernel.  A step that contains a collective must run the
+    # same number of times on every rank: fixed count instead of a clock.
+    collective_in_step = world > 1 and (merkle or args.gather == "step")
+    t_spin, i_spin = time.perf_counter(), 0
+    while (i_spin < 32) if collective_in_step else (time.perf_counter() - t_spin < args.spinup_seconds):
         step(i_spin)
         i_spin += 1
         if i_spin % 4 == 0:
-            drain()
             torch.cuda.synchronize()
-    drain()
     for i in range(args.warmup):
         step(i)
-    drain()
     final_gather()      # also warms RCCL's lazily built rings up, outside the timed region
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -258,23 +316,34 @@ def main():
     ev0.record(stream)
     for i in range(args.steps):
         step(i)
-    drain()
+    ev_k = torch.cuda.Event(enable_timing=True)
+    ev_k.record(stream)
     final_gather()
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
+    steps_ms = ev0.elapsed_time(ev_k)       # ... the K steps without the epilogue gather
 
-    times = torch.tensor([elapsed, dev_ms / 1e3], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    times = torch.tensor([elapsed, dev_ms / 1e3, steps_ms / 1e3], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    elapsed, dev_s = float(times[0]), float(times[1])
+    elapsed, dev_s, steps_s = float(times[0]), float(times[1]), float(times[2])
+
+    # ---- verification (untimed): one pass over a FRESH copy of the seeded inputs, sample against the C restatement ------
+    verify = None
+    if not args.no_verify:
+        verify = run_verification(locals())
+        flag = torch.tensor([1 if verify["ok"] else 0], device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verify["ok"] = bool(int(flag))
 
     if rank == 0:
         value = units_per_step * args.steps / elapsed
-        # dominant kernel: permute_kernel (hash_kernel in the Merkle mode); its average launch duration from the
-        # HIP events on this rank's launch stream (at N=1 the timed region holds nothing but the back-to-back launches)
-        kernel_s = dev_s / args.steps
+        # dominant kernel: permute_kernel (compress kernels in the Merkle mode); its average launch duration from the HIP
+        # events on this rank's launch stream around the K steps (back-to-back launches, nothing else on the stream)
+        kernel_s = steps_s / args.steps
         per_gpu_units = units_per_step / world
         bytes_per_unit = 96 if merkle else 2 * t * 32       # 2*t*32 B per permutation; 64 in + 32 out per 2-to-1
         if hashing:
@@ -286,25 +355,36 @@ def main():
         mads = mads_per_permutation(t, alpha, rf, rp, optimised=3 <= t <= 9, row_tables=3 <= t <= 5, lane_tables=3 <= t <= 9) \
             + (3 if merkle else 2 * t) * 162   # + ABI conversions
         mad_rate = mads * per_gpu_units / kernel_s
+        traffic, traffic_src = load_traffic(args.workload, per_gpu_units)
         out = {
             "metric": "Poseidon permutations/sec (%s, t=%d)" % ({"bls12_381_fr": "BLS12-381 Fr", "bn254_fr": "BN254 Fr"}[field_name], t),
             "value": value, "unit": "permutations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": desc, "arithmetic": "255-bit modular integers as 9 x 29-bit limbs in u32, Montgomery form",
-                       "units_per_gpu": n, "permutations_per_step": units_per_step,
-                       "gather": (args.gather if (world > 1 and not merkle) else ("roots" if merkle and world > 1 else "n/a")),
+            "config": {"workload": f"{desc}, {fmt_pow2(n_total)} units in all = {fmt_pow2(n)} per GPU x {world}",
+                       "baseline_config": baseline_cfg,
+                       "arithmetic": "255-bit modular integers as 9 x 29-bit limbs in u32, Montgomery form",
+                       "units_total": n_total, "units_per_gpu": n, "permutations_per_step": units_per_step,
+                       "gather": (args.gather if (world > 1 and not merkle and not hashing) else ("roots" if merkle and world > 1 else "n/a")),
                        "sharding": f"contiguous x{world}",
-                       **({"rehearsal_backend": backend} if backend != "nccl" else {})},
+                       "series": "N=1 runs configs[1] (2^20 states); N>1 shard configs[3]'s 2^24 states (strong scaling)"
+                                 if args.workload == "c2" and baseline_cfg else None},
+            "rccl": rccl,
+            "verified": (verify["ok"] if verify else None), "verify": verify,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "pmx::compress_kernel / compress_coop_kernel (per tree level)" if merkle else
                                    ("pmx::hash_kernel" if hashing else "pmx::permute_kernel"),
                          "kernel_ms": 1e3 * kernel_s, "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer-VALU bound, not HBM bound (DESIGN.md): see int_valu"},
-            "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": VALU_MAD_PEAK,
-                         "unit": "lane-instr/s", "frac": mad_rate / VALU_MAD_PEAK, "mads_per_permutation": mads},
+            "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": peak.lane_mads_per_s,
+                         "unit": "lane-instr/s", "frac": mad_rate / peak.lane_mads_per_s, "mads_per_permutation": mads,
+                         "peak_source": "pmx_diag_int_valu_peak on this device just before the warm-up (%d launches, median of the later half)" % peak.launches,
+                         "peak_best_launch": peak.best_lane_mads_per_s, "shader_clock_hz": peak.shader_clock_hz,
+                         "theoretical_peak": peak.theoretical_lane_mads_per_s, "compute_units": peak.compute_units,
+                         "frac_of_theoretical": mad_rate / peak.theoretical_lane_mads_per_s if peak.theoretical_lane_mads_per_s else None},
+            "gather_ms": 1e3 * (dev_s - steps_s) if world > 1 else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(field_name, rate, alpha, rf, rp, seed, args.cpu_seconds)
@@ -314,16 +394,121 @@ def main():
 
     if world > 1:
         dist.barrier()
+        if group is not None:
+            group.close()
         dist.destroy_process_group()
+    if verify is not None and not verify["ok"]:
+        sys.exit(3)
 
 
-def load_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
+def fmt_pow2(n):
+    return f"2^{n.bit_length() - 1}" if n and n & (n - 1) == 0 else str(n)
+
+
+def run_verification(env):
+    """One untimed pass of the same step functions' engine over a fresh copy of the seeded inputs; a sample of the
+    results against the C restatement (oracle/), per rank.  At N > 1 the permutation workloads check the GATHERED buffer:
+    rank r's shard must sit at offset r's span, whoever did the gather."""
+    import torch
+    from sponge_amd import mgpu, synth
+    import sponge_amd as S
+    args, world, rank, dev = env["args"], env["world"], env["rank"], env["dev"]
+    ctx, group, stream = env["ctx"], env["group"], env["stream"]
+    field, field_name, t = env["field"], env["field_name"], env["t"]
+    rate, alpha, rf, rp, seed = env["rate"], env["alpha"], env["rf"], env["rp"], env["seed"]
+    n, n_total, start = env["n"], env["n_total"], env["start"]
+    cr = oracle_engine(field_name, rate, alpha, rf, rp)
+    res = {"ok": True, "engine": "oracle/poseidon_ref.c (C restatement)", "what": None}
+
+    def to_np(x):
+        return x.cpu().numpy().view(np.uint64)
+
+    if env["hashing"]:
+        in_len, out_len = env["in_len"], env["out_len"]
+        host, d_in = env["fresh_inputs"]()
+        d_out = torch.zeros((n, out_len, 4), dtype=torch.int64, device=dev)
+        ctx.hash_batch_dev(d_in.data_ptr(), in_len, d_out.data_ptr(), out_len, n, stream.cuda_stream)
+        torch.cuda.synchronize()
+        idx = sample_indices(n, 2048)
+        want = cr.hash_batch(np.ascontiguousarray(host.reshape(n, in_len, 4)[idx]), in_len, out_len, threads=0)
+        res["ok"] = bool(np.array_equal(to_np(d_out).reshape(n, out_len, 4)[idx], want))
+        res["what"] = f"{len(idx)} of this rank's {n} rows of one fresh launch"
+    elif env["merkle"]:
+        host, d_leaves = env["fresh_inputs"]()
+        nodes = torch.zeros((2 * n - 1, 4), dtype=torch.int64, device=dev)
+        nodes[:n] = d_leaves.reshape(n, 4)
+        top = torch.zeros((max(2 * world - 1, 1), 4), dtype=torch.int64, device=dev)
+        if group is not None:
+            group.merkle_2to1_dev([nodes.data_ptr()], [top.data_ptr()], n_total)
+        else:
+            ctx.merkle_2to1_dev(nodes.data_ptr(), n, stream.cuda_stream)
+            if world > 1:
+                env["torch_all_gather"](nodes[2 * n - 2:2 * n - 1], top[:world])
+                ctx.merkle_2to1_dev(top.data_ptr(), world, stream.cuda_stream)
+        torch.cuda.synchronize()
+        got = to_np(nodes)
+        ok = True
+        # level 1 on a sample of pairs
+        if n >= 2:
+            idx = sample_indices(n // 2, 2048)
+            pairs = np.ascontiguousarray(host.reshape(n // 2, 2, 4)[idx])
+            ok &= bool(np.array_equal(got[n + idx], cr.hash_batch(pairs, 2, 1, threads=0).reshape(-1, 4)))
+        # the top of this rank's subtree, rebuilt by the checker from the GPU's own level of <= 1024 nodes
+        w = min(n, 1024)
+        first = 2 * n - 2 * w                                 # offset of the level that has w nodes
+        sub = cr.merkle(np.ascontiguousarray(got[first:first + w]), threads=0)
+        ok &= bool(np.array_equal(sub[w:], got[first + w:]))
+        if world > 1:
+            gtop = to_np(top)
+            ok &= bool(np.array_equal(gtop[rank], got[-1]))                       # my root at my rank's slot
+            ok &= bool(np.array_equal(cr.merkle(np.ascontiguousarray(gtop[:world]), threads=0), gtop))   # the top log2 N levels
+        res["ok"] = ok
+        res["what"] = (f"a fresh tree: level 1 on a sample, the top {w.bit_length() - 1} levels of this rank's subtree"
+                       + (f", the {world} gathered roots and the levels above them" if world > 1 else ""))
+    else:
+        host, fresh = env["fresh_inputs"]()
+        fresh = fresh.reshape(n, t, 4)
+        if group is not None:
+            group.permute_shards_dev([fresh.data_ptr()], n_total)
+        else:
+            ctx.permute_batch_dev(fresh.data_ptr(), n, stream.cuda_stream)
+        gathered = env.get("gathered")
+        if world > 1 and gathered is not None:
+            gathered.zero_()
+            if group is not None:
+                group.all_gather_dev([fresh.data_ptr()], [gathered.data_ptr()], n_total, t)
+            else:
+                env["torch_all_gather"](fresh, gathered)
+            torch.cuda.synchronize()
+            ok, checked = True, 0
+            for r in range(world):               # every rank checks every shard of ITS copy of the gathered result
+                s_r, c_r = mgpu.shard_bounds(n_total, world, r)
+                idx = s_r + sample_indices(c_r, 256)
+                inp = np.stack([synth.random_elements(field, t, seed, offset=int(i) * t) for i in idx])
+                ok &= bool(np.array_equal(to_np(gathered[torch.from_numpy(idx).to(dev)]), cr.permute_batch(inp, threads=0)))
+                checked += len(idx)
+            res["ok"] = ok
+            res["what"] = f"gathered buffer of one fresh pass: {checked} states, a sample of every rank's span at its offset"
+        else:
+            torch.cuda.synchronize()
+            idx = sample_indices(n, 4096)
+            want = cr.permute_batch(np.ascontiguousarray(host.reshape(n, t, 4)[idx]), threads=0)
+            res["ok"] = bool(np.array_equal(to_np(fresh)[idx], want))
+            res["what"] = f"{len(idx)} of this rank's {n} states of one fresh launch"
+    return res
+
+
+def load_traffic(workload, per_gpu_units):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json); it
+    cannot be collected inside a timed run.  Only quoted when the profile was taken at this run's size."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
-        return json.load(open(path))[workload]["bytes_per_launch"]
+        rec = json.load(open(path))[workload]
+        if "units_per_launch" in rec and abs(rec["units_per_launch"] - per_gpu_units) > 1:
+            return None, None
+        return rec["bytes_per_launch"], "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
     except Exception:
-        return None
+        return None, None
 
 
 if __name__ == "__main__":

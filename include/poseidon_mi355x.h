@@ -19,7 +19,10 @@
  * src/poseidon/mod.rs:196-203).  There is NO CPU fallback: without a usable HIP device every data-path
  * call fails with PMX_ERR_HIP.
  *
- * Threading: a pmx_ctx is single-caller; distinct contexts are independent.
+ * Threading: the host-buffer entry points of one pmx_ctx serialise on a lock inside the context (they share its
+ * staging buffers and streams); the *_dev entry points only enqueue on the caller's stream and may be called
+ * concurrently.  Distinct contexts are independent.  Every call runs with its context's device current and restores
+ * the calling thread's current HIP device before it returns; a `stream` argument must belong to the context's device.
  */
 #ifndef POSEIDON_MI355X_H
 #define POSEIDON_MI355X_H
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 1
+#define PMX_ABI_VERSION 2
 #define PMX_LIMBS 4        /* uint64_t limbs per field element */
 #define PMX_MAX_WIDTH 16   /* largest rate+capacity accepted (reference default table uses 3..9) */
 
@@ -40,7 +43,8 @@ typedef enum pmx_status {
     PMX_ERR_CONFIG = -1,      /* violates the asserts of PoseidonConfig::new (src/poseidon/mod.rs:196-203) or a limit of this build */
     PMX_ERR_ARG = -2,         /* null pointer / bad size / bad mode word */
     PMX_ERR_HIP = -3,         /* HIP runtime failure or no device */
-    PMX_ERR_UNSUPPORTED = -4  /* width without a compiled kernel */
+    PMX_ERR_UNSUPPORTED = -4, /* width without a compiled kernel */
+    PMX_ERR_RCCL = -5         /* RCCL failure in a device group (pmx_mgpu_*) */
 } pmx_status;
 
 /* DuplexSpongeMode (src/lib.rs:198-210) as two words per sponge: tag + index. */
@@ -98,6 +102,13 @@ int pmx_from_mont(const uint64_t modulus[PMX_LIMBS], uint64_t *elems, size_t n);
  * uploaded to `device`.  */
 int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out);
 int pmx_ctx_destroy(pmx_ctx *ctx);
+/* The same context from a process-wide cache keyed by (config contents, device), reference-counted: what a binding's
+ * CryptographicSponge::new should call, so that a sponge per transcript (the reference's usage, mod.rs:219-230 clones
+ * ~4 KB of parameters per sponge) costs a hash of the constants, not a table derivation + upload.  Contexts whose
+ * count drops to zero stay resident (a few, oldest evicted first); pmx_ctx_cache_clear frees the idle ones. */
+int pmx_ctx_acquire(const pmx_config *cfg, int device, pmx_ctx **out);
+int pmx_ctx_release(pmx_ctx *ctx);
+int pmx_ctx_cache_clear(void);
 /* width t = rate + capacity of the context's config */
 int pmx_ctx_width(const pmx_ctx *ctx);
 
@@ -139,6 +150,81 @@ int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_m
 int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint64_t *nodes, uint64_t *root);
 /* Device variant: d_nodes [2*n_leaves-1][4] must already hold the leaves in its first n_leaves rows. */
 int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_leaves, void *stream);
+
+/* ---- device groups: the batch sharded over the GPUs of one node -------------------------------------
+ * The reference is single-threaded and has no distributed code; nothing in src/poseidon/mod.rs:62-183 couples one
+ * sponge state to another, so n states are cut into `world` contiguous shards (pmx_shard_bounds), one per GPU, and
+ * the permutation itself needs NO collective.  RCCL over xGMI is used for the final gather of the result shards
+ * (ncclAllGather; a group of ncclBroadcasts when n is not a multiple of world) and for the 32-byte subtree roots of
+ * the sharded Merkle reduction.
+ *
+ * A group is either all GPUs of ONE process (pmx_mgpu_create = ncclCommInitAll; this is what a Rust caller uses:
+ * BatchPoseidon::new_multi in INTEGRATION.md) or ONE rank of a multi-process job (pmx_mgpu_create_rank =
+ * ncclCommInitRank; rank 0 makes the id with pmx_mgpu_unique_id and the launcher carries it to the other ranks).
+ * A group holds `n_local` devices with consecutive ranks first_rank .. first_rank + n_local - 1 of `world`.
+ * Arrays indexed [local] below have n_local entries.  The *_dev calls enqueue on the group's own per-device
+ * streams (pmx_mgpu_stream) and return; pmx_mgpu_synchronize waits for all of them. */
+#define PMX_UNIQUE_ID_BYTES 128
+#define PMX_MAX_LOCAL_DEVICES 16
+typedef struct pmx_mgpu pmx_mgpu;
+typedef struct pmx_mgpu_info {
+    int world;            /* ranks the group was created for */
+    int n_local;          /* devices driven by this process */
+    int first_rank;       /* rank of local device 0 */
+    int width;            /* t = rate + capacity */
+    int rccl_version;     /* ncclGetVersion, e.g. 22707 */
+    int comm_ranks;       /* ncclCommCount of the LIVE communicator: proof that RCCL joined `world` ranks */
+    int comm_first_rank;  /* ncclCommUserRank of local device 0 */
+    int devices[PMX_MAX_LOCAL_DEVICES]; /* HIP device of each local slot */
+} pmx_mgpu_info;
+
+/* rank `rank` of `world` owns units [start, start + count) of n: contiguous, the first n % world shards one longer.
+ * Pure host arithmetic (no device needed). */
+int pmx_shard_bounds(size_t n, int world, int rank, size_t *start, size_t *count);
+int pmx_mgpu_unique_id(uint8_t id[PMX_UNIQUE_ID_BYTES]);
+/* devices: n_devices HIP device ordinals, or NULL for 0 .. n_devices-1 */
+int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *devices, pmx_mgpu **out);
+int pmx_mgpu_create_rank(const pmx_config *cfg, int device, int rank, int world, const uint8_t id[PMX_UNIQUE_ID_BYTES],
+                         pmx_mgpu **out);
+int pmx_mgpu_destroy(pmx_mgpu *g);
+int pmx_mgpu_get_info(const pmx_mgpu *g, pmx_mgpu_info *info);
+void *pmx_mgpu_stream(const pmx_mgpu *g, int local);     /* hipStream_t of local device `local` (NULL if out of range) */
+pmx_ctx *pmx_mgpu_ctx(const pmx_mgpu *g, int local);     /* its context (owned by the group) */
+int pmx_mgpu_synchronize(pmx_mgpu *g);
+
+/* PoseidonSponge::permute (src/poseidon/mod.rs:95-118) on n states in host memory, in place, sharded over the
+ * group's devices (single-process groups): every device pipelines its own shard over PCIe, all devices at once. */
+int pmx_mgpu_permute_batch(pmx_mgpu *g, uint64_t *states, size_t n);
+/* The same on device-resident shards: d_shards[local] = [count][t][4] on that device, count from
+ * pmx_shard_bounds(n_total, world, first_rank + local).  Only enqueues. */
+int pmx_mgpu_permute_shards_dev(pmx_mgpu *g, uint64_t *const *d_shards, size_t n_total);
+/* The final gather: d_all[local] = [n_total][row_elems][4] on every device receives all shards in rank order
+ * (row_elems = t for states, 1 for digests).  RCCL; only enqueues. */
+int pmx_mgpu_all_gather_dev(pmx_mgpu *g, const uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total,
+                            size_t row_elems);
+/* 2-to-1 Merkle tree of n_leaves = world * m leaves (both powers of two): d_nodes[local] = [2m-1][4] holds that rank's
+ * m leaves in its first m rows and receives its subtree (pmx_merkle_2to1_dev); the `world` subtree roots are
+ * all-gathered into d_top[local] = [2*world-1][4], which then receives the top levels, root last (world = 1: [1][4]).
+ * Only enqueues. */
+int pmx_mgpu_merkle_2to1_dev(pmx_mgpu *g, uint64_t *const *d_nodes, uint64_t *const *d_top, size_t n_leaves);
+/* Host leaves [n_leaves][4] -> root [4] (single-process groups). */
+int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t n_leaves, uint64_t *root);
+
+/* ---- diagnostics ---------------------------------------------------------------------------------------
+ * The binding roofline of these kernels is the issue rate of v_mad_u64_u32 (one per 32x32-bit limb product), not
+ * HBM.  It depends on the clock the chip holds under load, so it is measured, per device and per run: a dense loop
+ * of that instruction on every SIMD for about `seconds` (default 0.02).  lane_mads_per_s = median of the later
+ * launches; shader_clock_hz from s_memtime / s_memrealtime inside the kernel; theoretical = CUs x 4 SIMDs x 16
+ * lanes per clock (a half-rate instruction) x that clock. */
+typedef struct pmx_valu_peak {
+    double lane_mads_per_s;
+    double best_lane_mads_per_s;
+    double shader_clock_hz;
+    double theoretical_lane_mads_per_s;
+    int compute_units;
+    int launches;
+} pmx_valu_peak;
+int pmx_diag_int_valu_peak(int device, double seconds, pmx_valu_peak *out);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,11 @@ PMX_ERR_CONFIG = -1
 PMX_ERR_ARG = -2
 PMX_ERR_HIP = -3
 PMX_ERR_UNSUPPORTED = -4
+PMX_ERR_RCCL = -5
+
+ABI_VERSION = 2
+UNIQUE_ID_BYTES = 128
+MAX_LOCAL_DEVICES = 16
 
 MODE_ABSORBING = 0
 MODE_SQUEEZING = 1
@@ -37,6 +42,22 @@ class PmxConfig(ctypes.Structure):
     ]
 
 
+class PmxMgpuInfo(ctypes.Structure):
+    _fields_ = [
+        ("world", ctypes.c_int), ("n_local", ctypes.c_int), ("first_rank", ctypes.c_int), ("width", ctypes.c_int),
+        ("rccl_version", ctypes.c_int), ("comm_ranks", ctypes.c_int), ("comm_first_rank", ctypes.c_int),
+        ("devices", ctypes.c_int * 16),
+    ]
+
+
+class PmxValuPeak(ctypes.Structure):
+    _fields_ = [
+        ("lane_mads_per_s", ctypes.c_double), ("best_lane_mads_per_s", ctypes.c_double),
+        ("shader_clock_hz", ctypes.c_double), ("theoretical_lane_mads_per_s", ctypes.c_double),
+        ("compute_units", ctypes.c_int), ("launches", ctypes.c_int),
+    ]
+
+
 _u64p = ctypes.c_void_p
 _u32p = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -55,6 +76,9 @@ SIGNATURES = {
     "pmx_from_mont": (ctypes.c_int, [_u64p, _u64p, _sz]),
     "pmx_ctx_create": (ctypes.c_int, [ctypes.POINTER(PmxConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "pmx_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_ctx_acquire": (ctypes.c_int, [ctypes.POINTER(PmxConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_ctx_release": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_ctx_cache_clear": (ctypes.c_int, []),
     "pmx_ctx_width": (ctypes.c_int, [ctypes.c_void_p]),
     "pmx_permute_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz]),
     "pmx_permute_batch_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, ctypes.c_void_p]),
@@ -68,6 +92,25 @@ SIGNATURES = {
                                                     ctypes.c_void_p]),
     "pmx_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p, _u64p]),
     "pmx_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, ctypes.c_void_p]),
+    # device groups
+    "pmx_shard_bounds": (ctypes.c_int, [_sz, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "pmx_mgpu_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_mgpu_create": (ctypes.c_int, [ctypes.POINTER(PmxConfig), ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_mgpu_create_rank": (ctypes.c_int, [ctypes.POINTER(PmxConfig), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_mgpu_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_mgpu_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PmxMgpuInfo)]),
+    "pmx_mgpu_stream": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "pmx_mgpu_ctx": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "pmx_mgpu_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_mgpu_permute_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz]),
+    "pmx_mgpu_permute_shards_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _sz]),
+    "pmx_mgpu_all_gather_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
+    "pmx_mgpu_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz]),
+    "pmx_mgpu_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p]),
+    # diagnostics
+    "pmx_diag_int_valu_peak": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.POINTER(PmxValuPeak)]),
 }
 
 _lib = None

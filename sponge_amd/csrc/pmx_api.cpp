@@ -6,11 +6,15 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/poseidon_mi355x.h"
+#include "pmx_ctx.hpp"
 #include "pmx_internal.hpp"
 #include "pmx_prepare.hpp"
 #include "pmx_launch.hpp"
@@ -27,35 +31,13 @@ int set_error(int code, const char *fmt, ...) {
     return code;
 }
 
-static int hip_fail(hipError_t e, const char *what) {
+int hip_fail(hipError_t e, const char *what) {
     return set_error(PMX_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
-
-#define PMX_HIP(expr)                                        \
-    do {                                                     \
-        hipError_t e_ = (expr);                              \
-        if (e_ != hipSuccess) return hip_fail(e_, #expr);    \
-    } while (0)
 
 }  // namespace pmx
 
 using namespace pmx;
-
-struct pmx_ctx {
-    int device;
-    uint32_t t;
-    DevConfig dev;           // kernel-argument block (points at d_consts)
-    uint32_t *d_consts;      // device: ark | mds as u32 limbs
-    hipStream_t stream;      // used by the host-buffer entry points
-    hipStream_t stream2;     // second lane of the pinned-memory pipeline
-    void *scratch[4];        // grow-only device staging for the host-buffer entry points
-    size_t scratch_bytes[4];
-};
-
-static int ctx_bind(pmx_ctx *ctx) {
-    PMX_HIP(hipSetDevice(ctx->device));
-    return PMX_OK;
-}
 
 static int ctx_scratch(pmx_ctx *ctx, int slot, size_t bytes, void **out) {
     if (bytes == 0) bytes = 16;
@@ -114,11 +96,10 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
 
     pmx_ctx *ctx = new (std::nothrow) pmx_ctx();
     if (!ctx) return set_error(PMX_ERR_ARG, "out of host memory");
-    std::memset((void *)ctx, 0, sizeof *ctx);
     ctx->device = device;
     ctx->t = pp.t;
-    rc = ctx_bind(ctx);
-    if (rc) { delete ctx; return rc; }
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) { delete ctx; return hip_fail(guard.err, "hipSetDevice"); }
 
     const size_t bytes = pp.consts.size() * 4;
     e = hipMalloc((void **)&ctx->d_consts, bytes);
@@ -143,6 +124,11 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.tab_bdense_offset = (uint32_t)pp.tab_bdense_offset;
     d.io_offset = (uint32_t)pp.io_offset;
     d.has_opt = pp.has_opt ? 1u : 0u;
+    {
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds <= 0) lds = 64 * 1024;
+        d.max_lds_bytes = (uint32_t)lds;
+    }
     d.rounds = pp.c;
     d.field = pp.f;
     d.field.io = nullptr;   // engines point it at consts + io_offset on the device
@@ -151,9 +137,8 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     return PMX_OK;
 }
 
-extern "C" int pmx_ctx_destroy(pmx_ctx *ctx) {
-    if (!ctx) return PMX_OK;
-    (void)hipSetDevice(ctx->device);
+static int ctx_free(pmx_ctx *ctx) {
+    DeviceGuard guard(ctx->device);
     for (hipStream_t st : {ctx->stream, ctx->stream2}) {
         if (st) {
             (void)hipStreamSynchronize(st);
@@ -164,6 +149,116 @@ extern "C" int pmx_ctx_destroy(pmx_ctx *ctx) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_consts) (void)hipFree(ctx->d_consts);
     delete ctx;
+    return PMX_OK;
+}
+
+extern "C" int pmx_ctx_destroy(pmx_ctx *ctx) {
+    if (!ctx) return PMX_OK;
+    if (ctx->cache_key) return set_error(PMX_ERR_ARG, "pmx_ctx_destroy: this context came from pmx_ctx_acquire; hand it back with pmx_ctx_release");
+    return ctx_free(ctx);
+}
+
+// ---- shared contexts ---------------------------------------------------------------------------------
+// CryptographicSponge::new clones the parameters into every sponge (src/poseidon/mod.rs:219-230) and downstream code
+// calls it once per transcript.  Creating a device context per sponge would re-derive the sparse-round tables, allocate
+// and upload every time, so the bindings take their context from this process-wide cache instead: one context per
+// (config contents, device), reference-counted; idle contexts stay resident (at most kMaxIdle of them, oldest first
+// out) so that  new -> drop -> new  does not rebuild either.
+namespace {
+struct CtxCache {
+    std::mutex lock;
+    std::unordered_map<uint64_t, std::vector<pmx_ctx *>> by_key;
+    std::deque<pmx_ctx *> idle;   // refs == 0, oldest first
+};
+CtxCache &ctx_cache() {
+    static CtxCache *c = new CtxCache();   // never destroyed: contexts may outlive static destructors' order
+    return *c;
+}
+constexpr size_t kMaxIdle = 8;
+
+std::string config_blob(const pmx_config *cfg, int device) {
+    const size_t t = (size_t)cfg->rate + cfg->capacity, rounds = (size_t)cfg->full_rounds + cfg->partial_rounds;
+    std::string b;
+    auto put = [&](const void *p, size_t n) { b.append((const char *)p, n); };
+    put(&device, sizeof device);
+    put(&cfg->full_rounds, 4); put(&cfg->partial_rounds, 4); put(&cfg->alpha, 8); put(&cfg->rate, 4); put(&cfg->capacity, 4);
+    put(cfg->modulus, 32);
+    put(cfg->ark, rounds * t * 32);
+    put(cfg->mds, t * t * 32);
+    return b;
+}
+uint64_t fnv1a(const std::string &b) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : b) { h ^= c; h *= 1099511628211ull; }
+    return h ? h : 1;
+}
+}  // namespace
+
+extern "C" int pmx_ctx_acquire(const pmx_config *cfg, int device, pmx_ctx **out) {
+    if (!cfg || !out) return set_error(PMX_ERR_ARG, "pmx_ctx_acquire: null pointer");
+    *out = nullptr;
+    if (!cfg->ark || !cfg->mds) return set_error(PMX_ERR_ARG, "pmx_ctx_acquire: null ark/mds");
+    const uint64_t t64 = (uint64_t)cfg->rate + cfg->capacity, rounds = (uint64_t)cfg->full_rounds + cfg->partial_rounds;
+    if (t64 == 0 || t64 > PMX_MAX_WIDTH || rounds == 0 || rounds > 4096) return pmx_ctx_create(cfg, device, out);   // let create() report it
+    std::string blob = config_blob(cfg, device);
+    const uint64_t key = fnv1a(blob);
+    CtxCache &cc = ctx_cache();
+    std::lock_guard<std::mutex> lock(cc.lock);
+    auto &bucket = cc.by_key[key];
+    for (pmx_ctx *c : bucket) {
+        if (c->cache_blob == blob) {
+            if (c->cache_refs++ == 0) {
+                for (auto it = cc.idle.begin(); it != cc.idle.end(); ++it)
+                    if (*it == c) { cc.idle.erase(it); break; }
+            }
+            *out = c;
+            return PMX_OK;
+        }
+    }
+    pmx_ctx *c = nullptr;
+    int rc = pmx_ctx_create(cfg, device, &c);
+    if (rc) return rc;
+    c->cache_key = key;
+    c->cache_refs = 1;
+    c->cache_blob = std::move(blob);
+    bucket.push_back(c);
+    *out = c;
+    return PMX_OK;
+}
+
+static void cache_evict(CtxCache &cc, pmx_ctx *c) {
+    auto &bucket = cc.by_key[c->cache_key];
+    for (auto it = bucket.begin(); it != bucket.end(); ++it)
+        if (*it == c) { bucket.erase(it); break; }
+    if (bucket.empty()) cc.by_key.erase(c->cache_key);
+    (void)ctx_free(c);
+}
+
+extern "C" int pmx_ctx_release(pmx_ctx *ctx) {
+    if (!ctx) return PMX_OK;
+    if (!ctx->cache_key) return set_error(PMX_ERR_ARG, "pmx_ctx_release: this context came from pmx_ctx_create; use pmx_ctx_destroy");
+    CtxCache &cc = ctx_cache();
+    std::lock_guard<std::mutex> lock(cc.lock);
+    if (ctx->cache_refs <= 0) return set_error(PMX_ERR_ARG, "pmx_ctx_release: released more often than acquired");
+    if (--ctx->cache_refs == 0) {
+        cc.idle.push_back(ctx);
+        while (cc.idle.size() > kMaxIdle) {
+            pmx_ctx *old = cc.idle.front();
+            cc.idle.pop_front();
+            cache_evict(cc, old);
+        }
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_ctx_cache_clear(void) {
+    CtxCache &cc = ctx_cache();
+    std::lock_guard<std::mutex> lock(cc.lock);
+    while (!cc.idle.empty()) {
+        pmx_ctx *old = cc.idle.front();
+        cc.idle.pop_front();
+        cache_evict(cc, old);
+    }
     return PMX_OK;
 }
 
@@ -206,8 +301,7 @@ extern "C" int pmx_permute_batch_dev(pmx_ctx *ctx, uint64_t *d_states, size_t n,
     if (n == 0) return PMX_OK;
     if (!aligned16(d_states)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
-    int rc = ctx_bind(ctx);
-    if (rc) return rc;
+    PMX_BIND(ctx);
     PMX_HIP(launch_permute(ctx->dev, ctx->t, d_states, n, (hipStream_t)stream));
     return PMX_OK;
 }
@@ -215,8 +309,9 @@ extern "C" int pmx_permute_batch_dev(pmx_ctx *ctx, uint64_t *d_states, size_t n,
 extern "C" int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n) {
     if (!ctx || (!states && n)) return set_error(PMX_ERR_ARG, "pmx_permute_batch: null pointer");
     if (n == 0) return PMX_OK;
-    int rc = ctx_bind(ctx);
-    if (rc) return rc;
+    PMX_BIND(ctx);
+    int rc = PMX_OK;
+    std::lock_guard<std::mutex> lock(ctx->host_lock);
     const size_t row = (size_t)ctx->t * 32;
     size_t bytes = 0;
     if ((rc = batch_bytes(n, ctx->t, &bytes))) return rc;
@@ -245,8 +340,7 @@ extern "C" int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_
     if (n == 0) return PMX_OK;
     if (!aligned16(d_in) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
-    int rc = ctx_bind(ctx);
-    if (rc) return rc;
+    PMX_BIND(ctx);
     PMX_HIP(launch_hash(ctx->dev, ctx->t, d_in, in_len, d_out, out_len, n, (hipStream_t)stream));
     return PMX_OK;
 }
@@ -254,8 +348,9 @@ extern "C" int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_
 extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n) {
     if (!ctx || (!in && n && in_len) || (!out && n && out_len)) return set_error(PMX_ERR_ARG, "pmx_hash_batch: null pointer");
     if (n == 0) return PMX_OK;
-    int rc = ctx_bind(ctx);
-    if (rc) return rc;
+    PMX_BIND(ctx);
+    int rc = PMX_OK;
+    std::lock_guard<std::mutex> lock(ctx->host_lock);
     size_t in_bytes = 0, out_bytes = 0;
     if ((rc = batch_bytes(n, in_len, &in_bytes)) || (rc = batch_bytes(n, out_len, &out_bytes))) return rc;
     void *d_in = nullptr, *d_out = nullptr;
@@ -287,8 +382,7 @@ extern "C" int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uin
     if (n == 0 || in_len == 0) return PMX_OK;  // absorbing an empty input changes nothing (mod.rs:234-236)
     if (!aligned16(d_states) || !aligned16(d_in)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
-    int rc = ctx_bind(ctx);
-    if (rc) return rc;
+    PMX_BIND(ctx);
     PMX_HIP(launch_absorb(ctx->dev, ctx->t, d_states, d_tag, d_index, d_in, in_len, n, (hipStream_t)stream));
     return PMX_OK;
 }
@@ -300,8 +394,7 @@ extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, ui
     if (n == 0) return PMX_OK;
     if (!aligned16(d_states) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
-    int rc = ctx_bind(ctx);
-    if (rc) return rc;
+    PMX_BIND(ctx);
     PMX_HIP(launch_squeeze(ctx->dev, ctx->t, d_states, d_tag, d_index, d_out, out_len, n, (hipStream_t)stream));
     return PMX_OK;
 }
@@ -322,7 +415,8 @@ static int sponge_host(pmx_ctx *ctx, uint64_t *states, uint32_t *tag, uint32_t *
     if ((absorb && !in) || (!absorb && !out && len)) return set_error(PMX_ERR_ARG, "pmx_sponge_*_batch: null data pointer");
     int rc = check_modes(ctx, tag, index, n);
     if (rc) return rc;
-    if ((rc = ctx_bind(ctx))) return rc;
+    PMX_BIND(ctx);
+    std::lock_guard<std::mutex> lock(ctx->host_lock);
     size_t st_bytes = 0, io_bytes = 0;
     if ((rc = batch_bytes(n, ctx->t, &st_bytes)) || (rc = batch_bytes(n, len, &io_bytes))) return rc;
     void *d_st = nullptr, *d_io = nullptr, *d_tag = nullptr, *d_idx = nullptr;
@@ -368,8 +462,7 @@ extern "C" int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_lea
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two");
     if (ctx->dev.rounds.rate < 2) return set_error(PMX_ERR_CONFIG, "2-to-1 compression needs rate >= 2");
     if (!aligned16(d_nodes)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
-    int rc = ctx_bind(ctx);
-    if (rc) return rc;
+    PMX_BIND(ctx);
     size_t src = 0, width = n_leaves;
     while (width > 1) {
         PMX_HIP(launch_compress(ctx->dev, ctx->t, d_nodes + src * 4, d_nodes + (src + width) * 4, width / 2, (hipStream_t)stream));
@@ -382,9 +475,10 @@ extern "C" int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_lea
 extern "C" int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint64_t *nodes, uint64_t *root) {
     if (!ctx || !leaves) return set_error(PMX_ERR_ARG, "pmx_merkle_2to1: null pointer");
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two");
-    int rc = ctx_bind(ctx);
-    if (rc) return rc;
+    PMX_BIND(ctx);
+    int rc = PMX_OK;
     if (n_leaves > SIZE_MAX / 64) return set_error(PMX_ERR_ARG, "tree byte size overflows size_t");
+    std::lock_guard<std::mutex> lock(ctx->host_lock);
     const size_t n_nodes = 2 * n_leaves - 1;
     void *d = nullptr;
     if ((rc = ctx_scratch(ctx, 0, n_nodes * 32, &d))) return rc;

@@ -1,0 +1,63 @@
+// Private definition of pmx_ctx and the helpers shared by pmx_api.cpp (one device) and pmx_mgpu.cpp (device groups).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+
+#include "../../include/poseidon_mi355x.h"
+#include "pmx_internal.hpp"
+
+struct pmx_ctx {
+    int device = 0;
+    uint32_t t = 0;
+    pmx::DevConfig dev{};            // kernel-argument block (points at d_consts)
+    uint32_t *d_consts = nullptr;    // device: constant table (pmx_prepare.hpp layout)
+    hipStream_t stream = nullptr;    // used by the host-buffer entry points (and by a device group for this device)
+    hipStream_t stream2 = nullptr;   // second lane of the pinned-memory pipeline
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // grow-only device staging for the host-buffer entry points
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    // The host-buffer entry points use the staging buffers and the two streams above: one caller at a time.  Contexts
+    // handed out by pmx_ctx_acquire are shared between sponges (and threads), so those entry points take this lock;
+    // the *_dev entry points only read the immutable fields and enqueue on the caller's stream.
+    std::mutex host_lock;
+    // pmx_ctx_acquire / pmx_ctx_release bookkeeping (0 for contexts made by pmx_ctx_create)
+    uint64_t cache_key = 0;
+    long cache_refs = 0;
+    std::string cache_blob;          // the config bytes the key was computed from (collision check)
+};
+
+namespace pmx {
+
+int hip_fail(hipError_t e, const char *what);
+
+#define PMX_HIP(expr)                                             \
+    do {                                                          \
+        hipError_t e_ = (expr);                                   \
+        if (e_ != hipSuccess) return ::pmx::hip_fail(e_, #expr);  \
+    } while (0)
+
+// Every entry point runs with its context's device current and puts the caller's device back on the way out: in a
+// process that drives several GPUs (torch, a device group) a call must not leave the thread's current device changed
+// behind the caller's back.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+        else prev = -1;   // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+#define PMX_BIND(ctx)                                                                \
+    ::pmx::DeviceGuard device_guard_((ctx)->device);                                 \
+    if (device_guard_.err != hipSuccess) return ::pmx::hip_fail(device_guard_.err, "hipSetDevice")
+
+}  // namespace pmx

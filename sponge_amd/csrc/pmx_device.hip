@@ -719,15 +719,22 @@ PMX_HYB_DECL(hybridg_)
 // tables, src/test.rs:14-31) run on the register/LDS hybrid - alpha = 5 specialised, any other exponent on the
 // generic S-box; everything else uses the LDS-resident run-time-width engine.
 // alpha 5 and 17 have dedicated addition chains, other exponents share the generic S-box.
+// The register engine stages its round constants in LDS (144 B per round at t = 3, 576 B in the cooperative kernel):
+// configs with hundreds of rounds do not fit a workgroup's LDS and take the run-time-width engine, whose constants
+// come through the scalar cache, instead of failing at launch.
+template <class Engine>
+static bool lds_fits(const DevConfig &c, uint32_t t) { return Engine::lds_bytes(c, t) <= (size_t)c.max_lds_bytes; }
+
 #define PMX_DISPATCH(CALL)                                                                  \
     do {                                                                                    \
         const uint64_t alpha = c.rounds.alpha;                                              \
-        if (t == 3 && c.has_opt) {                                                          \
+        if (t == 3 && c.has_opt && lds_fits<RegEngine<3, 0, true, true>>(c, t)) {           \
             if (alpha == 5) return Launch<RegEngine<3, 5, true, true>>::CALL;               \
             if (alpha == 17) return Launch<RegEngine<3, 17, true, true>>::CALL;             \
             return Launch<RegEngine<3, 0, true, true>>::CALL;                               \
         }                                                                                   \
-        if (t == 3) return Launch<RegEngine<3, 0, false>>::CALL;                            \
+        if (t == 3 && !c.has_opt && lds_fits<RegEngine<3, 0, false>>(c, t))                 \
+            return Launch<RegEngine<3, 0, false>>::CALL;                                    \
         if (c.has_opt && t >= 4 && t <= 9) {                                                \
             if (alpha == 5) return hybrid5_##CALL;                                          \
             return hybridg_##CALL;                                                          \
@@ -751,7 +758,7 @@ static constexpr size_t kTabMinPermute = PMX_TAB_MIN_PERMUTE, kTabMinCompress = 
 // t = 3, alpha 5 / 17, fewer than `limit` units: the element-form engine
 #define PMX_SMALL_BATCH(LIMIT, CALL)                                                                 \
     do {                                                                                             \
-        if (t == 3 && c.has_opt && n < (LIMIT)) {                                                    \
+        if (t == 3 && c.has_opt && n < (LIMIT) && lds_fits<RegEngine<3, 5, true, false>>(c, t)) {   \
             if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, false>>::CALL;              \
             if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, false>>::CALL;            \
         }                                                                                            \
@@ -779,7 +786,11 @@ static hipError_t launch_compress_coop(const DevConfig &c, const uint64_t *in, u
 }
 
 hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
-    if (t == 3 && c.has_opt && n <= kCoopMaxUnits) {
+    // the cooperative kernel hard-codes state = [0, l, r] and reads lane 1: capacity 1, rate 2 only (the split
+    // (rate 3, capacity 0) of the same width takes the one-lane-per-state kernel at every level)
+    const bool coop_shape = t == 3 && c.has_opt && c.rounds.capacity == 1 && c.rounds.rate == 2 &&
+                            (size_t)c.rounds.total_rounds * 3 * kCoopElems * kFeStride * 4 <= (size_t)c.max_lds_bytes;
+    if (coop_shape && n <= kCoopMaxUnits) {
         if (c.rounds.alpha == 5) return launch_compress_coop<5>(c, in, out, n, st);
         if (c.rounds.alpha == 17) return launch_compress_coop<17>(c, in, out, n, st);
         return launch_compress_coop<0>(c, in, out, n, st);

@@ -20,6 +20,7 @@ struct DevConfig {
     uint32_t tab_mds_offset, tab_sparse_offset, tab_bdense_offset;   // shifted tables (pmx_field.hpp: tab_dot)
     uint32_t io_offset;       // FieldRt::io block; `field.io` itself holds a HOST address and is re-pointed by the engines
     uint32_t has_opt;         // optimised schedule tables present (and, for t = 3, the cooperative table)
+    uint32_t max_lds_bytes;   // LDS one workgroup may ask for on this device (launcher-side engine choice only)
     Rounds rounds;
     FieldRt field;
     Fe one;                   // 2^261 mod p

@@ -1,0 +1,331 @@
+// Device groups: the batch sharded over the GPUs of one node, RCCL (over xGMI) for the final gather.
+//
+// Sponge states are independent - the reference has no cross-state data flow anywhere in src/poseidon/mod.rs:62-183 -
+// so the batch is cut into contiguous shards [g n / G, (g+1) n / G), one per GPU, and the data path needs NO
+// collective.  RCCL moves data in exactly two places: the final gather of the result shards (ncclAllGather, or a group
+// of ncclBroadcasts when the shards are ragged) and the 32-byte subtree roots of the sharded Merkle reduction.
+//
+// A group is either every GPU of one process (pmx_mgpu_create: ncclCommInitAll, one host thread drives all devices)
+// or one rank of a multi-process job (pmx_mgpu_create_rank: ncclCommInitRank with an id made by pmx_mgpu_unique_id
+// and carried to the other processes by the caller).  Either way a group holds `n_local` (device, pmx_ctx, stream,
+// communicator) slots with consecutive ranks starting at `first_rank`.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/poseidon_mi355x.h"
+#include "pmx_ctx.hpp"
+
+using namespace pmx;
+
+static_assert(PMX_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the ABI's id size is RCCL's");
+
+struct pmx_mgpu {
+    int world = 0;        // ranks in the communicator
+    int first_rank = 0;   // rank of local slot 0
+    std::vector<int> device;
+    std::vector<pmx_ctx *> ctx;       // owned (pmx_ctx_create)
+    std::vector<ncclComm_t> comm;
+    uint32_t t = 0;
+};
+
+static int rccl_fail(ncclResult_t r, const char *what) {
+    return set_error(PMX_ERR_RCCL, "%s: %s", what, ncclGetErrorString(r));
+}
+
+#define PMX_RCCL(expr)                                        \
+    do {                                                      \
+        ncclResult_t r_ = (expr);                             \
+        if (r_ != ncclSuccess) return rccl_fail(r_, #expr);   \
+    } while (0)
+
+extern "C" int pmx_shard_bounds(size_t n, int world, int rank, size_t *start, size_t *count) {
+    if (world <= 0 || rank < 0 || rank >= world || !start || !count) return set_error(PMX_ERR_ARG, "pmx_shard_bounds: bad argument");
+    const size_t base = n / (size_t)world, extra = n % (size_t)world, r = (size_t)rank;
+    *start = r * base + (r < extra ? r : extra);
+    *count = base + (r < extra ? 1 : 0);
+    return PMX_OK;
+}
+
+extern "C" int pmx_mgpu_unique_id(uint8_t id[PMX_UNIQUE_ID_BYTES]) {
+    if (!id) return set_error(PMX_ERR_ARG, "pmx_mgpu_unique_id: null pointer");
+    ncclUniqueId u;
+    PMX_RCCL(ncclGetUniqueId(&u));
+    std::memcpy(id, u.internal, PMX_UNIQUE_ID_BYTES);
+    return PMX_OK;
+}
+
+static void group_free(pmx_mgpu *g) {
+    for (size_t l = 0; l < g->comm.size(); ++l) {
+        if (g->comm[l]) {
+            DeviceGuard guard(g->device[l]);
+            (void)ncclCommDestroy(g->comm[l]);
+        }
+    }
+    for (pmx_ctx *c : g->ctx)
+        if (c) (void)pmx_ctx_destroy(c);
+    delete g;
+}
+
+static int group_contexts(pmx_mgpu *g, const pmx_config *cfg) {
+    for (size_t l = 0; l < g->device.size(); ++l) {
+        pmx_ctx *c = nullptr;
+        int rc = pmx_ctx_create(cfg, g->device[l], &c);
+        if (rc) return rc;
+        g->ctx[l] = c;
+    }
+    g->t = (uint32_t)pmx_ctx_width(g->ctx[0]);
+    return PMX_OK;
+}
+
+extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *devices, pmx_mgpu **out) {
+    if (!cfg || !out) return set_error(PMX_ERR_ARG, "pmx_mgpu_create: null pointer");
+    *out = nullptr;
+    const int visible = pmx_device_count();
+    if (visible == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
+    if (n_devices <= 0 || n_devices > visible) return set_error(PMX_ERR_ARG, "n_devices %d out of range [1,%d]", n_devices, visible);
+    pmx_mgpu *g = new (std::nothrow) pmx_mgpu();
+    if (!g) return set_error(PMX_ERR_ARG, "out of host memory");
+    g->world = n_devices;
+    g->first_rank = 0;
+    g->device.resize(n_devices);
+    g->ctx.assign(n_devices, nullptr);
+    g->comm.assign(n_devices, nullptr);
+    for (int l = 0; l < n_devices; ++l) {
+        g->device[l] = devices ? devices[l] : l;
+        if (g->device[l] < 0 || g->device[l] >= visible) { group_free(g); return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", g->device[l], visible); }
+        for (int k = 0; k < l; ++k)
+            if (g->device[k] == g->device[l]) { group_free(g); return set_error(PMX_ERR_ARG, "device %d listed twice", g->device[l]); }
+    }
+    int rc = group_contexts(g, cfg);
+    if (rc) { group_free(g); return rc; }
+    ncclResult_t r = ncclCommInitAll(g->comm.data(), n_devices, g->device.data());
+    if (r != ncclSuccess) { group_free(g); return rccl_fail(r, "ncclCommInitAll"); }
+    *out = g;
+    return PMX_OK;
+}
+
+extern "C" int pmx_mgpu_create_rank(const pmx_config *cfg, int device, int rank, int world,
+                                    const uint8_t id[PMX_UNIQUE_ID_BYTES], pmx_mgpu **out) {
+    if (!cfg || !out || !id) return set_error(PMX_ERR_ARG, "pmx_mgpu_create_rank: null pointer");
+    *out = nullptr;
+    if (world <= 0 || rank < 0 || rank >= world) return set_error(PMX_ERR_ARG, "rank %d / world %d out of range", rank, world);
+    const int visible = pmx_device_count();
+    if (visible == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
+    if (device < 0 || device >= visible) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, visible);
+    pmx_mgpu *g = new (std::nothrow) pmx_mgpu();
+    if (!g) return set_error(PMX_ERR_ARG, "out of host memory");
+    g->world = world;
+    g->first_rank = rank;
+    g->device.assign(1, device);
+    g->ctx.assign(1, nullptr);
+    g->comm.assign(1, nullptr);
+    int rc = group_contexts(g, cfg);
+    if (rc) { group_free(g); return rc; }
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, PMX_UNIQUE_ID_BYTES);
+    {
+        DeviceGuard guard(device);
+        if (guard.err != hipSuccess) { group_free(g); return hip_fail(guard.err, "hipSetDevice"); }
+        ncclResult_t r = ncclCommInitRank(&g->comm[0], world, u, rank);
+        if (r != ncclSuccess) { group_free(g); return rccl_fail(r, "ncclCommInitRank"); }
+    }
+    *out = g;
+    return PMX_OK;
+}
+
+extern "C" int pmx_mgpu_destroy(pmx_mgpu *g) {
+    if (!g) return PMX_OK;
+    (void)pmx_mgpu_synchronize(g);
+    group_free(g);
+    return PMX_OK;
+}
+
+extern "C" int pmx_mgpu_get_info(const pmx_mgpu *g, pmx_mgpu_info *info) {
+    if (!g || !info) return set_error(PMX_ERR_ARG, "pmx_mgpu_get_info: null pointer");
+    std::memset(info, 0, sizeof *info);
+    info->world = g->world;
+    info->n_local = (int)g->device.size();
+    info->first_rank = g->first_rank;
+    info->width = (int)g->t;
+    PMX_RCCL(ncclGetVersion(&info->rccl_version));
+    // what the LIVE communicator says about itself (not what the group was asked for)
+    PMX_RCCL(ncclCommCount(g->comm[0], &info->comm_ranks));
+    PMX_RCCL(ncclCommUserRank(g->comm[0], &info->comm_first_rank));
+    for (size_t l = 0; l < g->device.size() && l < PMX_MAX_LOCAL_DEVICES; ++l) info->devices[l] = g->device[l];
+    return PMX_OK;
+}
+
+extern "C" void *pmx_mgpu_stream(const pmx_mgpu *g, int local) {
+    if (!g || local < 0 || local >= (int)g->ctx.size()) return nullptr;
+    return (void *)g->ctx[local]->stream;
+}
+
+extern "C" pmx_ctx *pmx_mgpu_ctx(const pmx_mgpu *g, int local) {
+    if (!g || local < 0 || local >= (int)g->ctx.size()) return nullptr;
+    return g->ctx[local];
+}
+
+extern "C" int pmx_mgpu_synchronize(pmx_mgpu *g) {
+    if (!g) return set_error(PMX_ERR_ARG, "pmx_mgpu_synchronize: null pointer");
+    for (size_t l = 0; l < g->ctx.size(); ++l) {
+        if (!g->ctx[l]) continue;
+        PMX_BIND(g->ctx[l]);
+        PMX_HIP(hipStreamSynchronize(g->ctx[l]->stream));
+    }
+    return PMX_OK;
+}
+
+static int local_span(const pmx_mgpu *g, size_t n_total, size_t l, size_t *start, size_t *count) {
+    return pmx_shard_bounds(n_total, g->world, g->first_rank + (int)l, start, count);
+}
+
+// ---- permutation ---------------------------------------------------------------------------------------------------
+extern "C" int pmx_mgpu_permute_shards_dev(pmx_mgpu *g, uint64_t *const *d_shards, size_t n_total) {
+    if (!g || !d_shards) return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_shards_dev: null pointer");
+    for (size_t l = 0; l < g->ctx.size(); ++l) {
+        size_t start = 0, count = 0;
+        int rc = local_span(g, n_total, l, &start, &count);
+        if (rc) return rc;
+        if ((rc = pmx_permute_batch_dev(g->ctx[l], d_shards[l], count, g->ctx[l]->stream))) return rc;   // no collective on the data path
+    }
+    return PMX_OK;
+}
+
+// Host batch, single-process groups: shard l goes through device l's own host path (pinned memory: chunked H2D / kernel
+// / D2H pipeline on two streams), one host thread per device so that all devices copy and compute concurrently - also
+// for pageable memory, whose copies block the calling thread.
+extern "C" int pmx_mgpu_permute_batch(pmx_mgpu *g, uint64_t *states, size_t n) {
+    if (!g || (!states && n)) return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_batch: null pointer");
+    if ((int)g->ctx.size() != g->world)
+        return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_batch needs a single-process group (this one holds %zu of %d ranks)", g->ctx.size(), g->world);
+    if (n == 0) return PMX_OK;
+    const size_t L = g->ctx.size();
+    std::vector<int> rcs(L, PMX_OK);
+    std::vector<std::string> msgs(L);
+    auto run = [&](size_t l) {
+        size_t start = 0, count = 0;
+        int rc = local_span(g, n, l, &start, &count);
+        if (!rc && count) rc = pmx_permute_batch(g->ctx[l], states + start * g->t * 4, count);
+        rcs[l] = rc;
+        if (rc) msgs[l] = pmx_last_error();   // the error text is thread-local: carry it back to the caller's thread
+    };
+    std::vector<std::thread> workers;
+    for (size_t l = 1; l < L; ++l) workers.emplace_back(run, l);
+    run(0);
+    for (auto &w : workers) w.join();
+    for (size_t l = 0; l < L; ++l)
+        if (rcs[l]) return set_error(rcs[l], "device %d: %s", g->device[l], msgs[l].c_str());
+    return PMX_OK;
+}
+
+// ---- the final gather ------------------------------------------------------------------------------------------------
+// Every rank ends with all shards in rank order.  Equal shards: one ncclAllGather.  Ragged shards (n_total not a
+// multiple of the world size): one ncclBroadcast per rank inside a group call, each into its own span of the output.
+extern "C" int pmx_mgpu_all_gather_dev(pmx_mgpu *g, const uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total,
+                                       size_t row_elems) {
+    if (!g || !d_shards || !d_all) return set_error(PMX_ERR_ARG, "pmx_mgpu_all_gather_dev: null pointer");
+    if (row_elems == 0 || n_total == 0) return PMX_OK;
+    if (n_total > SIZE_MAX / (row_elems * 32)) return set_error(PMX_ERR_ARG, "gather byte size overflows size_t");
+    const size_t words = row_elems * 4;   // u64 words per unit
+    const bool equal = n_total % (size_t)g->world == 0;
+    PMX_RCCL(ncclGroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (size_t l = 0; l < g->ctx.size() && r == ncclSuccess; ++l) {
+        DeviceGuard guard(g->device[l]);
+        hipStream_t st = g->ctx[l]->stream;
+        if (equal) {
+            r = ncclAllGather(d_shards[l], d_all[l], (n_total / (size_t)g->world) * words, ncclUint64, g->comm[l], st);
+        } else {
+            for (int root = 0; root < g->world && r == ncclSuccess; ++root) {
+                size_t start = 0, count = 0;
+                (void)pmx_shard_bounds(n_total, g->world, root, &start, &count);
+                if (count == 0) continue;
+                const bool mine = root == g->first_rank + (int)l;
+                r = ncclBroadcast(mine ? (const void *)d_shards[l] : (const void *)(d_all[l] + start * words), d_all[l] + start * words,
+                                  count * words, ncclUint64, root, g->comm[l], st);
+            }
+        }
+    }
+    ncclResult_t e = ncclGroupEnd();
+    if (r != ncclSuccess) return rccl_fail(r, equal ? "ncclAllGather" : "ncclBroadcast");
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupEnd");
+    return PMX_OK;
+}
+
+// ---- Merkle 2-to-1 ---------------------------------------------------------------------------------------------------
+// Each rank reduces its own contiguous subtree of m = n_leaves / world leaves (level by level, pmx_merkle_2to1_dev), the
+// `world` subtree roots - 32 bytes each - are all-gathered, and every rank finishes the top log2(world) levels itself.
+extern "C" int pmx_mgpu_merkle_2to1_dev(pmx_mgpu *g, uint64_t *const *d_nodes, uint64_t *const *d_top, size_t n_leaves) {
+    if (!g || !d_nodes || !d_top) return set_error(PMX_ERR_ARG, "pmx_mgpu_merkle_2to1_dev: null pointer");
+    const size_t W = (size_t)g->world;
+    if (W & (W - 1)) return set_error(PMX_ERR_ARG, "the sharded tree needs a power-of-two number of ranks (have %d)", g->world);
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || n_leaves < W) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two >= the number of ranks");
+    const size_t m = n_leaves / W;
+    for (size_t l = 0; l < g->ctx.size(); ++l) {
+        int rc = pmx_merkle_2to1_dev(g->ctx[l], d_nodes[l], m, g->ctx[l]->stream);
+        if (rc) return rc;
+    }
+    if (W == 1) {
+        PMX_BIND(g->ctx[0]);
+        PMX_HIP(hipMemcpyAsync(d_top[0], d_nodes[0] + (2 * m - 2) * 4, 32, hipMemcpyDeviceToDevice, g->ctx[0]->stream));
+        return PMX_OK;
+    }
+    PMX_RCCL(ncclGroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (size_t l = 0; l < g->ctx.size() && r == ncclSuccess; ++l) {
+        DeviceGuard guard(g->device[l]);
+        r = ncclAllGather(d_nodes[l] + (2 * m - 2) * 4, d_top[l], 4, ncclUint64, g->comm[l], g->ctx[l]->stream);
+    }
+    ncclResult_t e = ncclGroupEnd();
+    if (r != ncclSuccess) return rccl_fail(r, "ncclAllGather");
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupEnd");
+    for (size_t l = 0; l < g->ctx.size(); ++l) {
+        int rc = pmx_merkle_2to1_dev(g->ctx[l], d_top[l], W, g->ctx[l]->stream);
+        if (rc) return rc;
+    }
+    return PMX_OK;
+}
+
+// Host leaves, single-process groups.  root: [4].
+extern "C" int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t n_leaves, uint64_t *root) {
+    if (!g || !leaves || !root) return set_error(PMX_ERR_ARG, "pmx_mgpu_merkle_2to1: null pointer");
+    if ((int)g->ctx.size() != g->world)
+        return set_error(PMX_ERR_ARG, "pmx_mgpu_merkle_2to1 needs a single-process group (this one holds %zu of %d ranks)", g->ctx.size(), g->world);
+    const size_t W = (size_t)g->world, L = g->ctx.size();
+    if (W & (W - 1)) return set_error(PMX_ERR_ARG, "the sharded tree needs a power-of-two number of ranks (have %d)", g->world);
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || n_leaves < W) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two >= the number of ranks");
+    if (n_leaves > SIZE_MAX / 64) return set_error(PMX_ERR_ARG, "tree byte size overflows size_t");
+    const size_t m = n_leaves / W;
+    std::vector<uint64_t *> d_nodes(L, nullptr), d_top(L, nullptr);
+    int rc = PMX_OK;
+    auto cleanup = [&]() {
+        (void)pmx_mgpu_synchronize(g);
+        for (size_t l = 0; l < L; ++l) {
+            DeviceGuard guard(g->device[l]);
+            if (d_nodes[l]) (void)hipFree(d_nodes[l]);
+            if (d_top[l]) (void)hipFree(d_top[l]);
+        }
+    };
+    for (size_t l = 0; l < L && !rc; ++l) {
+        DeviceGuard guard(g->device[l]);
+        hipError_t e = hipMalloc((void **)&d_nodes[l], (2 * m - 1) * 32);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_top[l], (2 * W - 1) * 32);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_nodes[l], leaves + (size_t)l * m * 4, m * 32, hipMemcpyHostToDevice, g->ctx[l]->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "pmx_mgpu_merkle_2to1: device staging");
+    }
+    if (!rc) rc = pmx_mgpu_merkle_2to1_dev(g, d_nodes.data(), d_top.data(), n_leaves);
+    if (!rc) {
+        DeviceGuard guard(g->device[0]);
+        hipError_t e = hipMemcpyAsync(root, d_top[0] + (W == 1 ? 0 : (2 * W - 2) * 4), 32, hipMemcpyDeviceToHost, g->ctx[0]->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->ctx[0]->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "pmx_mgpu_merkle_2to1: root copy");
+    }
+    cleanup();
+    return rc;
+}

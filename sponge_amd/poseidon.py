@@ -157,26 +157,33 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
 
+def c_config(cfg: "PoseidonConfig") -> "_lib.PmxConfig":
+    """pmx_config view of a PoseidonConfig (borrows cfg.ark / cfg.mds: keep `cfg` alive while it is used)."""
+    c = _lib.PmxConfig()
+    c.full_rounds, c.partial_rounds, c.alpha = cfg.full_rounds, cfg.partial_rounds, cfg.alpha
+    c.rate, c.capacity = cfg.rate, cfg.capacity
+    for i, l in enumerate(cfg.field.modulus_limbs()):
+        c.modulus[i] = int(l)
+    c.ark = cfg.ark.ctypes.data
+    c.mds = cfg.mds.ctypes.data
+    return c
+
+
 class Context:
-    """pmx_ctx: one validated config resident on one GPU."""
+    """pmx_ctx: one validated config resident on one GPU, taken from the library's process-wide cache
+    (pmx_ctx_acquire): equal configs share one device context however many PoseidonConfig objects carry them."""
 
     def __init__(self, cfg: PoseidonConfig, device: int = 0):
         self.cfg = cfg
         self.device = device
-        c = _lib.PmxConfig()
-        c.full_rounds, c.partial_rounds, c.alpha = cfg.full_rounds, cfg.partial_rounds, cfg.alpha
-        c.rate, c.capacity = cfg.rate, cfg.capacity
-        for i, l in enumerate(cfg.field.modulus_limbs()):
-            c.modulus[i] = int(l)
-        c.ark = cfg.ark.ctypes.data
-        c.mds = cfg.mds.ctypes.data
+        c = c_config(cfg)
         handle = ctypes.c_void_p()
-        _lib.check(_lib.lib().pmx_ctx_create(ctypes.byref(c), device, ctypes.byref(handle)))
+        _lib.check(_lib.lib().pmx_ctx_acquire(ctypes.byref(c), device, ctypes.byref(handle)))
         self._h = handle
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().pmx_ctx_destroy(self._h)
+            _lib.lib().pmx_ctx_release(self._h)
             self._h = None
 
     def __del__(self):
@@ -358,12 +365,20 @@ class PoseidonSponge:
         f = self.parameters.field
         if all(sz is None for sz in sizes):
             return f.to_ints(self.squeeze_native_field_elements(len(sizes)))
-        return self.squeeze_field_elements_with_sizes(sizes, f)
+        return self._squeeze_field_elements_with_sizes_default_impl(sizes, f)
 
     def squeeze_field_elements_with_sizes(self, sizes, field2: Field) -> List[int]:
-        """Non-native default (src/lib.rs:61-100): every requested element takes MODULUS_BIT_SIZE(F2) - 1 bits
-        (FieldElementSize::num_bits ignores the Truncated value, src/lib.rs:45-52), little-endian, reduced mod p2.
-        `sizes`: None for Full, an int for Truncated(n)."""
+        """PoseidonSponge's override (mod.rs:288-304): a field of the native characteristic goes through
+        squeeze_native_field_elements_with_sizes (full native elements when every size is Full); any other field
+        takes the bit-recomposition default.  `sizes`: None for Full, an int for Truncated(n).  Canonical integers."""
+        if field2.modulus == self.parameters.field.modulus:
+            return self.squeeze_native_field_elements_with_sizes(sizes)
+        return self._squeeze_field_elements_with_sizes_default_impl(sizes, field2)
+
+    def _squeeze_field_elements_with_sizes_default_impl(self, sizes, field2: Field) -> List[int]:
+        """squeeze_field_elements_with_sizes_default_impl (src/lib.rs:61-100): every requested element takes
+        MODULUS_BIT_SIZE(F2) - 1 bits (FieldElementSize::num_bits ignores the Truncated value, src/lib.rs:45-52),
+        little-endian, reduced mod p2."""
         if len(sizes) == 0:
             return []
         nb = field2.modulus_bit_size - 1

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.pmx_abi_version() == 1
+    assert lib.pmx_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_no_device_means_loud_failure_not_fallback():

@@ -114,6 +114,12 @@ def test_absorb_objects_fork_and_nonnative_squeeze_on_gpu():
         [sum(b << i for i, b in enumerate(obits[k * 254:(k + 1) * 254])) % P for k in range(2)]
     with pytest.raises(ValueError):
         forked.clone().squeeze_native_field_elements_with_sizes([256])      # panic at src/lib.rs:48
+    # squeeze_field_elements_with_sizes::<F2> with F2 of the native characteristic (mod.rs:288-299) is the native
+    # squeeze: all-Full sizes return whole native elements, not 254-bit truncations
+    s3, s4 = forked.clone(), forked.clone()
+    assert s3.squeeze_field_elements_with_sizes([None, None], F) == oforked.clone().squeeze_native_field_elements(2)
+    assert s4.squeeze_field_elements_with_sizes([None, 100], F) == \
+        [sum(b << i for i, b in enumerate(obits[k * 254:(k + 1) * 254])) % P for k in range(2)]
     # single_field_element (tests.rs:26-33): elem and elem + 1 give different outputs
     a, b = S.PoseidonSponge.new(cfg), S.PoseidonSponge.new(cfg)
     a.absorb(A.Fp(987654321, F))

@@ -49,10 +49,9 @@ def test_c3_full_batch_2e18_bn254_t9_alpha5():
     cfg.context().permute_batch_dev(d.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = to_numpy(d).reshape(n, 9, 4)
-    # the restatement needs ~0.25 ms per t=9 permutation per core: check a strided 1/16 sample in full
-    idx = np.arange(0, n, 16)
-    want = c_oracle(name).permute_batch(np.ascontiguousarray(states[idx]), threads=0)
-    assert np.array_equal(got[idx], want)
+    # the whole batch (the restatement needs ~0.25 ms per t=9 permutation per core: a few seconds on the box's cores)
+    want = c_oracle(name).permute_batch(states, threads=0)
+    assert np.array_equal(got, want)
 
 
 def test_c5_merkle_2e20_leaves_root_and_decomposition():
@@ -135,3 +134,63 @@ def test_every_large_batch_kernel_of_t3_vs_c_oracle(alpha, rf, rp):
     nodes, root = ctx.merkle_2to1(leaves)
     want = cr.merkle(leaves, threads=0)
     assert np.array_equal(nodes, want) and np.array_equal(root, want[-1])
+
+
+# ---- the per-GPU shards of the 8-GPU configurations, and the whole C5 tree on one GPU ---------------------------------
+def test_c4_per_gpu_shard_2e21_states_whole_batch():
+    """BASELINE configs[3] puts 2^24 states on 8 GPUs: 2^21 per GPU.  Shard 5 of that batch (the global seeded batch at
+    offset 5 * 2^21, exactly what bench.py gives rank 5), whole shard against the C restatement."""
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    n, shard = 1 << 21, 5
+    states = synth.random_elements(cfg.field, n * 3, seed=0x5EED0002, offset=shard * n * 3).reshape(n, 3, 4)
+    d = dev_tensor(states)
+    cfg.context().permute_batch_dev(d.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_numpy(d).reshape(n, 3, 4), c_oracle(name).permute_batch(states, threads=0))
+
+
+def test_c5_per_gpu_subtree_2e21_leaves_all_nodes():
+    """BASELINE configs[4] on 8 GPUs: every GPU reduces a 2^21-leaf subtree.  All 2^22 - 1 nodes against the C restatement."""
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    m = 1 << 21
+    leaves = synth.random_elements(cfg.field, m, seed=0x5EED0005, offset=3 * m)        # rank 3's leaves
+    nodes = torch.zeros((2 * m - 1, 4), dtype=torch.int64, device="cuda:0")
+    nodes[:m] = dev_tensor(leaves)
+    cfg.context().merkle_2to1_dev(nodes.data_ptr(), m, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_numpy(nodes), c_oracle(name).merkle(leaves, threads=0))
+
+
+def test_c5_whole_tree_2e24_leaves_on_one_gpu():
+    """The whole C5 tree - 2^24 leaves, 2^24 - 1 compressions, 1 GiB of nodes - on one GPU: every node against the C
+    restatement, and the root against the root rebuilt from the 8 subtree roots (the 8-GPU decomposition: subtree g is
+    leaves [g 2^21, (g+1) 2^21), its root is node g of the level that has 8 nodes)."""
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    ctx = cfg.context()
+    m = 1 << 24
+    leaves = synth.random_elements(cfg.field, m, seed=0x5EED0005)
+    nodes = torch.zeros((2 * m - 1, 4), dtype=torch.int64, device="cuda:0")
+    nodes[:m] = dev_tensor(leaves)
+    ctx.merkle_2to1_dev(nodes.data_ptr(), m, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = to_numpy(nodes)
+    del nodes
+    # the 8-GPU split: each 2^21-leaf subtree on its own, then 3 more levels over the 8 roots
+    sub_roots = []
+    for g in (0, 7):                                  # two of the eight as separate launches ...
+        sub = torch.zeros((2 * (m // 8) - 1, 4), dtype=torch.int64, device="cuda:0")
+        sub[:m // 8] = dev_tensor(leaves[g * (m // 8):(g + 1) * (m // 8)])
+        ctx.merkle_2to1_dev(sub.data_ptr(), m // 8, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        sub_roots.append((g, to_numpy(sub[-1:]).reshape(4)))
+        del sub
+    level8 = got[2 * m - 16: 2 * m - 8]               # ... all eight are the level with 8 nodes of the big tree
+    for g, r in sub_roots:
+        assert np.array_equal(level8[g], r)
+    _, top = ctx.merkle_2to1(level8, want_nodes=False)
+    assert np.array_equal(top, got[-1])
+    want = c_oracle(name).merkle(leaves, threads=0)
+    assert np.array_equal(got, want)

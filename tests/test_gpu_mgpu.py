@@ -1,0 +1,147 @@
+"""Device groups through the C ABI on whatever GPUs the box has (1 on the development box, N on a multi-GPU node):
+sharded permutation of host and device-resident batches, the RCCL gather, the sharded Merkle reduction - all against
+the C restatement - and the live communicator's own account of its ranks."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import sponge_amd as S
+from sponge_amd import _lib, mgpu, synth
+
+from gpu_helpers import c_oracle, product_config
+
+pytestmark = pytest.mark.gpu
+
+NAME = "bls_t3_a5_8_31"
+
+
+def _group():
+    cfg = product_config(NAME)
+    return cfg, mgpu.DeviceGroup.single_process(cfg, _lib.lib().pmx_device_count())
+
+
+def test_group_info_reports_the_live_communicator():
+    cfg, g = _group()
+    info = g.info()
+    ndev = _lib.lib().pmx_device_count()
+    assert info["world"] == info["n_local"] == info["comm_ranks"] == ndev
+    assert info["first_rank"] == info["comm_first_rank"] == 0
+    assert info["devices"] == list(range(ndev)) and info["width"] == 3
+    assert info["rccl_version"] >= 20000
+    assert g.stream(0) != 0 and g.stream(ndev) == 0
+    g.close()
+
+
+@pytest.mark.parametrize("n", [1, 1000, 100003, (1 << 18) + 17])
+def test_host_batch_sharded_over_all_devices(n):
+    cfg, g = _group()
+    states = synth.random_elements(cfg.field, n * 3, seed=0x5EED0040 + n).reshape(n, 3, 4)
+    got = g.permute_batch(states)
+    assert np.array_equal(got, c_oracle(NAME).permute_batch(states, threads=0))
+    # page-locked memory takes the pipelined path of every device
+    pinned = S.pinned_empty((n, 3, 4))
+    pinned[:] = states
+    g.permute_batch_inplace(pinned)
+    assert np.array_equal(pinned, got)
+    g.close()
+
+
+@pytest.mark.parametrize("n_total", [1 << 16, (1 << 16) + 5])     # equal shards: ncclAllGather; ragged: grouped ncclBroadcast
+def test_device_resident_shards_and_rccl_gather(n_total):
+    cfg, g = _group()
+    world = g.world
+    whole = synth.random_elements(cfg.field, n_total * 3, seed=0x5EED0041).reshape(n_total, 3, 4)
+    shards, alls = [], []
+    for l, dev in enumerate(g.devices):
+        start, count = g.local_span(n_total, l)
+        shards.append(torch.from_numpy(whole[start:start + count].view(np.int64).copy()).to(f"cuda:{dev}"))
+        alls.append(torch.zeros((n_total, 3, 4), dtype=torch.int64, device=f"cuda:{dev}"))
+    torch.cuda.synchronize()
+    g.permute_shards_dev([s.data_ptr() for s in shards], n_total)
+    g.all_gather_dev([s.data_ptr() for s in shards], [a.data_ptr() for a in alls], n_total, 3)
+    g.synchronize()
+    want = c_oracle(NAME).permute_batch(whole, threads=0)
+    for l in range(world):
+        assert np.array_equal(alls[l].cpu().numpy().view(np.uint64), want), f"gathered copy on local device {l}"
+    g.close()
+
+
+@pytest.mark.parametrize("log2_leaves", [0, 1, 5, 16])
+def test_sharded_merkle_root(log2_leaves):
+    cfg, g = _group()
+    m = 1 << log2_leaves
+    if m < g.world:
+        pytest.skip("fewer leaves than ranks")
+    if g.world & (g.world - 1):
+        pytest.skip("the sharded tree needs a power-of-two number of ranks")
+    leaves = synth.random_elements(cfg.field, m, seed=0x5EED0042 + log2_leaves)
+    assert np.array_equal(g.merkle_root(leaves), c_oracle(NAME).merkle(leaves, threads=0)[-1])
+    g.close()
+
+
+def test_one_rank_group_with_a_unique_id():
+    """The multi-process constructor (what bench.py uses under torchrun), here as a world of one."""
+    cfg = product_config(NAME)
+    uid = mgpu.unique_id()
+    assert len(uid) == 128 and any(uid)
+    g = mgpu.DeviceGroup.one_rank(cfg, 0, 0, 1, uid)
+    assert g.info()["comm_ranks"] == 1
+    n = 5000
+    states = synth.random_elements(cfg.field, n * 3, seed=0x5EED0043).reshape(n, 3, 4)
+    d = torch.from_numpy(states.view(np.int64).copy()).to("cuda:0")
+    out = torch.zeros_like(d)
+    torch.cuda.synchronize()
+    g.permute_shards_dev([d.data_ptr()], n)
+    g.all_gather_dev([d.data_ptr()], [out.data_ptr()], n, 3)
+    g.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), c_oracle(NAME).permute_batch(states, threads=0))
+    g.close()
+
+
+def test_bad_group_arguments():
+    cfg = product_config(NAME)
+    ndev = _lib.lib().pmx_device_count()
+    with pytest.raises(S.PmxError) as ei:
+        mgpu.DeviceGroup.single_process(cfg, ndev + 1)
+    assert ei.value.code == _lib.PMX_ERR_ARG
+    with pytest.raises(S.PmxError):
+        mgpu.DeviceGroup.single_process(cfg, devices=[0, 0])
+    _, g = _group()
+    with pytest.raises(S.PmxError):
+        g.merkle_root(np.zeros((3, 4), dtype=np.uint64))          # not a power of two
+    g.close()
+
+
+def test_shared_context_cache():
+    """pmx_ctx_acquire: equal configs share one device context; idle contexts stay resident; the two ownership
+    families do not mix."""
+    from sponge_amd.poseidon import c_config
+    lib = _lib.lib()
+    a = S.poseidon_config_from_lfsr(S.BLS12_381_FR, 2, 5, 8, 31)
+    b = S.poseidon_config_from_lfsr(S.BLS12_381_FR, 2, 5, 8, 31)      # separate object, same contents
+    c = S.poseidon_config_from_lfsr(S.BLS12_381_FR, 2, 17, 8, 31)
+    ha, hb, hc = a.context()._h.value, b.context()._h.value, c.context()._h.value
+    assert ha == hb and ha != hc
+    assert lib.pmx_ctx_destroy(ctypes.c_void_p(ha)) == _lib.PMX_ERR_ARG          # acquired contexts are released, not destroyed
+    h = ctypes.c_void_p()
+    cc = c_config(a)
+    _lib.check(lib.pmx_ctx_acquire(ctypes.byref(cc), 0, ctypes.byref(h)))
+    assert h.value == ha
+    _lib.check(lib.pmx_ctx_release(h))
+    own = ctypes.c_void_p()
+    _lib.check(lib.pmx_ctx_create(ctypes.byref(cc), 0, ctypes.byref(own)))
+    assert own.value != ha
+    assert lib.pmx_ctx_release(own) == _lib.PMX_ERR_ARG
+    _lib.check(lib.pmx_ctx_destroy(own))
+    # a sponge per transcript: 200 PoseidonSponge.new on fresh-but-equal configs reuse the one context
+    st = synth.random_elements(S.BLS12_381_FR, 2, seed=7)
+    outs = set()
+    for _ in range(200):
+        cfg = S.PoseidonConfig(a.field, a.full_rounds, a.partial_rounds, a.alpha, a.mds, a.ark, a.rate, a.capacity)
+        sp = S.PoseidonSponge.new(cfg)
+        sp.absorb(st)
+        outs.add(sp.squeeze_native_field_elements(1).tobytes())
+        assert cfg.context()._h.value == ha
+    assert len(outs) == 1

@@ -315,3 +315,46 @@ def test_other_rate_capacity_splits(rate, capacity):
     osp.absorb(msg[:2])
     assert f.to_ints(sponge.squeeze_native_field_elements(1)) == osp.squeeze_native_field_elements(1)
     assert f.to_ints(sponge.state) == osp.state and (sponge.mode.tag, sponge.mode.index) == (osp.mode, osp.index)
+
+
+def test_merkle_tree_with_rate3_capacity0_crosses_the_narrow_level_threshold():
+    """Width 3 as (rate 3, capacity 0): 2-to-1 compression is permute([l, r, 0])[0] there, which the quad kernel of
+    the narrow levels (state [0, l, r], lane 1; capacity 1 only) does not compute - every level of this split has to
+    take the one-lane-per-state kernel.  A 2^16-leaf tree crosses the 16384-compression switch; all nodes against the
+    C restatement, and the batched path verifier against the tree."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    base = S.poseidon_config_from_lfsr(f, 2, 5, 8, 31)
+    cfg = S.PoseidonConfig(f, 8, 31, 5, base.mds, base.ark, 3, 0)
+    ob = O.make_config(O.BLS12_381_FR, 255, 2, 5, 8, 31)
+    cr = cref.CRef(O.PoseidonConfig(ob.p, 8, 31, 5, ob.ark, ob.mds, 3, 0))
+    m = 1 << 16
+    leaves = synth.random_elements(f, m, seed=0x5EED0030)
+    nodes, root = cfg.context().merkle_2to1(leaves)
+    want = cr.merkle(leaves, threads=0)
+    assert np.array_equal(nodes, want) and np.array_equal(root, want[-1])
+    tree = S.MerkleTree(cfg, leaves)
+    idx = [0, 1, 12345, m - 1]
+    assert S.verify_paths(cfg, leaves[idx], idx, [tree.path(i) for i in idx], tree.root).all()
+
+
+@pytest.mark.parametrize("rf,rp", [(300, 8), (120, 31), (600, 0)])
+def test_configs_whose_round_constants_exceed_lds_fall_back_to_the_run_time_engine(rf, rp):
+    """The t = 3 register engine stages 144 B of round constants per round in LDS (576 B in the quad kernel): hundreds
+    of rounds do not fit a workgroup's LDS.  The reference handles any round count (mod.rs:95-118), so such configs run
+    on the engine that reads its constants through the scalar cache - every entry point, against the C restatement."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    cfg = S.poseidon_config_from_lfsr(f, 2, 5, rf, rp)
+    cr = cref.CRef(O.make_config(O.BLS12_381_FR, 255, 2, 5, rf, rp))
+    ctx = cfg.context()
+    n = 300
+    states = synth.random_elements(f, n * 3, seed=rf).reshape(n, 3, 4)
+    assert np.array_equal(ctx.permute_batch(states), cr.permute_batch(states, threads=0))
+    msgs = synth.random_elements(f, n * 5, seed=rf + 1).reshape(n, 5, 4)
+    assert np.array_equal(ctx.hash_batch(msgs, 5, 3), cr.hash_batch(msgs, 5, 3, threads=0))
+    leaves = synth.random_elements(f, 256, seed=rf + 2)
+    nodes, _ = ctx.merkle_2to1(leaves)
+    assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
