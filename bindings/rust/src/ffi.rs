@@ -15,6 +15,30 @@ pub struct pmx_config {
 }
 #[repr(C)]
 pub struct pmx_ctx { _private: [u8; 0] }
+#[repr(C)]
+pub struct pmx_mgpu { _private: [u8; 0] }
+pub const PMX_UNIQUE_ID_BYTES: usize = 128;
+pub const PMX_MAX_LOCAL_DEVICES: usize = 16;
+#[repr(C)]
+pub struct pmx_mgpu_info {
+    pub world: c_int,
+    pub n_local: c_int,
+    pub first_rank: c_int,
+    pub width: c_int,
+    pub rccl_version: c_int,
+    pub comm_ranks: c_int,
+    pub comm_first_rank: c_int,
+    pub devices: [c_int; PMX_MAX_LOCAL_DEVICES],
+}
+#[repr(C)]
+pub struct pmx_valu_peak {
+    pub lane_mads_per_s: f64,
+    pub best_lane_mads_per_s: f64,
+    pub shader_clock_hz: f64,
+    pub theoretical_lane_mads_per_s: f64,
+    pub compute_units: c_int,
+    pub launches: c_int,
+}
 
 pub const PMX_MODE_ABSORBING: u32 = 0;
 pub const PMX_MODE_SQUEEZING: u32 = 1;
@@ -49,4 +73,27 @@ extern "C" {
     pub fn pmx_sponge_squeeze_batch_dev(ctx: *mut pmx_ctx, d_states: *mut u64, d_mode_tag: *mut u32, d_mode_index: *mut u32,
                                         d_out: *mut u64, out_len: usize, n: usize, stream: *mut c_void) -> c_int;
     pub fn pmx_merkle_2to1_dev(ctx: *mut pmx_ctx, d_nodes: *mut u64, n_leaves: usize, stream: *mut c_void) -> c_int;
+    // shared contexts
+    pub fn pmx_ctx_acquire(cfg: *const pmx_config, device: c_int, out: *mut *mut pmx_ctx) -> c_int;
+    pub fn pmx_ctx_release(ctx: *mut pmx_ctx) -> c_int;
+    pub fn pmx_ctx_cache_clear() -> c_int;
+    // device groups
+    pub fn pmx_shard_bounds(n: usize, world: c_int, rank: c_int, start: *mut usize, count: *mut usize) -> c_int;
+    pub fn pmx_mgpu_unique_id(id: *mut u8) -> c_int;
+    pub fn pmx_mgpu_create(cfg: *const pmx_config, n_devices: c_int, devices: *const c_int, out: *mut *mut pmx_mgpu) -> c_int;
+    pub fn pmx_mgpu_create_rank(cfg: *const pmx_config, device: c_int, rank: c_int, world: c_int, id: *const u8,
+                                out: *mut *mut pmx_mgpu) -> c_int;
+    pub fn pmx_mgpu_destroy(g: *mut pmx_mgpu) -> c_int;
+    pub fn pmx_mgpu_get_info(g: *const pmx_mgpu, info: *mut pmx_mgpu_info) -> c_int;
+    pub fn pmx_mgpu_stream(g: *const pmx_mgpu, local: c_int) -> *mut c_void;
+    pub fn pmx_mgpu_ctx(g: *const pmx_mgpu, local: c_int) -> *mut pmx_ctx;
+    pub fn pmx_mgpu_synchronize(g: *mut pmx_mgpu) -> c_int;
+    pub fn pmx_mgpu_permute_batch(g: *mut pmx_mgpu, states: *mut u64, n: usize) -> c_int;
+    pub fn pmx_mgpu_permute_shards_dev(g: *mut pmx_mgpu, d_shards: *const *mut u64, n_total: usize) -> c_int;
+    pub fn pmx_mgpu_all_gather_dev(g: *mut pmx_mgpu, d_shards: *const *const u64, d_all: *const *mut u64, n_total: usize,
+                                   row_elems: usize) -> c_int;
+    pub fn pmx_mgpu_merkle_2to1_dev(g: *mut pmx_mgpu, d_nodes: *const *mut u64, d_top: *const *mut u64, n_leaves: usize) -> c_int;
+    pub fn pmx_mgpu_merkle_2to1(g: *mut pmx_mgpu, leaves: *const u64, n_leaves: usize, root: *mut u64) -> c_int;
+    // diagnostics
+    pub fn pmx_diag_int_valu_peak(device: c_int, seconds: f64, out: *mut pmx_valu_peak) -> c_int;
 }

@@ -15,27 +15,39 @@ fn check(rc: i32) {
     }
 }
 
-/// Device context shared by all sponges cloned from one config.
+/// Device context of one (config contents, device), taken from the library's process-wide cache: every sponge made
+/// from an equal config - however many times `new` is called - shares one set of device tables (pmx_ctx_acquire).
+/// The host-buffer entry points serialise on a lock inside the context, so sharing it across threads is sound.
 struct Ctx(*mut ffi::pmx_ctx);
 unsafe impl Send for Ctx {}
-impl Drop for Ctx { fn drop(&mut self) { unsafe { ffi::pmx_ctx_destroy(self.0); } } }
+unsafe impl Sync for Ctx {}
+impl Drop for Ctx { fn drop(&mut self) { unsafe { ffi::pmx_ctx_release(self.0); } } }
 
 fn limbs<F: PrimeField>(v: &[F]) -> *const u64 { v.as_ptr() as *const u64 }        // F is [u64;4] Montgomery
 fn limbs_mut<F: PrimeField>(v: &mut [F]) -> *mut u64 { v.as_mut_ptr() as *mut u64 }
 
-fn make_ctx<F: PrimeField>(p: &PoseidonConfig<F>, device: i32) -> Arc<Ctx> {
+/// Flattens a `PoseidonConfig` into the C view and hands it to `f` (the pointers are borrowed for the call only).
+fn with_c_config<F: PrimeField, R>(p: &PoseidonConfig<F>, f: impl FnOnce(&ffi::pmx_config) -> R) -> R {
     assert_eq!(core::mem::size_of::<F>(), 32, "4-limb Montgomery fields only");
     let ark: Vec<F> = p.ark.iter().flatten().copied().collect();
     let mds: Vec<F> = p.mds.iter().flatten().copied().collect();
     let mut modulus = [0u64; 4];
     modulus.copy_from_slice(F::MODULUS.as_ref());
-    let cfg = ffi::pmx_config {
+    f(&ffi::pmx_config {
         full_rounds: p.full_rounds as u32, partial_rounds: p.partial_rounds as u32, alpha: p.alpha,
         rate: p.rate as u32, capacity: p.capacity as u32, modulus, ark: limbs(&ark), mds: limbs(&mds),
-    };
-    let mut h = core::ptr::null_mut();
-    check(unsafe { ffi::pmx_ctx_create(&cfg, device, &mut h) });
-    Arc::new(Ctx(h))
+    })
+}
+
+/// `CryptographicSponge::new` calls this once per sponge (the reference clones ~4 KB of parameters there,
+/// src/poseidon/mod.rs:219-230): the cost here is flattening + hashing the constants; the table derivation, the
+/// device allocation and the upload happen once per distinct config and device.
+fn make_ctx<F: PrimeField>(p: &PoseidonConfig<F>, device: i32) -> Arc<Ctx> {
+    with_c_config(p, |cfg| {
+        let mut h = core::ptr::null_mut();
+        check(unsafe { ffi::pmx_ctx_acquire(cfg, device, &mut h) });
+        Arc::new(Ctx(h))
+    })
 }
 
 /// `PoseidonSponge` with the permutation on an MI355X; same public fields as `poseidon::PoseidonSponge`.
@@ -136,17 +148,57 @@ impl<F: PrimeField> SpongeExt for Mi355xPoseidonSponge<F> {
     fn into_state(self) -> Self::State { PoseidonSpongeState { state: self.state, mode: self.mode } }
 }
 
+/// All GPUs of this process as one device group (pmx_mgpu_create = ncclCommInitAll): contiguous shards, no collective on
+/// the permutation, RCCL for the gather of device-resident results and for the subtree roots of the sharded tree.
+struct Group(*mut ffi::pmx_mgpu);
+unsafe impl Send for Group {}
+impl Drop for Group { fn drop(&mut self) { unsafe { ffi::pmx_mgpu_destroy(self.0); } } }
+
 /// The data-parallel entry points: n sponges / n messages / one Merkle tree per call.
-pub struct BatchPoseidon<F: PrimeField> { ctx: Arc<Ctx>, t: usize, _f: core::marker::PhantomData<F> }
+pub struct BatchPoseidon<F: PrimeField> { ctx: Arc<Ctx>, group: Option<Group>, t: usize, _f: core::marker::PhantomData<F> }
 
 impl<F: PrimeField> BatchPoseidon<F> {
     pub fn new(p: &PoseidonConfig<F>, device: i32) -> Self {
-        Self { ctx: make_ctx(p, device), t: p.rate + p.capacity, _f: Default::default() }
+        Self { ctx: make_ctx(p, device), group: None, t: p.rate + p.capacity, _f: Default::default() }
     }
-    /// `permute` on every `t`-element state of `states` (len = n*t), in place.
+    /// The same over `n_devices` GPUs of this node (0 = all visible ones): `permute` and `merkle_root` shard their input.
+    pub fn new_multi(p: &PoseidonConfig<F>, n_devices: i32) -> Self {
+        let n = if n_devices == 0 { unsafe { ffi::pmx_device_count() } } else { n_devices };
+        let group = with_c_config(p, |cfg| {
+            let mut g = core::ptr::null_mut();
+            check(unsafe { ffi::pmx_mgpu_create(cfg, n, core::ptr::null(), &mut g) });
+            Group(g)
+        });
+        Self { ctx: make_ctx(p, 0), group: Some(group), t: p.rate + p.capacity, _f: Default::default() }
+    }
+    /// Ranks RCCL actually joined (1 without a group).
+    pub fn ranks(&self) -> usize {
+        match &self.group {
+            None => 1,
+            Some(g) => {
+                let mut info = core::mem::MaybeUninit::<ffi::pmx_mgpu_info>::zeroed();
+                check(unsafe { ffi::pmx_mgpu_get_info(g.0, info.as_mut_ptr()) });
+                unsafe { info.assume_init() }.comm_ranks as usize
+            }
+        }
+    }
+    /// `permute` on every `t`-element state of `states` (len = n*t), in place; sharded over the group's devices if any.
     pub fn permute(&self, states: &mut [F]) {
         assert_eq!(states.len() % self.t, 0);
-        check(unsafe { ffi::pmx_permute_batch(self.ctx.0, limbs_mut(states), states.len() / self.t) });
+        let n = states.len() / self.t;
+        match &self.group {
+            Some(g) => check(unsafe { ffi::pmx_mgpu_permute_batch(g.0, limbs_mut(states), n) }),
+            None => check(unsafe { ffi::pmx_permute_batch(self.ctx.0, limbs_mut(states), n) }),
+        }
+    }
+    /// Root of the 2-to-1 tree over `leaves` (power of two): one subtree per device, roots gathered over RCCL.
+    pub fn merkle_root(&self, leaves: &[F]) -> F {
+        let mut root = [F::zero()];
+        match &self.group {
+            Some(g) => check(unsafe { ffi::pmx_mgpu_merkle_2to1(g.0, limbs(leaves), leaves.len(), limbs_mut(&mut root)) }),
+            None => check(unsafe { ffi::pmx_merkle_2to1(self.ctx.0, limbs(leaves), leaves.len(), core::ptr::null_mut(), limbs_mut(&mut root)) }),
+        }
+        root[0]
     }
     /// per row: `new; absorb(row); squeeze_native_field_elements(out_len)`
     pub fn hash(&self, rows: &[F], in_len: usize, out_len: usize) -> Vec<F> {

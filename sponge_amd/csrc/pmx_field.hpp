@@ -493,7 +493,20 @@ PMX_FN void cols_compress(Cols &t) {
     }
 }
 
-// Montgomery reduction of compressed columns (each < 2^30): norm result, B < value / (p 2^261) + 1
+// the same for columns lo .. hi only (the ones a long dot product would overflow; matrix_row in pmx_permute.hpp)
+template <int LO, int HI>
+PMX_FN void cols_compress_range(Cols &t) {
+#pragma unroll
+    for (int k = LO; k <= HI; ++k) {
+        t.c[k + 1] += t.c[k] >> kW;
+        t.c[k] &= kMask;
+    }
+}
+
+// Montgomery reduction of 18 columns, compressed or not: column k is consumed as (carry from below + its own sum), so
+// the only requirement is that no column overflows 64 bits once its up to nine m_j p_i products and the carry (< 2^35)
+// are added - callers bound their column sums accordingly (matrix_row; tests/test_hostcheck.py replays the worst case).
+// Norm result, B < value / (p 2^261) + 1.
 PMX_FN Fe cols_redc(Cols &t, const FieldRt &f) {
 #pragma unroll
     for (int k = 0; k < kN; ++k) {

@@ -193,13 +193,21 @@ PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, co
 // The scratch holds elements 0..T-2 only: the last element / matrix row is peeled off the rolled loops and handled
 // with a static index, which keeps the array at 2.25 (T-1) KiB - at t = 9 that is what lets 8 waves (2 per SIMD)
 // share a CU's 160 KiB of LDS instead of 7.
+// Column budget of a T-term row on normalised operands (every limb < 2^29, a product < 2^58, 64 products per 64-bit
+// column): column k receives min(k+1, 17-k) products per term and, in the reduction, as many m_j p_i products, so up to
+// six terms need no carry propagation at all (col 8: 54 + 9 = 63), and a longer row overflows only its middle columns
+// 6 .. 10.  Those five are compressed once, after kRowMidTerm terms; everything else - including the final carry
+// propagation - is left to cols_redc, which consumes each column together with the carry from below.  Per 9-term row:
+// 20 carry instructions instead of 136.  tests/test_hostcheck.py replays the worst case (all limbs 2^29 - 1).
+constexpr int kRowFreeTerms = 6, kRowMidTerm = 5, kRowMidLo = 6, kRowMidHi = 10;
 template <int T>
 PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
+    static_assert(T <= 9, "one mid-row compression covers up to 9 terms");
     Cols acc;
     cols_zero(acc);
-    static_for<0, T>([&](auto j) {   // operands are norm here: 5 terms (45 products < 2^58) per compression
+    static_for<0, T>([&](auto j) {
         cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
-        if ((j % 5 == 4 && j + 1 < T) || j == T - 1) cols_compress(acc);
+        if constexpr (T > kRowFreeTerms && j == kRowMidTerm - 1) cols_compress_range<kRowMidLo, kRowMidHi>(acc);
     });
     return cols_redc(acc, f);
 }

@@ -114,11 +114,13 @@ struct DuplexSpongeMode {
     bool operator==(const DuplexSpongeMode &o) const { return tag == o.tag && index == o.index; }
 };
 
-// pmx_ctx owner: one validated config resident on one GPU
+// pmx_ctx holder: one validated config resident on one GPU, taken from the library's process-wide cache
+// (pmx_ctx_acquire): sponges made from equal configs - each PoseidonSponge::make copies its PoseidonConfig, like
+// CryptographicSponge::new clones the parameters (src/poseidon/mod.rs:219-230) - share one set of device tables.
 class Context {
 public:
-    Context(const pmx_config &c, int device) { check(pmx_ctx_create(&c, device, &h_)); }
-    ~Context() { pmx_ctx_destroy(h_); }
+    Context(const pmx_config &c, int device) { check(pmx_ctx_acquire(&c, device, &h_)); }
+    ~Context() { pmx_ctx_release(h_); }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     pmx_ctx *get() const { return h_; }

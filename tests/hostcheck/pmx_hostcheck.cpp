@@ -354,6 +354,41 @@ extern "C" void hc_worst_column(int terms, uint32_t amax, uint32_t bmax, uint64_
     *lo = (uint64_t)worst;
 }
 
+// matrix_row<T> (pmx_permute.hpp) replayed with 128-bit columns and every limb of every operand, of p and of every m at
+// 2^29 - 1: the largest value any of its 18 columns holds at any point, same schedule constants as the kernel code.
+extern "C" void hc_worst_matrix_row(int terms, uint64_t *hi, uint64_t *lo) {
+    unsigned __int128 c[2 * kN] = {0}, worst = 0;
+    auto note = [&]() {
+        for (int k = 0; k < 2 * kN; ++k)
+            if (c[k] > worst) worst = c[k];
+    };
+    const unsigned __int128 prod = (unsigned __int128)kMask * kMask;
+    for (int j = 0; j < terms; ++j) {
+        for (int i = 0; i < kN; ++i)
+            for (int l = 0; l < kN; ++l) c[i + l] += prod;
+        note();
+        if (terms > kRowFreeTerms && j == kRowMidTerm - 1) {
+            for (int k = kRowMidLo; k <= kRowMidHi; ++k) {
+                c[k + 1] += c[k] >> kW;
+                c[k] &= kMask;
+            }
+            note();
+        }
+    }
+    for (int k = 0; k < kN; ++k) {   // cols_redc
+        for (int jj = 0; jj < kN; ++jj) c[k + jj] += prod;
+        note();
+        c[k + 1] += c[k] >> kW;
+        note();
+    }
+    for (int k = kN; k < 2 * kN - 1; ++k) {
+        c[k + 1] += c[k] >> kW;
+        note();
+    }
+    *hi = (uint64_t)(worst >> 64);
+    *lo = (uint64_t)worst;
+}
+
 // Same for mont_sqr with every limb of the operand equal to `amax` (cross products use the doubled limb).
 extern "C" void hc_worst_sqr_column(uint32_t amax, uint64_t *hi, uint64_t *lo) {
     unsigned __int128 worst = 0, acc = 0;

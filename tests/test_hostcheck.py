@@ -33,6 +33,7 @@ def hc():
     lib.hc_worst_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_sqr_column.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_tab_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.hc_worst_matrix_row.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_tab_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
@@ -110,6 +111,18 @@ def test_shifted_table_products_match_bigint(hc, p):
         for n in (2, 8):
             a, c, s = pick(), [pick() for _ in range(n)], [pick() for _ in range(n)]
             assert run(3, n, [a], c, s, n) == [(a * ci + si) % p for ci, si in zip(c, s)], n
+
+
+def test_matrix_row_columns_cannot_overflow(hc):
+    """The explicit-column rows of the wide engines (t = 6 .. 9) propagate carries only where they must: no compression
+    up to six terms, columns 6 .. 10 once for longer rows, the rest inside the reduction.  Replay of the exact schedule
+    with every limb (operands, p, m) at 2^29 - 1: every column stays below 2^64 for every row length in use."""
+    hi, lo = np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint64)
+    for terms in range(1, 10):
+        hc.hc_worst_matrix_row(terms, hi.ctypes.data, lo.ctypes.data)
+        assert int(hi[0]) == 0, terms
+    hc.hc_worst_matrix_row(9, hi.ctypes.data, lo.ctypes.data)
+    assert int(lo[0]) > (1 << 63)            # ... and the budget is really used (the replay is not vacuous)
 
 
 def test_table_column_accumulators_cannot_overflow(hc):
