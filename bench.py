@@ -166,11 +166,22 @@ def main():
     import sponge_amd as S
     from sponge_amd import _lib, mgpu, synth
 
+    # PMX_BENCH_REHEARSAL=1: a dry run of the N > 1 code path on a box with ONE GPU (tools/gpu_n2_rehearsal.sh): the ranks
+    # share the visible GPUs round-robin, torch.distributed runs on gloo and the gathers are staged through the host
+    # (RCCL refuses two ranks on one device).  It exercises the sharding, the step functions, the verification of the
+    # gathered buffer and the JSON line; its numbers mean nothing and the line says so.
+    rehearsal = os.environ.get("PMX_BENCH_REHEARSAL", "") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctl = torch.device("cpu") if rehearsal else dev      # where the control-plane tensors of torch.distributed live
 
     field_name, rate, alpha, rf, rp, log2_one, log2_total_multi, seed, desc = WORKLOADS[args.workload]
     t = rate + 1
@@ -199,7 +210,9 @@ def main():
 
     # ---- the engine: one context at N = 1, the C ABI's device group (RCCL) at N > 1 -------------------------------------
     group, group_error, rccl = None, None, None
-    if world > 1:
+    if world > 1 and rehearsal:
+        rccl = {"ranks": None, "version": None, "via": "REHEARSAL on gloo, gathers staged through the host - not a measurement"}
+    elif world > 1:
         uid = [mgpu.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0, device=dev)
         try:
@@ -223,7 +236,12 @@ def main():
         stream = torch.cuda.current_stream()
 
     def torch_all_gather(local, out):
-        dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
+        if rehearsal:
+            parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
+            dist.all_gather(parts, local.cpu())
+            out.view(-1).copy_(torch.cat([p.reshape(-1) for p in parts]))
+        else:
+            dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
 
     def fresh_inputs():
         """this rank's shard of the global seeded input, uploaded (used for the timed buffers and again for the check)"""
@@ -325,7 +343,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
     steps_ms = ev0.elapsed_time(ev_k)       # ... the K steps without the epilogue gather
 
-    times = torch.tensor([elapsed, dev_ms / 1e3, steps_ms / 1e3], dtype=torch.float64, device=dev)
+    times = torch.tensor([elapsed, dev_ms / 1e3, steps_ms / 1e3], dtype=torch.float64, device=ctl)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, dev_s, steps_s = float(times[0]), float(times[1]), float(times[2])
@@ -334,7 +352,7 @@ def main():
     verify = None
     if not args.no_verify:
         verify = run_verification(locals())
-        flag = torch.tensor([1 if verify["ok"] else 0], device=dev)
+        flag = torch.tensor([1 if verify["ok"] else 0], device=ctl)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         verify["ok"] = bool(int(flag))
@@ -367,7 +385,7 @@ def main():
                        "arithmetic": "255-bit modular integers as 9 x 29-bit limbs in u32, Montgomery form",
                        "units_total": n_total, "units_per_gpu": n, "permutations_per_step": units_per_step,
                        "gather": (args.gather if (world > 1 and not merkle and not hashing) else ("roots" if merkle and world > 1 else "n/a")),
-                       "sharding": f"contiguous x{world}",
+                       "sharding": f"contiguous x{world}", **({"REHEARSAL": "ranks share one GPU, gloo: not a measurement"} if rehearsal else {}),
                        "series": "N=1 runs configs[1] (2^20 states); N>1 shard configs[3]'s 2^24 states (strong scaling)"
                                  if args.workload == "c2" and baseline_cfg else None},
             "rccl": rccl,
