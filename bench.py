@@ -80,6 +80,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--total-log2", type=int, default=None, help="log2 of the units (states / leaves / rows) over ALL ranks")
+    ap.add_argument("--total-units", type=int, default=None, help="units over ALL ranks, any number (ragged shards)")
     ap.add_argument("--states-per-gpu-log2", type=int, default=None, help="log2 of the units PER rank (weak scaling)")
     ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
                     help="N>1 permutation batches: 'final' = one RCCL all-gather of the result shards after the K steps (inside "
@@ -188,7 +189,9 @@ def main():
     merkle = args.workload == "c5"
     hashing = args.workload in HASH_SHAPES
     # ---- sizes: the BASELINE configuration of this (workload, N), unless overridden -----------------------------------
-    if args.total_log2 is not None:
+    if args.total_units is not None:
+        n_total, scaling, baseline_cfg = args.total_units, "strong", None
+    elif args.total_log2 is not None:
         n_total, scaling, baseline_cfg = 1 << args.total_log2, "strong", None
     elif args.states_per_gpu_log2 is not None:
         n_total, scaling, baseline_cfg = world << args.states_per_gpu_log2, "weak", None

@@ -12,7 +12,10 @@ Encodings follow src/absorb.rs line by line; two of them lean on ark-ff (not in 
     each read as a little-endian integer (always < p) - used for byte slices after the u64-LE length prefix
     (src/absorb.rs:135-139);
   * `Fp::serialize_compressed` (ark-serialize): ceil(MODULUS_BIT_SIZE/8) bytes, little-endian canonical value
-    (src/absorb.rs:152-154).
+    (src/absorb.rs:152-154);
+  * curve points (src/absorb.rs:232-254) go through ark-ec's `ToConstraintField`: a twisted-Edwards affine point is
+    [x, y], a short-Weierstrass affine point [x, y, infinity as 0/1] over the base field; their byte form is that
+    Vec<BaseField> under `serialize_compressed` (ark-serialize: u64-LE element count, then every element).
 """
 from __future__ import annotations
 
@@ -168,6 +171,51 @@ class Fp(Absorb):
             if a.f.modulus != field.modulus:
                 raise ValueError("Trying to absorb non-native field elements (field_cast returned None)")
             dest.append(a.v)
+
+
+class _AffinePoint(Absorb):
+    """Shared by TEAffine / SWAffine (src/absorb.rs:232-254): `self.to_field_elements()` over the curve's base field,
+    then - bytes: that vector under serialize_compressed; field elements: field_cast::<BaseField, F>(..).unwrap(),
+    i.e. absorbing a point whose base field is not the sponge's field panics."""
+
+    def __init__(self, base_field: Field):
+        self.base = base_field
+
+    def to_field_elements(self) -> List[int]:
+        raise NotImplementedError
+
+    def to_sponge_bytes(self, dest):
+        elems = self.to_field_elements()
+        dest += len(elems).to_bytes(8, "little")           # Vec<T>::serialize: the length as u64
+        for v in elems:
+            dest += v.to_bytes((self.base.modulus_bit_size + 7) // 8, "little")
+
+    def to_sponge_field_elements(self, field, dest):
+        if field.modulus != self.base.modulus:
+            raise ValueError("Trying to absorb non-native field elements (field_cast returned None)")
+        dest.extend(self.to_field_elements())
+
+
+class TEAffine(_AffinePoint):
+    """Twisted-Edwards affine point (x, y), canonical integers of `base_field` (src/absorb.rs:232-242)."""
+
+    def __init__(self, x: int, y: int, base_field: Field):
+        super().__init__(base_field)
+        self.x, self.y = x % base_field.modulus, y % base_field.modulus
+
+    def to_field_elements(self):
+        return [self.x, self.y]
+
+
+class SWAffine(_AffinePoint):
+    """Short-Weierstrass affine point (x, y, infinity) (src/absorb.rs:244-254)."""
+
+    def __init__(self, x: int, y: int, infinity: bool, base_field: Field):
+        super().__init__(base_field)
+        self.x, self.y, self.infinity = x % base_field.modulus, y % base_field.modulus, bool(infinity)
+
+    def to_field_elements(self):
+        return [self.x, self.y, 1 if self.infinity else 0]
 
 
 class Seq(Absorb):

@@ -2,7 +2,7 @@
 // CryptographicSponge::fork (src/lib.rs:149-157) and the absorb! / collect_sponge_* macros (src/absorb.rs:319-355).
 // Overload set:  to_sponge_bytes(x, dest)  /  to_sponge_field_elements(field, x, dest)  for
 //   uint8_t..uint64_t, unsigned __int128, int8_t..int64_t, bool, Fp (native), std::vector<A>, std::optional<A>,
-//   WithLength<std::vector<A>>.
+//   WithLength<std::vector<A>>, TEAffine / SWAffine (curve points as their base-field coordinates, src/absorb.rs:232-254).
 // Two encodings rest on ark-ff / ark-serialize behaviour outside the reference tree: byte slices are packed
 // (MODULUS_BIT_SIZE-1)/8 bytes per element after a u64-LE length prefix (src/absorb.rs:135-139), and an Fp
 // serialises as ceil(MODULUS_BIT_SIZE/8) little-endian bytes of its canonical value (:153-155).
@@ -40,6 +40,27 @@ inline void to_sponge_bytes(const FpOf &e, std::vector<uint8_t> &dest) {   // se
     const auto c = fp_into_bigint(e.f, e.x);
     const uint8_t *b = reinterpret_cast<const uint8_t *>(c.data());
     dest.insert(dest.end(), b, b + (e.f.modulus_bit_size() + 7) / 8);
+}
+// Curve points (src/absorb.rs:232-254): ark-ec's ToConstraintField gives [x, y] for a twisted-Edwards affine point and
+// [x, y, infinity] for a short-Weierstrass one, over the curve's base field `f`.
+struct TEAffine {
+    const Field &f;
+    Fp x, y;
+    std::vector<FpOf> to_field_elements() const { return {FpOf{f, x}, FpOf{f, y}}; }
+};
+struct SWAffine {
+    const Field &f;
+    Fp x, y;
+    bool infinity;
+    std::vector<FpOf> to_field_elements() const {
+        return {FpOf{f, x}, FpOf{f, y}, FpOf{f, fp_from_bigint(f, {infinity ? 1ull : 0ull, 0, 0, 0})}};
+    }
+};
+template <class P, std::enable_if_t<std::is_same_v<P, TEAffine> || std::is_same_v<P, SWAffine>, int> = 0>
+inline void to_sponge_bytes(const P &pt, std::vector<uint8_t> &dest) {   // Vec<BaseField>::serialize_compressed
+    const auto elems = pt.to_field_elements();
+    to_sponge_bytes((uint64_t)elems.size(), dest);
+    for (const FpOf &e : elems) to_sponge_bytes(e, dest);
 }
 template <class A>
 inline void to_sponge_bytes(const std::vector<A> &v, std::vector<uint8_t> &dest) {
@@ -79,6 +100,13 @@ inline void to_sponge_field_elements(const Field &f, I x, std::vector<Fp> &dest)
 inline void to_sponge_field_elements(const Field &f, bool x, std::vector<Fp> &dest) { dest.push_back(fp_from_u128(f, x ? 1 : 0)); }
 inline void to_sponge_field_elements(const Field &f, const FpOf &e, std::vector<Fp> &dest) {
     if (e.f == f) dest.push_back(e.x);   // field_cast; non-native single elements are dropped (`let _ =`, :157)
+}
+template <class P, std::enable_if_t<std::is_same_v<P, TEAffine> || std::is_same_v<P, SWAffine>, int> = 0>
+inline void to_sponge_field_elements(const Field &f, const P &pt, std::vector<Fp> &dest) {
+    for (const FpOf &e : pt.to_field_elements()) {   // field_cast::<BaseField, F>(..).unwrap()
+        if (!(e.f == f)) throw Error(PMX_ERR_ARG, "Trying to absorb non-native field elements");
+        dest.push_back(e.x);
+    }
 }
 // &[u8]: u64-LE length, then the bytes, packed (src/absorb.rs:135-139 + ark-ff ToConstraintField for [u8])
 inline void to_sponge_field_elements(const Field &f, const std::vector<uint8_t> &bytes, std::vector<Fp> &dest) {

@@ -68,6 +68,21 @@ static void test_absorb_encodings_host() {
     const B a1{1, 2, 3, 4}, a2{5, 6}, b1{1, 2}, b2{3, 4, 5, 6};
     EXPECT(collect_sponge_bytes(with_length(a1), with_length(a2)) != collect_sponge_bytes(with_length(b1), with_length(b2)));
     EXPECT(collect_sponge_bytes(a1, a2) == collect_sponge_bytes(b1, b2));
+    // curve points (src/absorb.rs:232-254): base-field coordinates, [x, y] / [x, y, infinity]; bytes = u64 count + elements
+    const TEAffine te{Fr, fp_from_u64(Fr, 7), fp_from_u64(Fr, 9)};
+    const SWAffine sw{Fr, fp_from_u64(Fr, 7), fp_from_u64(Fr, 9), true};
+    auto tf = collect_sponge_field_elements(Fr, te), sf = collect_sponge_field_elements(Fr, sw);
+    EXPECT(tf.size() == 2 && tf[0] == fp_from_u64(Fr, 7) && tf[1] == fp_from_u64(Fr, 9));
+    EXPECT(sf.size() == 3 && sf[2] == fp_from_u64(Fr, 1));
+    auto tb = collect_sponge_bytes(te);
+    EXPECT(tb.size() == 8 + 64 && tb[0] == 2 && tb[8] == 7 && tb[40] == 9);
+    EXPECT(collect_sponge_bytes(sw).size() == 8 + 96);
+    const Field Bn = Field::bn254_fr();
+    bool refused = false;
+    try {
+        (void)collect_sponge_field_elements(Fr, TEAffine{Bn, fp_from_u64(Bn, 1), fp_from_u64(Bn, 2)});
+    } catch (const Error &) { refused = true; }
+    EXPECT(refused);
 }
 
 static void test_macros_and_fork_on_gpu() {

@@ -33,6 +33,9 @@ def pairs():
         (A.Opt(None), ("opt", None)), (A.Opt(A.U8(3)), ("opt", ("u8", 3))),
         (A.WithLength(A.Bytes(bytes([1, 2, 3, 4]))), ("with_len", ("vec", "u8", [1, 2, 3, 4]))),
         (A.WithLength(A.Seq([A.U64(5), A.U64(6)])), ("with_len", ("vec", "u64", [5, 6]))),
+        (A.TEAffine(11, P - 3, F), ("te", 11, P - 3)), (A.SWAffine(5, 6, False, F), ("sw", 5, 6, False)),
+        (A.SWAffine(0, 1, True, F), ("sw", 0, 1, True)),
+        (A.Seq([A.TEAffine(1, 2, F), A.TEAffine(3, 4, F)]), ("vec", "te", [("te", 1, 2), ("te", 3, 4)])),
     ]
 
 
@@ -48,6 +51,19 @@ def test_byte_packing_boundaries():
         assert len(A.Bytes(bytes(n)).to_sponge_field_elements_as_vec(F)) == want
     assert all(v < 2**248 for v in A.Bytes(bytes([255]) * 200).to_sponge_field_elements_as_vec(F))
     assert len(A.Bytes(bytes(54)).to_sponge_field_elements_as_vec(S.BN254_FR)) == 2
+
+
+def test_curve_points():
+    """src/absorb.rs:232-254: a point absorbs as its base-field coordinates ([x, y] / [x, y, infinity]); a point over
+    another field panics (field_cast(..).unwrap()); the byte form carries the Vec's u64 element count."""
+    te, sw = A.TEAffine(7, 9, F), A.SWAffine(7, 9, False, F)
+    assert te.to_sponge_field_elements_as_vec(F) == [7, 9]
+    assert sw.to_sponge_field_elements_as_vec(F) == [7, 9, 0]
+    assert A.SWAffine(0, 1, True, F).to_sponge_field_elements_as_vec(F)[2] == 1
+    assert len(te.to_sponge_bytes_as_vec()) == 8 + 2 * 32 and te.to_sponge_bytes_as_vec()[:8] == (2).to_bytes(8, "little")
+    assert len(sw.to_sponge_bytes_as_vec()) == 8 + 3 * 32
+    with pytest.raises(ValueError):
+        A.TEAffine(7, 9, S.BN254_FR).to_sponge_field_elements_as_vec(F)
 
 
 def test_macros():

@@ -18,7 +18,7 @@ for l in sys.stdin:
 run c4_final --workload c2
 run c2_step --workload c2 --total-log2 18 --gather step
 run c2_none --workload c2 --total-log2 18 --gather none
-run c2_ragged --workload c2 --states-per-gpu-log2 12
+run c2_ragged --workload c2 --total-units 100003
 run c3 --workload c3
 run c5 --workload c5 --total-log2 21
 run h3 --workload h3
