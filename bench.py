@@ -239,12 +239,24 @@ def main():
         stream = torch.cuda.current_stream()
 
     def torch_all_gather(local, out):
+        """The gather through torch.distributed (fallback / rehearsal): rank r's rows land at r's span of `out`.  Shards may
+        be ragged (n_total not a multiple of the world size): every rank pads to the longest shard."""
+        spans = [mgpu.shard_bounds(out.shape[0], world, r) for r in range(world)]
+        longest = max(c for _, c in spans)
+        row = tuple(local.shape[1:])
+        padded = local
+        if local.shape[0] != longest:
+            padded = torch.zeros((longest,) + row, dtype=local.dtype, device=local.device)
+            padded[:local.shape[0]] = local
         if rehearsal:
-            parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
-            dist.all_gather(parts, local.cpu())
-            out.view(-1).copy_(torch.cat([p.reshape(-1) for p in parts]))
+            parts = [torch.empty((longest,) + row, dtype=local.dtype) for _ in range(world)]
+            dist.all_gather(parts, padded.cpu())
         else:
-            dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
+            flat = torch.empty((world * longest,) + row, dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(flat.view(-1), padded.contiguous().view(-1))
+            parts = [flat[r * longest:(r + 1) * longest] for r in range(world)]
+        for r, (s_r, c_r) in enumerate(spans):
+            out[s_r:s_r + c_r].copy_(parts[r][:c_r])
 
     def fresh_inputs():
         """this rank's shard of the global seeded input, uploaded (used for the timed buffers and again for the check)"""

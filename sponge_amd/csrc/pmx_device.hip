@@ -564,17 +564,31 @@ __global__ void __launch_bounds__(256, 2)
     const bool active = g < n;
     Fe s = fe_zero();                                        // state = [0, l, r]
     if (active && (q == 1 || q == 2)) s = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(in + (g * 2 + (q - 1)) * 4)), f);
-    const uint32_t role = q < 3 ? q : 2;                     // the idle lane shadows lane 2 (its result is never read)
+    const uint32_t role = q < 3 ? q : 2;                     // lane 3 reads lane 2's entries; in the uniform rounds it shadows lane 2 (its result is never read)
+    const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
+    auto quad = [](const Fe &v, auto lane) {                 // element held by lane `lane` of this quad, in every lane
+        constexpr int sel = decltype(lane)::value * 0x55;    // quad_perm [l, l, l, l]
+        Fe r;
+#pragma unroll
+        for (int w = 0; w < kN; ++w) r.l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[w], sel, 0xf, 0xf, false);
+        return r;
+    };
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *entry = coop + ((size_t)r * 3 + role) * kCoopElems * kFeStride;
+        if (kCoopFolded<ALPHA> && r >= first_partial && r < last_partial) {   // sparse round, three multiplications deep
+            const Fe x = quad(fe_add_lazy(s, fe_const(entry)), std::integral_constant<int, 0>{});
+            const Fe res_a = coop_fold_a(q, x, entry, f);
+            const Fe res_b = coop_fold_b(q, s, res_a, entry, f);
+            Fe xpow = res_b;
+#pragma unroll
+            for (int k = 0; k < kCoopExtraSquarings<ALPHA>; ++k) xpow = mont_sqr(xpow, f);
+            s = coop_fold_c(q, s, quad(xpow, std::integral_constant<int, 3>{}), res_a, quad(res_b, std::integral_constant<int, 1>{}),
+                            quad(res_b, std::integral_constant<int, 2>{}), f);
+            continue;
+        }
         const Fe z = coop_pre<ALPHA>(s, entry, is_full_round(r, c) || q == 0, c, one, f);
         Fe zz[3];
-#pragma unroll
-        for (int w = 0; w < kN; ++w) {
-            zz[0].l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)z.l[w], 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
-            zz[1].l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)z.l[w], 0x55, 0xf, 0xf, false);   // quad_perm [1,1,1,1]
-            zz[2].l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)z.l[w], 0xaa, 0xf, 0xf, false);   // quad_perm [2,2,2,2]
-        }
+        static_for<0, 3>([&](auto j) { zz[j] = quad(z, j); });
         s = coop_post(zz, entry, f);
     }
     const Abi digest = fe_to_abi(s, f);
@@ -774,9 +788,14 @@ hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
 
-// Levels of at most this many compressions run on the cooperative kernel: up to here the one-lane-per-state kernel
-// has at most a quarter of a wave per SIMD and is bound by the 51k-multiply dependent chain of a single permutation.
-static constexpr size_t kCoopMaxUnits = 16384;
+// Levels of at most this many compressions run on the cooperative kernel: the one-lane-per-state kernel has at most
+// half a wave per SIMD there and is bound by the 51k-multiply dependent chain of a single permutation (0.145 ms),
+// while the quad kernel's chain is 23k multiplies (0.067 ms alone on a SIMD, 0.12 ms with two waves per SIMD at 32768
+// compressions; A/B at 16384 vs 32768 on a 2^21-leaf tree: 4.70 vs 4.65 ms).
+#ifndef PMX_COOP_MAX_UNITS
+#define PMX_COOP_MAX_UNITS 32768
+#endif
+static constexpr size_t kCoopMaxUnits = PMX_COOP_MAX_UNITS;
 
 template <int ALPHA>
 static hipError_t launch_compress_coop(const DevConfig &c, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {

@@ -362,6 +362,42 @@ PMX_FN Fe coop_post(const Fe (&z)[3], const uint32_t *entry, const FieldRt &f) {
     return mont_dot<3>(z, row, f);
 }
 
+// ---- folded sparse rounds (S-box exponents with alpha - 1 a power of two: 5 and 17) ---------------------------------
+// What the narrow tree levels pay is the LENGTH of the dependent chain of one permutation, and in the uniform form above
+// a sparse round is four multiplications deep: x^2, x^4, x^5, then the row.  The fourth lane of the quad is idle, and
+//     s_0' = m00 x^5 + v_1 s_1 + v_2 s_2 = x^4 (x m00) + (v_1 s_1 + v_2 s_2),      s_i' = s_i + x^4 (x w_i)
+// so the constants can be multiplied in WHILE the spare lane squares - three multiplications deep instead of four:
+//     stage A   lane 3: x x           lanes 0, 1, 2: x m00, x w_1, x w_2                        (one multiplication)
+//     stage B   lane 3: x^2 x^2       lanes 1, 2: v_1 s_1, v_2 s_2                              (one multiplication)
+//     (alpha = 17: lane 3 squares twice more)
+//     stage C   lanes 0, 1, 2: x^(alpha-1) (stage A) + (v_1 s_1 + v_2 s_2 | s_1 | s_2)          (one multiply-add)
+// 495 multiplies per sparse round instead of 738 (alpha = 5).  The identity lanes are then plain accumulators as in
+// permute_opt (uncapped, bounded by opt_schedule_lane_headroom: each round adds less than (1 + 1.2 / Q) p).
+// Table entry of a sparse round (pmx_prepare.hpp): lane 0: [e_k, m00, 0, 0], lane q = 1, 2: [0, w_q, v_q, 0].
+template <int ALPHA>
+constexpr bool kCoopFolded = ALPHA == 5 || ALPHA == 17;
+template <int ALPHA>
+constexpr int kCoopExtraSquarings = ALPHA == 17 ? 2 : 0;
+
+PMX_FN Fe fe_select(bool c, const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int w = 0; w < kN; ++w) r.l[w] = c ? a.l[w] : b.l[w];
+    return r;
+}
+
+// x = s_0 + e_k (lazy: limbs < 2^30, below 6.1 p) as seen by every lane of the quad
+PMX_FN Fe coop_fold_a(uint32_t q, const Fe &x, const uint32_t *entry, const FieldRt &f) {
+    return mont_mul(x, fe_select(q == 3, x, fe_const(entry + kFeStride)), f);
+}
+PMX_FN Fe coop_fold_b(uint32_t q, const Fe &s, const Fe &res_a, const uint32_t *entry, const FieldRt &f) {
+    return mont_mul(fe_select(q == 3, res_a, s), fe_select(q == 3, res_a, fe_const(entry + 2 * kFeStride)), f);
+}
+// xpow = x^(alpha-1) from lane 3, p1 / p2 = stage B of lanes 1 / 2
+PMX_FN Fe coop_fold_c(uint32_t q, const Fe &s, const Fe &xpow, const Fe &res_a, const Fe &p1, const Fe &p2, const FieldRt &f) {
+    return mont_mul_add(xpow, res_a, fe_select(q == 0, fe_add_lazy(p1, p2), s), f);
+}
+
 // Dense schedule, width known only at run time.  `State` provides get(i) / set(i, x) on the current state and
 // set_next(i, x) / swap() on a second buffer (LDS on the device).  Element loops are rolled.
 template <int ALPHA, class State>

@@ -291,8 +291,15 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
                 } else if (r + 1 == half + rp) {
                     for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, bdense_i + (q * 3 + j) * kFeStride);
                 } else {
-                    const uint32_t *sp = sparse_i + (r - half) * 5 * kFeStride;   // row0[3], w[2]
-                    if (q == 0) {
+                    const uint32_t *sp = sparse_i + (r - half) * 5 * kFeStride;   // row0[3] = (m00, v_1, v_2), w[2]
+                    if (cfg->alpha == 5 || cfg->alpha == 17) {   // folded sparse rounds (pmx_permute.hpp: coop_fold_*)
+                        if (q == 0) {
+                            put(r, q, 1, sp);                             // stage A: x * m00
+                        } else {
+                            put(r, q, 1, sp + (3 + q - 1) * kFeStride);   // stage A: x * w_q
+                            put(r, q, 2, sp + q * kFeStride);             // stage B: s_q * v_q
+                        }
+                    } else if (q == 0) {
                         for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, sp + j * kFeStride);
                     } else {
                         put(r, q, 1, sp + (3 + q - 1) * kFeStride);   // w_q * z_0

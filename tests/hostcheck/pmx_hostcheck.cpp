@@ -67,7 +67,31 @@ static void permute_opt_t(const Prepared &pp, uint64_t *states, size_t n) {
     }
 }
 
-// cooperative t = 3 schedule, three "lanes" simulated in turn
+// cooperative t = 3 schedule, the four lanes of a quad simulated in turn (lane 3: the squaring lane of the folded sparse
+// rounds; in the uniform rounds it only shadows lane 2)
+template <int ALPHA>
+static void coop_permute_one(Fe (&s)[4], const uint32_t *coop, const Prepared &pp) {
+    const uint32_t first_partial = pp.c.half_full, last_partial = pp.c.half_full + pp.c.partial_rounds - 1;
+    for (uint32_t r = 0; r < pp.c.total_rounds; ++r) {
+        auto entry = [&](int q) { return coop + ((size_t)r * 3 + (q < 3 ? q : 2)) * kCoopElems * kFeStride; };
+        if (kCoopFolded<ALPHA> && r >= first_partial && r < last_partial) {
+            const Fe x = fe_add_lazy(s[0], fe_const(entry(0)));
+            Fe res_a[4], res_b[4], xpow;
+            for (int q = 0; q < 4; ++q) res_a[q] = coop_fold_a(q, x, entry(q), pp.f);
+            for (int q = 0; q < 4; ++q) res_b[q] = coop_fold_b(q, s[q], res_a[q], entry(q), pp.f);
+            xpow = res_b[3];
+            for (int k = 0; k < kCoopExtraSquarings<ALPHA>; ++k) xpow = mont_sqr(xpow, pp.f);
+            for (int q = 0; q < 4; ++q) s[q] = coop_fold_c(q, s[q], xpow, res_a[q], res_b[1], res_b[2], pp.f);
+            for (int q = 0; q < 3; ++q) PMX_TRACK(q == 0 ? 0 : 1, s[q], pp.f);
+            continue;
+        }
+        Fe z[3], nxt[4];
+        for (int q = 0; q < 3; ++q) z[q] = coop_pre<ALPHA>(s[q], entry(q), is_full_round(r, pp.c) || q == 0, pp.c, pp.one, pp.f);
+        for (int q = 0; q < 4; ++q) nxt[q] = coop_post(z, entry(q), pp.f);
+        for (int q = 0; q < 4; ++q) s[q] = nxt[q];
+    }
+}
+
 extern "C" int hc_permute_coop(const pmx_config *cfg, uint64_t *states, size_t n) {
     Prepared pp;
     std::string err;
@@ -76,20 +100,12 @@ extern "C" int hc_permute_coop(const pmx_config *cfg, uint64_t *states, size_t n
     if (!pp.has_opt || pp.t != 3) return PMX_ERR_UNSUPPORTED;
     const uint32_t *coop = pp.consts.data() + pp.coop_offset;
     for (size_t k = 0; k < n; ++k) {
-        Fe s[3];
+        Fe s[4];
         for (int i = 0; i < 3; ++i) s[i] = fe_from_abi(load_abi(states + (k * 3 + i) * 4), pp.f);
-        for (uint32_t r = 0; r < pp.c.total_rounds; ++r) {
-            Fe z[3], nxt[3];
-            for (int q = 0; q < 3; ++q) {
-                const uint32_t *entry = coop + ((size_t)r * 3 + q) * kCoopElems * kFeStride;
-                const bool sbox = is_full_round(r, pp.c) || q == 0;
-                if (pp.c.alpha == 5) z[q] = coop_pre<5>(s[q], entry, sbox, pp.c, pp.one, pp.f);
-                else if (pp.c.alpha == 17) z[q] = coop_pre<17>(s[q], entry, sbox, pp.c, pp.one, pp.f);
-                else z[q] = coop_pre<0>(s[q], entry, sbox, pp.c, pp.one, pp.f);
-            }
-            for (int q = 0; q < 3; ++q) nxt[q] = coop_post(z, coop + ((size_t)r * 3 + q) * kCoopElems * kFeStride, pp.f);
-            for (int q = 0; q < 3; ++q) s[q] = nxt[q];
-        }
+        s[3] = fe_zero();
+        if (pp.c.alpha == 5) coop_permute_one<5>(s, coop, pp);
+        else if (pp.c.alpha == 17) coop_permute_one<17>(s, coop, pp);
+        else coop_permute_one<0>(s, coop, pp);
         for (int i = 0; i < 3; ++i) store_abi(states + (k * 3 + i) * 4, fe_to_abi(s[i], pp.f));
     }
     return PMX_OK;

@@ -320,7 +320,7 @@ def test_other_rate_capacity_splits(rate, capacity):
 def test_merkle_tree_with_rate3_capacity0_crosses_the_narrow_level_threshold():
     """Width 3 as (rate 3, capacity 0): 2-to-1 compression is permute([l, r, 0])[0] there, which the quad kernel of
     the narrow levels (state [0, l, r], lane 1; capacity 1 only) does not compute - every level of this split has to
-    take the one-lane-per-state kernel.  A 2^16-leaf tree crosses the 16384-compression switch; all nodes against the
+    take the one-lane-per-state kernel.  A 2^16-leaf tree lies entirely below the 32768-compression switch to the quad kernel; all nodes against the
     C restatement, and the batched path verifier against the tree."""
     from oracle import cref
     from oracle import poseidon_oracle as O

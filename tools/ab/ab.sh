@@ -9,7 +9,7 @@ for W in ${WORKLOADS:-c2}; do
 for round in 1 2 3; do
   for v in new old; do
     cp tools/ab/libposeidon_$v.so sponge_amd/libposeidon_mi355x.so
-    python bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('$W $v round $round %.4g perm/s  kernel_ms %.4f'%(d['value'],d['roofline']['kernel_ms']))"
+    python bench.py --workload $W --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('$W $v round $round %.4g perm/s  kernel_ms %.4f'%(d['value'],d['roofline']['kernel_ms']))"
   done
 done
 done
