@@ -209,7 +209,7 @@ def main():
 
     # ---- per-run integer-VALU roofline of THIS device, before anything is timed -----------------------------------------
     peak = _lib.PmxValuPeak()
-    _lib.check(_lib.lib().pmx_diag_int_valu_peak(local_rank, 0.05, peak))
+    _lib.check(_lib.lib().pmx_diag_int_valu_peak(local_rank, 0.1, peak))
 
     # ---- the engine: one context at N = 1, the C ABI's device group (RCCL) at N > 1 -------------------------------------
     group, group_error, rccl = None, None, None
@@ -413,8 +413,9 @@ def main():
                          "note": "integer-VALU bound, not HBM bound (DESIGN.md): see int_valu"},
             "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": peak.lane_mads_per_s,
                          "unit": "lane-instr/s", "frac": mad_rate / peak.lane_mads_per_s, "mads_per_permutation": mads,
-                         "peak_source": "pmx_diag_int_valu_peak on this device just before the warm-up (%d launches, median of the later half)" % peak.launches,
-                         "peak_best_launch": peak.best_lane_mads_per_s, "shader_clock_hz": peak.shader_clock_hz,
+                         "peak_source": "pmx_diag_int_valu_peak on this device just before the warm-up (%d launches of a dense v_mad_u64_u32 loop, two forms, median of the later half of each)" % peak.launches,
+                         "peak_best_launch": peak.best_lane_mads_per_s,
+                         "peak_by_carry_destination": {"vcc": peak.lane_mads_per_s_vcc, "sgpr_pair": peak.lane_mads_per_s_sgpr}, "shader_clock_hz": peak.shader_clock_hz,
                          "theoretical_peak": peak.theoretical_lane_mads_per_s, "compute_units": peak.compute_units,
                          "frac_of_theoretical": mad_rate / peak.theoretical_lane_mads_per_s if peak.theoretical_lane_mads_per_s else None},
             "gather_ms": 1e3 * (dev_s - steps_s) if world > 1 else None,

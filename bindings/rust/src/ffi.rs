@@ -33,6 +33,8 @@ pub struct pmx_mgpu_info {
 #[repr(C)]
 pub struct pmx_valu_peak {
     pub lane_mads_per_s: f64,
+    pub lane_mads_per_s_vcc: f64,
+    pub lane_mads_per_s_sgpr: f64,
     pub best_lane_mads_per_s: f64,
     pub shader_clock_hz: f64,
     pub theoretical_lane_mads_per_s: f64,

@@ -217,7 +217,9 @@ int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t n_leaves, u
  * launches; shader_clock_hz from s_memtime / s_memrealtime inside the kernel; theoretical = CUs x 4 SIMDs x 16
  * lanes per clock (a half-rate instruction) x that clock. */
 typedef struct pmx_valu_peak {
-    double lane_mads_per_s;
+    double lane_mads_per_s;             /* the faster of the two forms below */
+    double lane_mads_per_s_vcc;         /* carry-out of every multiply written to VCC */
+    double lane_mads_per_s_sgpr;        /* ... to an allocator-chosen SGPR pair (what compiled kernels do) */
     double best_lane_mads_per_s;
     double shader_clock_hz;
     double theoretical_lane_mads_per_s;

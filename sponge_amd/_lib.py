@@ -52,7 +52,8 @@ class PmxMgpuInfo(ctypes.Structure):
 
 class PmxValuPeak(ctypes.Structure):
     _fields_ = [
-        ("lane_mads_per_s", ctypes.c_double), ("best_lane_mads_per_s", ctypes.c_double),
+        ("lane_mads_per_s", ctypes.c_double), ("lane_mads_per_s_vcc", ctypes.c_double),
+        ("lane_mads_per_s_sgpr", ctypes.c_double), ("best_lane_mads_per_s", ctypes.c_double),
         ("shader_clock_hz", ctypes.c_double), ("theoretical_lane_mads_per_s", ctypes.c_double),
         ("compute_units", ctypes.c_int), ("launches", ctypes.c_int),
     ]

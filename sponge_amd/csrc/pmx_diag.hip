@@ -18,6 +18,9 @@ using namespace pmx;
 
 namespace {
 
+// CARRY_IN_VCC: where the instruction's (unused) carry-out goes - VCC, or an SGPR pair the register allocator picks, which
+// is what compiled kernels use.  Both forms are timed; the faster one is the peak.
+template <bool CARRY_IN_VCC>
 __global__ void __launch_bounds__(256) mad_chain_kernel(unsigned *out, unsigned long long *stamps, int trips, unsigned seed) {
     unsigned long long a[8];
     const unsigned x = threadIdx.x * 2654435761u + seed, y = x ^ 0x9E3779B9u;
@@ -28,7 +31,14 @@ __global__ void __launch_bounds__(256) mad_chain_kernel(unsigned *out, unsigned 
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[k]) : "v"(x), "v"(y) : "vcc");
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (CARRY_IN_VCC) {
+                    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[k]) : "v"(x), "v"(y) : "vcc");
+                } else {
+                    unsigned long long carry;
+                    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(a[k]), "=s"(carry) : "v"(x), "v"(y));
+                }
+            }
         }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -67,22 +77,27 @@ extern "C" int pmx_diag_int_valu_peak(int device, double seconds, pmx_valu_peak 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    std::vector<double> rates;
-    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<double> rates[2];
     int launches = 0;
-    while (e == hipSuccess) {
-        e = hipEventRecord(e0, st);
-        hipLaunchKernelGGL(mad_chain_kernel, dim3(blocks), dim3(256), 0, st, d_out, d_stamps, trips, 1u + launches);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(e1, st);
-        if (e == hipSuccess) e = hipEventSynchronize(e1);
-        float ms = 0;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        if (e != hipSuccess) break;
-        rates.push_back((double)blocks * 256 * 64.0 * trips / (ms * 1e-3));
-        ++launches;
-        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-        if (elapsed >= seconds && launches >= 4) break;
+    for (int form = 0; form < 2 && e == hipSuccess; ++form) {
+        const auto t_begin = std::chrono::steady_clock::now();
+        int n_form = 0;
+        while (e == hipSuccess) {
+            e = hipEventRecord(e0, st);
+            if (form == 0) hipLaunchKernelGGL(mad_chain_kernel<true>, dim3(blocks), dim3(256), 0, st, d_out, d_stamps, trips, 1u + launches);
+            else hipLaunchKernelGGL(mad_chain_kernel<false>, dim3(blocks), dim3(256), 0, st, d_out, d_stamps, trips, 1u + launches);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) break;
+            rates[form].push_back((double)blocks * 256 * 64.0 * trips / (ms * 1e-3));
+            ++launches;
+            ++n_form;
+            const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+            if (elapsed >= seconds / 2 && n_form >= 4) break;
+        }
     }
     std::vector<unsigned long long> stamps((size_t)blocks * 2);
     if (e == hipSuccess) e = hipMemcpy(stamps.data(), d_stamps, stamps.size() * 8, hipMemcpyDeviceToHost);
@@ -92,11 +107,18 @@ extern "C" int pmx_diag_int_valu_peak(int device, double seconds, pmx_valu_peak 
     if (d_out) (void)hipFree(d_out);
     if (d_stamps) (void)hipFree(d_stamps);
     if (e != hipSuccess) return hip_fail(e, "pmx_diag_int_valu_peak");
-    // the clock ramps over the first launches: the figure is the median of the second half of the window
-    std::vector<double> tail(rates.begin() + rates.size() / 2, rates.end());
-    std::sort(tail.begin(), tail.end());
-    out->lane_mads_per_s = tail[tail.size() / 2];
-    out->best_lane_mads_per_s = *std::max_element(rates.begin(), rates.end());
+    // the clock ramps over the first launches: per form the figure is the median of the second half of its window
+    double med[2] = {0, 0}, best = 0;
+    for (int form = 0; form < 2; ++form) {
+        std::vector<double> tail(rates[form].begin() + rates[form].size() / 2, rates[form].end());
+        std::sort(tail.begin(), tail.end());
+        med[form] = tail[tail.size() / 2];
+        best = std::max(best, *std::max_element(rates[form].begin(), rates[form].end()));
+    }
+    out->lane_mads_per_s = std::max(med[0], med[1]);
+    out->lane_mads_per_s_vcc = med[0];
+    out->lane_mads_per_s_sgpr = med[1];
+    out->best_lane_mads_per_s = best;
     std::vector<double> clocks;
     for (int b = 0; b < blocks; ++b)
         if (stamps[2 * b + 1]) clocks.push_back((double)stamps[2 * b] / (double)stamps[2 * b + 1] * 100e6);
