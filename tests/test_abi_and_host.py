@@ -40,6 +40,14 @@ def test_rust_binding_source_declares_the_whole_header():
     assert not missing, missing
 
 
+def test_integration_md_shows_the_binding_files_verbatim():
+    """INTEGRATION.md embeds bindings/rust/{build.rs, src/ffi.rs, src/mod.rs}: the document and the files must not drift."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for rel in ("build.rs", os.path.join("src", "ffi.rs"), os.path.join("src", "mod.rs")):
+        text = open(os.path.join(ROOT, "bindings", "rust", rel)).read().rstrip("\n")
+        assert "```rust\n" + text + "\n```" in doc, rel
+
+
 def test_no_device_means_loud_failure_not_fallback():
     if _lib.lib().pmx_device_count() > 0:
         pytest.skip("a GPU is present")
