@@ -147,6 +147,7 @@ static int ctx_free(pmx_ctx *ctx) {
     }
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->d_consts) (void)hipFree(ctx->d_consts);
     delete ctx;
     return PMX_OK;
@@ -399,6 +400,8 @@ extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, ui
     return PMX_OK;
 }
 
+static constexpr size_t kSmallCallBytes = 64 * 1024;
+
 static int check_modes(const pmx_ctx *ctx, const uint32_t *tag, const uint32_t *index, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         if (tag[i] > PMX_MODE_SQUEEZING) return set_error(PMX_ERR_ARG, "sponge %zu: mode tag %u is neither Absorbing nor Squeezing", i, tag[i]);
@@ -419,6 +422,33 @@ static int sponge_host(pmx_ctx *ctx, uint64_t *states, uint32_t *tag, uint32_t *
     std::lock_guard<std::mutex> lock(ctx->host_lock);
     size_t st_bytes = 0, io_bytes = 0;
     if ((rc = batch_bytes(n, ctx->t, &st_bytes)) || (rc = batch_bytes(n, len, &io_bytes))) return rc;
+    // A handful of sponges (the single PoseidonSponge of the trait shims is n = 1): the call is all latency, and eight
+    // separate copies from pageable memory cost as much as the permutation itself.  Pack [states | io | tag | index] into
+    // the context's page-locked block: one copy in, the kernel, one copy out.
+    const size_t words = (n * 4 + 15) / 16 * 16, packed = st_bytes + io_bytes + 2 * words;
+    if (packed <= kSmallCallBytes) {
+        if (!ctx->pinned) PMX_HIP(hipHostMalloc(&ctx->pinned, kSmallCallBytes, hipHostMallocDefault));
+        void *d = nullptr;
+        if ((rc = ctx_scratch(ctx, 0, packed, &d))) return rc;
+        char *h = (char *)ctx->pinned, *dd = (char *)d;
+        const size_t o_io = st_bytes, o_tag = st_bytes + io_bytes, o_idx = o_tag + words;
+        std::memcpy(h, states, st_bytes);
+        if (absorb) std::memcpy(h + o_io, in, io_bytes);
+        std::memcpy(h + o_tag, tag, n * 4);
+        std::memcpy(h + o_idx, index, n * 4);
+        StreamDrain drain{ctx};
+        PMX_HIP(hipMemcpyAsync(dd, h, packed, hipMemcpyHostToDevice, ctx->stream));
+        if (absorb) rc = pmx_sponge_absorb_batch_dev(ctx, (uint64_t *)dd, (uint32_t *)(dd + o_tag), (uint32_t *)(dd + o_idx), (const uint64_t *)(dd + o_io), len, n, ctx->stream);
+        else rc = pmx_sponge_squeeze_batch_dev(ctx, (uint64_t *)dd, (uint32_t *)(dd + o_tag), (uint32_t *)(dd + o_idx), (uint64_t *)(dd + o_io), len, n, ctx->stream);
+        if (rc) return rc;
+        PMX_HIP(hipMemcpyAsync(h, dd, packed, hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(states, h, st_bytes);
+        std::memcpy(tag, h + o_tag, n * 4);
+        std::memcpy(index, h + o_idx, n * 4);
+        if (!absorb && io_bytes) std::memcpy(out, h + o_io, io_bytes);
+        return PMX_OK;
+    }
     void *d_st = nullptr, *d_io = nullptr, *d_tag = nullptr, *d_idx = nullptr;
     if ((rc = ctx_scratch(ctx, 0, st_bytes, &d_st))) return rc;
     if ((rc = ctx_scratch(ctx, 1, io_bytes, &d_io))) return rc;

@@ -18,6 +18,7 @@ struct pmx_ctx {
     hipStream_t stream2 = nullptr;   // second lane of the pinned-memory pipeline
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // grow-only device staging for the host-buffer entry points
     size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void *pinned = nullptr;          // page-locked host block for small host-buffer calls (allocated on first use)
     // The host-buffer entry points use the staging buffers and the two streams above: one caller at a time.  Contexts
     // handed out by pmx_ctx_acquire are shared between sponges (and threads), so those entry points take this lock;
     // the *_dev entry points only read the immutable fields and enqueue on the caller's stream.
