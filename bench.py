@@ -239,24 +239,9 @@ def main():
         stream = torch.cuda.current_stream()
 
     def torch_all_gather(local, out):
-        """The gather through torch.distributed (fallback / rehearsal): rank r's rows land at r's span of `out`.  Shards may
-        be ragged (n_total not a multiple of the world size): every rank pads to the longest shard."""
-        spans = [mgpu.shard_bounds(out.shape[0], world, r) for r in range(world)]
-        longest = max(c for _, c in spans)
-        row = tuple(local.shape[1:])
-        padded = local
-        if local.shape[0] != longest:
-            padded = torch.zeros((longest,) + row, dtype=local.dtype, device=local.device)
-            padded[:local.shape[0]] = local
-        if rehearsal:
-            parts = [torch.empty((longest,) + row, dtype=local.dtype) for _ in range(world)]
-            dist.all_gather(parts, padded.cpu())
-        else:
-            flat = torch.empty((world * longest,) + row, dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(flat.view(-1), padded.contiguous().view(-1))
-            parts = [flat[r * longest:(r + 1) * longest] for r in range(world)]
-        for r, (s_r, c_r) in enumerate(spans):
-            out[s_r:s_r + c_r].copy_(parts[r][:c_r])
+        """The gather through torch.distributed (fallback / rehearsal): rank r's rows at r's span of `out`, ragged or not."""
+        from sponge_amd import distributed as D
+        D.all_gather_rows(local, out, host_staged=rehearsal)
 
     def fresh_inputs():
         """this rank's shard of the global seeded input, uploaded (used for the timed buffers and again for the check)"""

@@ -1,7 +1,11 @@
-"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU
+"""torch.distributed helpers around the sharded batch: one process per GPU (backend "nccl" = RCCL over xGMI on the GPU
 box, "gloo" in the CPU tests).  Sponge states are independent (reference src/poseidon/mod.rs:62-183 has no
 cross-state data flow), so the batch is cut into contiguous shards and there is NO collective on the data
-path; RCCL is used only for the final gather of results (and for the 32-byte subtree roots of the Merkle mode).
+path; a collective is used only for the final gather of results (and for the 32-byte subtree roots of the Merkle mode).
+
+The product path for this is the C ABI's device group (pmx_mgpu_*, sponge_amd/mgpu.py), which talks to RCCL itself.
+What lives here is what bench.py falls back to if a group cannot be formed, what its single-GPU rehearsal uses, and
+what the world-size-2 gloo tests run on CPU.
 """
 from __future__ import annotations
 
@@ -32,6 +36,29 @@ def all_gather_equal(local: torch.Tensor, out: torch.Tensor | None = None, async
     else:
         work = dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), async_op=async_op)
     return (out, work) if async_op else out
+
+
+def all_gather_rows(local: torch.Tensor, out: torch.Tensor, host_staged: bool = False) -> None:
+    """Rank r's rows land at r's span of `out` ([n_total, ...]; spans = shard_bounds(n_total, world, r)).  Shards may be
+    ragged: every rank pads to the longest one.  host_staged: gather CPU copies (gloo cannot move device tensors)."""
+    world = dist.get_world_size()
+    spans = [shard_bounds(out.shape[0], world, r) for r in range(world)]
+    longest = max(c for _, c in spans)
+    row = tuple(local.shape[1:])
+    assert local.shape[0] == spans[dist.get_rank()][1], "this rank's shard has the wrong length"
+    padded = local
+    if local.shape[0] != longest:
+        padded = torch.zeros((longest,) + row, dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+    if host_staged:
+        parts = [torch.empty((longest,) + row, dtype=local.dtype) for _ in range(world)]
+        dist.all_gather(parts, padded.cpu())
+    else:
+        flat = torch.empty((world * longest,) + row, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(flat.view(-1), padded.contiguous().view(-1))
+        parts = [flat[r * longest:(r + 1) * longest] for r in range(world)]
+    for r, (s_r, c_r) in enumerate(spans):
+        out[s_r:s_r + c_r].copy_(parts[r][:c_r])
 
 
 class _Done:

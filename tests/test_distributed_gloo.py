@@ -50,6 +50,13 @@ def _worker(rank, port, results):
             return torch.from_numpy(nodes[-1].view(np.int64).copy())
 
         root = D.merkle_root_sharded(torch.from_numpy(leaves.view(np.int64)), subtree_root)
+        # 3. ragged shards (2 * N_PER_RANK + 1 states over 2 ranks): bench.py's fallback gather, every rank's copy checked
+        n_ragged = WORLD * N_PER_RANK + 1
+        r_start, r_count = D.shard_bounds(n_ragged, WORLD, rank)
+        mine = synth.random_elements(f, r_count * t, SEED + 2, offset=r_start * t).reshape(r_count, t, 4)
+        whole = torch.zeros((n_ragged, t, 4), dtype=torch.int64)
+        D.all_gather_rows(torch.from_numpy(cr.permute_batch(mine, threads=1).view(np.int64)), whole, host_staged=True)
+        results[f"ragged{rank}"] = whole.numpy().view(np.uint64).copy()
         if rank == 0:
             results["gathered"] = gathered.numpy().view(np.uint64).copy()
             results["root"] = root.numpy().view(np.uint64).copy()
@@ -68,6 +75,10 @@ def test_two_rank_shard_gather_and_merkle():
     assert np.array_equal(results["gathered"].reshape(-1, 3, 4), cr.permute_batch(whole, threads=2))
     leaves = synth.random_elements(f, WORLD * N_PER_RANK, SEED + 1)
     assert np.array_equal(results["root"].reshape(4), cr.merkle(leaves, threads=2)[-1])
+    n_ragged = WORLD * N_PER_RANK + 1
+    want = cr.permute_batch(synth.random_elements(f, n_ragged * 3, SEED + 2).reshape(n_ragged, 3, 4), threads=2)
+    for rank in range(WORLD):
+        assert np.array_equal(results[f"ragged{rank}"].reshape(-1, 3, 4), want), rank
 
 
 @pytest.mark.parametrize("n,world", [(10, 3), (8, 8), (7, 8), (1 << 24, 8), (5, 1)])
