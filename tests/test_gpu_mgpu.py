@@ -145,3 +145,10 @@ def test_shared_context_cache():
         outs.add(sp.squeeze_native_field_elements(1).tobytes())
         assert cfg.context()._h.value == ha
     assert len(outs) == 1
+    # idle contexts can be dropped at any time; live ones stay usable and a dropped config is simply rebuilt
+    d = S.poseidon_config_from_lfsr(S.BLS12_381_FR, 2, 257, 8, 13)
+    d.context().close()                                          # idle now
+    _lib.check(lib.pmx_ctx_cache_clear())
+    d._ctx.clear()
+    assert np.array_equal(d.context().permute_batch(st.reshape(1, 2, 4)[:, :1].repeat(3, axis=1)).shape, (1, 3, 4))
+    assert a.context()._h.value == ha                            # still referenced: untouched by the clear
