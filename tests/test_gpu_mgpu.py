@@ -58,7 +58,8 @@ def test_device_resident_shards_and_rccl_gather(n_total):
         start, count = g.local_span(n_total, l)
         shards.append(torch.from_numpy(whole[start:start + count].view(np.int64).copy()).to(f"cuda:{dev}"))
         alls.append(torch.zeros((n_total, 3, 4), dtype=torch.int64, device=f"cuda:{dev}"))
-    torch.cuda.synchronize()
+    for dev in g.devices:                     # the group's streams do not wait for torch's: finish the uploads and fills first
+        torch.cuda.synchronize(dev)
     g.permute_shards_dev([s.data_ptr() for s in shards], n_total)
     g.all_gather_dev([s.data_ptr() for s in shards], [a.data_ptr() for a in alls], n_total, 3)
     g.synchronize()
