@@ -400,6 +400,7 @@ PMX_FN Fe coop_fold_c(uint32_t q, const Fe &s, const Fe &xpow, const Fe &res_a, 
 
 // Dense schedule, width known only at run time.  `State` provides get(i) / set(i, x) on the current state and
 // set_next(i, x) / swap() on a second buffer (LDS on the device).  Element loops are rolled.
+constexpr uint32_t kRtLazyTerms = 3;
 template <int ALPHA, class State>
 PMX_FN void permute_dense_rt(State &st, uint32_t t, const uint32_t *ark, const uint32_t *mds, const Rounds &c,
                              const Fe &one, const FieldRt &f) {
@@ -419,14 +420,14 @@ PMX_FN void permute_dense_rt(State &st, uint32_t t, const uint32_t *ark, const u
             uint32_t pending = 0;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (uint32_t j = 0; j < t; ++j) {
-                cols_mul_acc(acc, st.get(j), fe_const(mds + ((size_t)i * t + j) * kFeStride));
-                if (++pending == 3) {   // at most 3 lazy terms per 64-bit column before re-compressing
+                if (pending == kRtLazyTerms) {   // at most 3 lazy terms (limbs < 2^30) per 64-bit column before re-compressing
                     cols_compress(acc);
                     pending = 0;
                 }
+                cols_mul_acc(acc, st.get(j), fe_const(mds + ((size_t)i * t + j) * kFeStride));
+                ++pending;
             }
-            if (pending) cols_compress(acc);
-            st.set_next(i, cols_redc(acc, f));
+            st.set_next(i, cols_redc(acc, f));   // the last <= 3 terms go into the reduction uncompressed (27 * 2^59 + 9 * 2^58 + carry < 2^64)
         }
         st.swap();
     }

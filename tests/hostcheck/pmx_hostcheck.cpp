@@ -405,6 +405,43 @@ extern "C" void hc_worst_matrix_row(int terms, uint64_t *hi, uint64_t *lo) {
     *lo = (uint64_t)worst;
 }
 
+// One row of permute_dense_rt (run-time width, lazily added operands: limbs < 2^30 against constants < 2^29) replayed the
+// same way: a full compression before every fourth term, the last <= 3 terms reduced uncompressed.
+extern "C" void hc_worst_dense_rt_row(int terms, uint64_t *hi, uint64_t *lo) {
+    unsigned __int128 c[2 * kN] = {0}, worst = 0;
+    auto note = [&]() {
+        for (int k = 0; k < 2 * kN; ++k)
+            if (c[k] > worst) worst = c[k];
+    };
+    const unsigned __int128 prod = (unsigned __int128)((1u << 30) - 1) * kMask, red = (unsigned __int128)kMask * kMask;
+    uint32_t pending = 0;
+    for (int j = 0; j < terms; ++j) {
+        if (pending == kRtLazyTerms) {
+            for (int k = 0; k < 2 * kN - 1; ++k) {
+                c[k + 1] += c[k] >> kW;
+                c[k] &= kMask;
+            }
+            pending = 0;
+        }
+        for (int i = 0; i < kN; ++i)
+            for (int l = 0; l < kN; ++l) c[i + l] += prod;
+        ++pending;
+        note();
+    }
+    for (int k = 0; k < kN; ++k) {
+        for (int jj = 0; jj < kN; ++jj) c[k + jj] += red;
+        note();
+        c[k + 1] += c[k] >> kW;
+        note();
+    }
+    for (int k = kN; k < 2 * kN - 1; ++k) {
+        c[k + 1] += c[k] >> kW;
+        note();
+    }
+    *hi = (uint64_t)(worst >> 64);
+    *lo = (uint64_t)worst;
+}
+
 // Same for mont_sqr with every limb of the operand equal to `amax` (cross products use the doubled limb).
 extern "C" void hc_worst_sqr_column(uint32_t amax, uint64_t *hi, uint64_t *lo) {
     unsigned __int128 worst = 0, acc = 0;

@@ -34,6 +34,7 @@ def hc():
     lib.hc_worst_sqr_column.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_tab_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_matrix_row.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.hc_worst_dense_rt_row.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_tab_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
@@ -123,6 +124,10 @@ def test_matrix_row_columns_cannot_overflow(hc):
         assert int(hi[0]) == 0, terms
     hc.hc_worst_matrix_row(9, hi.ctypes.data, lo.ctypes.data)
     assert int(lo[0]) > (1 << 63)            # ... and the budget is really used (the replay is not vacuous)
+    # rows of the run-time-width engine (lazy operands): compression before every fourth term, the tail left to the reduction
+    for terms in range(1, 17):
+        hc.hc_worst_dense_rt_row(terms, hi.ctypes.data, lo.ctypes.data)
+        assert int(hi[0]) == 0, terms
 
 
 def test_table_column_accumulators_cannot_overflow(hc):
