@@ -189,7 +189,10 @@ int pmx_mgpu_create_rank(const pmx_config *cfg, int device, int rank, int world,
 int pmx_mgpu_destroy(pmx_mgpu *g);
 int pmx_mgpu_get_info(const pmx_mgpu *g, pmx_mgpu_info *info);
 void *pmx_mgpu_stream(const pmx_mgpu *g, int local);     /* hipStream_t of local device `local` (NULL if out of range) */
-pmx_ctx *pmx_mgpu_ctx(const pmx_mgpu *g, int local);     /* its context (owned by the group) */
+/* Its context (owned by the group).  Any other per-shard work - the hash driver, absorb, squeeze - is the single-device
+ * *_dev entry point called with this context on pmx_mgpu_stream(g, local); pmx_mgpu_all_gather_dev then gathers the
+ * per-row outputs with row_elems = out_len. */
+pmx_ctx *pmx_mgpu_ctx(const pmx_mgpu *g, int local);
 int pmx_mgpu_synchronize(pmx_mgpu *g);
 
 /* PoseidonSponge::permute (src/poseidon/mod.rs:95-118) on n states in host memory, in place, sharded over the

@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from .poseidon import PoseidonConfig, c_config
+from .poseidon import Context, PoseidonConfig, c_config
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
@@ -89,6 +89,14 @@ class DeviceGroup:
     def stream(self, local: int = 0) -> int:
         """hipStream_t (as an integer) the group enqueues local device `local`'s work on."""
         return int(_lib.lib().pmx_mgpu_stream(self._h, local) or 0)
+
+    def context(self, local: int = 0) -> Context:
+        """The group's context of local device `local` (owned by the group): for the single-device *_dev entry points -
+        hash, absorb, squeeze - on this shard, enqueued on self.stream(local)."""
+        h = _lib.lib().pmx_mgpu_ctx(self._h, local)
+        if not h:
+            raise IndexError(local)
+        return Context.borrowed(self.cfg, self.devices[local], h)
 
     def local_span(self, n_total: int, local: int) -> Tuple[int, int]:
         return shard_bounds(n_total, self.world, self.first_rank + local)

@@ -181,9 +181,17 @@ class Context:
         _lib.check(_lib.lib().pmx_ctx_acquire(ctypes.byref(c), device, ctypes.byref(handle)))
         self._h = handle
 
+    @classmethod
+    def borrowed(cls, cfg: PoseidonConfig, device: int, handle: int) -> "Context":
+        """A view of a context somebody else owns (a device group's): never released from here."""
+        self = cls.__new__(cls)
+        self.cfg, self.device, self._h, self._borrowed = cfg, device, ctypes.c_void_p(handle), True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().pmx_ctx_release(self._h)
+            if not getattr(self, "_borrowed", False):
+                _lib.lib().pmx_ctx_release(self._h)
             self._h = None
 
     def __del__(self):

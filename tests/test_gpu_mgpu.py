@@ -69,6 +69,31 @@ def test_device_resident_shards_and_rccl_gather(n_total):
     g.close()
 
 
+def test_hash_driver_per_shard_then_gather():
+    """The absorb/squeeze batch driver sharded the same way: every rank hashes its rows with the single-device entry point
+    on the group's context and stream, the digests are gathered over RCCL (row_elems = out_len)."""
+    cfg, g = _group()
+    n_total, in_len, out_len = 50000 + 3, 5, 2
+    msgs = synth.random_elements(cfg.field, n_total * in_len, seed=0x5EED0044).reshape(n_total, in_len, 4)
+    d_in, d_out, d_all = [], [], []
+    for l, dev in enumerate(g.devices):
+        start, count = g.local_span(n_total, l)
+        d_in.append(torch.from_numpy(msgs[start:start + count].view(np.int64).copy()).to(f"cuda:{dev}"))
+        d_out.append(torch.zeros((count, out_len, 4), dtype=torch.int64, device=f"cuda:{dev}"))
+        d_all.append(torch.zeros((n_total, out_len, 4), dtype=torch.int64, device=f"cuda:{dev}"))
+    for dev in g.devices:
+        torch.cuda.synchronize(dev)
+    for l in range(g.n_local):
+        _, count = g.local_span(n_total, l)
+        g.context(l).hash_batch_dev(d_in[l].data_ptr(), in_len, d_out[l].data_ptr(), out_len, count, g.stream(l))
+    g.all_gather_dev([t.data_ptr() for t in d_out], [t.data_ptr() for t in d_all], n_total, out_len)
+    g.synchronize()
+    want = c_oracle(NAME).hash_batch(msgs, in_len, out_len, threads=0)
+    for l in range(g.n_local):
+        assert np.array_equal(d_all[l].cpu().numpy().view(np.uint64), want)
+    g.close()
+
+
 @pytest.mark.parametrize("log2_leaves", [0, 1, 5, 16])
 def test_sharded_merkle_root(log2_leaves):
     cfg, g = _group()
