@@ -178,3 +178,35 @@ def test_shared_context_cache():
     d._ctx.clear()
     assert np.array_equal(d.context().permute_batch(st.reshape(1, 2, 4)[:, :1].repeat(3, axis=1)).shape, (1, 3, 4))
     assert a.context()._h.value == ha                            # still referenced: untouched by the clear
+
+
+def test_shared_context_is_safe_across_threads():
+    """Sponges made from equal configs share one cached device context; its host-buffer entry points serialise on the
+    context's lock (ctypes drops the GIL during the calls, so these threads really overlap)."""
+    import threading
+    base = S.poseidon_config_from_lfsr(S.BLS12_381_FR, 2, 5, 8, 31)
+    msgs = synth.random_elements(S.BLS12_381_FR, 8 * 5, seed=0x5EED0045).reshape(8, 5, 4)
+    want = [c_oracle(NAME).hash_batch(msgs[i:i + 1], 5, 3, threads=1)[0] for i in range(8)]
+    batch = synth.random_elements(S.BLS12_381_FR, 3000 * 3, seed=0x5EED0046).reshape(3000, 3, 4)
+    want_batch = c_oracle(NAME).permute_batch(batch, threads=0)
+    errors = []
+
+    def worker(i):
+        try:
+            cfg = S.PoseidonConfig(base.field, base.full_rounds, base.partial_rounds, base.alpha, base.mds, base.ark, 2, 1)
+            for _ in range(20):
+                sp = S.PoseidonSponge.new(cfg)
+                sp.absorb(msgs[i])
+                if not np.array_equal(sp.squeeze_native_field_elements(3), want[i]):
+                    errors.append(("sponge", i))
+                if not np.array_equal(cfg.context().permute_batch(batch), want_batch):
+                    errors.append(("batch", i))
+        except Exception as e:                      # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
