@@ -97,10 +97,11 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
     g->ctx.assign(n_devices, nullptr);
     g->comm.assign(n_devices, nullptr);
     for (int l = 0; l < n_devices; ++l) {
-        g->device[l] = devices ? devices[l] : l;
-        if (g->device[l] < 0 || g->device[l] >= visible) { group_free(g); return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", g->device[l], visible); }
+        const int d = devices ? devices[l] : l;
+        g->device[l] = d;
+        if (d < 0 || d >= visible) { group_free(g); return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", d, visible); }
         for (int k = 0; k < l; ++k)
-            if (g->device[k] == g->device[l]) { group_free(g); return set_error(PMX_ERR_ARG, "device %d listed twice", g->device[l]); }
+            if (g->device[k] == d) { group_free(g); return set_error(PMX_ERR_ARG, "device %d listed twice", d); }
     }
     int rc = group_contexts(g, cfg);
     if (rc) { group_free(g); return rc; }
