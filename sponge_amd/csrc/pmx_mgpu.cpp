@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,7 +89,8 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
     *out = nullptr;
     const int visible = pmx_device_count();
     if (visible == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
-    if (n_devices <= 0 || n_devices > visible) return set_error(PMX_ERR_ARG, "n_devices %d out of range [1,%d]", n_devices, visible);
+    if (n_devices <= 0 || n_devices > visible || n_devices > PMX_MAX_LOCAL_DEVICES)
+        return set_error(PMX_ERR_ARG, "n_devices %d out of range [1,%d]", n_devices, visible < PMX_MAX_LOCAL_DEVICES ? visible : PMX_MAX_LOCAL_DEVICES);
     pmx_mgpu *g = new (std::nothrow) pmx_mgpu();
     if (!g) return set_error(PMX_ERR_ARG, "out of host memory");
     g->world = n_devices;
