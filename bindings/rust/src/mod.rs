@@ -207,6 +207,23 @@ impl<F: PrimeField> BatchPoseidon<F> {
         check(unsafe { ffi::pmx_hash_batch(self.ctx.0, limbs(rows), in_len, limbs_mut(&mut out), out_len, n) });
         out
     }
+    /// Authentication paths of `indices` over a node array made by `merkle`: `[k][depth]` siblings, bottom-up.
+    pub fn merkle_paths(&self, nodes: &[F], indices: &[u64]) -> Vec<F> {
+        let n_leaves = (nodes.len() + 1) / 2;
+        let depth = n_leaves.trailing_zeros() as usize;
+        let mut paths = vec![F::zero(); indices.len() * depth];
+        check(unsafe { ffi::pmx_merkle_paths(limbs(nodes), n_leaves, indices.as_ptr(), indices.len(), limbs_mut(&mut paths)) });
+        paths
+    }
+    /// `k` paths checked at once (one batched 2-to-1 hash per level): `true` where `leaves[i]` hashes up to `root`.
+    pub fn verify_paths(&self, leaves: &[F], indices: &[u64], paths: &[F], root: &F) -> Vec<bool> {
+        let k = leaves.len();
+        let depth = if k == 0 { 0 } else { paths.len() / k };
+        let mut ok = vec![0u8; k];
+        check(unsafe { ffi::pmx_merkle_verify_paths(self.ctx.0, limbs(leaves), indices.as_ptr(), limbs(paths), depth, k,
+                                                    limbs(core::slice::from_ref(root)), ok.as_mut_ptr()) });
+        ok.into_iter().map(|b| b != 0).collect()
+    }
     /// 2-to-1 tree over `leaves` (power of two): all nodes, leaves first, root last.
     pub fn merkle(&self, leaves: &[F]) -> Vec<F> {
         let mut nodes = vec![F::zero(); 2 * leaves.len() - 1];

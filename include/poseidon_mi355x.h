@@ -151,6 +151,17 @@ int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint6
 /* Device variant: d_nodes [2*n_leaves-1][4] must already hold the leaves in its first n_leaves rows. */
 int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_leaves, void *stream);
 
+/* Authentication paths over the node array pmx_merkle_2to1 produces ([2*n_leaves-1][4]: leaves, then every level, root
+ * last).  The container itself lives upstream (ark-crypto-primitives), not in arkworks-rs/sponge; a parent is
+ * (new; absorb([left, right]); squeeze_native(1))[0] as above.  depth = log2(n_leaves).
+ * pmx_merkle_paths: host-only gather - paths_out [k][depth][4] receives, for each indices[i], the sibling of the leaf and
+ * of each ancestor, bottom-up.
+ * pmx_merkle_verify_paths: k paths at once, one batched 2-to-1 hash call per level: ok_out[i] = 1 iff hashing leaves[i]
+ * up its path (indices[i] says left / right at each level) gives `root`. */
+int pmx_merkle_paths(const uint64_t *nodes, size_t n_leaves, const uint64_t *indices, size_t k, uint64_t *paths_out);
+int pmx_merkle_verify_paths(pmx_ctx *ctx, const uint64_t *leaves, const uint64_t *indices, const uint64_t *paths, size_t depth,
+                            size_t k, const uint64_t root[PMX_LIMBS], uint8_t *ok_out);
+
 /* ---- device groups: the batch sharded over the GPUs of one node -------------------------------------
  * The reference is single-threaded and has no distributed code; nothing in src/poseidon/mod.rs:62-183 couples one
  * sponge state to another, so n states are cut into `world` contiguous shards (pmx_shard_bounds), one per GPU, and

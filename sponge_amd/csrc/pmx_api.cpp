@@ -520,3 +520,45 @@ extern "C" int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_le
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
 }
+
+// ---- authentication paths ---------------------------------------------------------------------------------------------
+extern "C" int pmx_merkle_paths(const uint64_t *nodes, size_t n_leaves, const uint64_t *indices, size_t k, uint64_t *paths_out) {
+    if ((!nodes || !indices || !paths_out) && k) return set_error(PMX_ERR_ARG, "pmx_merkle_paths: null pointer");
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two");
+    size_t depth = 0;
+    while (((size_t)1 << depth) < n_leaves) ++depth;
+    for (size_t i = 0; i < k; ++i) {
+        if (indices[i] >= n_leaves) return set_error(PMX_ERR_ARG, "leaf index %llu out of range", (unsigned long long)indices[i]);
+        size_t idx = (size_t)indices[i], first = 0, width = n_leaves;   // first node of the current level, its width
+        for (size_t level = 0; level < depth; ++level) {
+            std::memcpy(paths_out + (i * depth + level) * 4, nodes + (first + (idx ^ 1)) * 4, 32);
+            first += width;
+            width /= 2;
+            idx >>= 1;
+        }
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_merkle_verify_paths(pmx_ctx *ctx, const uint64_t *leaves, const uint64_t *indices, const uint64_t *paths,
+                                       size_t depth, size_t k, const uint64_t root[PMX_LIMBS], uint8_t *ok_out) {
+    if (!ctx || ((!leaves || !indices || !ok_out) && k) || (!paths && k && depth) || !root)
+        return set_error(PMX_ERR_ARG, "pmx_merkle_verify_paths: null pointer");
+    if (ctx->dev.rounds.rate < 2) return set_error(PMX_ERR_CONFIG, "2-to-1 compression needs rate >= 2");
+    if (depth >= 64) return set_error(PMX_ERR_ARG, "depth out of range");
+    if (k == 0) return PMX_OK;
+    if (k > SIZE_MAX / 64) return set_error(PMX_ERR_ARG, "batch byte size overflows size_t");
+    std::vector<uint64_t> cur(leaves, leaves + k * 4), pairs(k * 8);
+    for (size_t level = 0; level < depth; ++level) {
+        for (size_t i = 0; i < k; ++i) {
+            const bool right = (indices[i] >> level) & 1;   // the running node is the right child at this level
+            const uint64_t *sib = paths + (i * depth + level) * 4;
+            std::memcpy(&pairs[i * 8 + (right ? 4 : 0)], &cur[i * 4], 32);
+            std::memcpy(&pairs[i * 8 + (right ? 0 : 4)], sib, 32);
+        }
+        int rc = pmx_hash_batch(ctx, pairs.data(), 2, cur.data(), 1, k);
+        if (rc) return rc;
+    }
+    for (size_t i = 0; i < k; ++i) ok_out[i] = std::memcmp(&cur[i * 4], root, 32) == 0 ? 1 : 0;
+    return PMX_OK;
+}

@@ -11,6 +11,9 @@ from typing import List
 
 import numpy as np
 
+import ctypes
+
+from . import _lib
 from .poseidon import PoseidonConfig
 
 
@@ -39,28 +42,31 @@ class MerkleTree:
     def path(self, leaf_index: int) -> np.ndarray:
         """Sibling of the leaf, then of each ancestor, bottom-up: [depth][4]."""
         assert 0 <= leaf_index < self.n_leaves
-        out = np.zeros((self.depth, 4), dtype=np.uint64)
-        idx = leaf_index
-        for level in range(self.depth):
-            out[level] = self.nodes[self.level_offset(level) + (idx ^ 1)]
-            idx >>= 1
+        return self.paths([leaf_index])[0]
+
+    def paths(self, leaf_indices) -> np.ndarray:
+        """[k][depth][4] for k leaves (pmx_merkle_paths: a host-side gather over the node array)."""
+        idx = np.ascontiguousarray(leaf_indices, dtype=np.uint64)
+        out = np.zeros((idx.shape[0], self.depth, 4), dtype=np.uint64)
+        nodes = np.ascontiguousarray(self.nodes, dtype=np.uint64)
+        _lib.check(_lib.lib().pmx_merkle_paths(ctypes.c_void_p(nodes.ctypes.data), self.n_leaves, ctypes.c_void_p(idx.ctypes.data),
+                                               idx.shape[0], ctypes.c_void_p(out.ctypes.data)))
         return out
 
 
 def verify_paths(parameters: PoseidonConfig, leaves: np.ndarray, indices, paths: np.ndarray, root: np.ndarray,
                  device: int = 0) -> np.ndarray:
-    """k authentication paths at once: leaves [k][4], indices [k], paths [k][depth][4] -> bool[k]."""
-    cur = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4).copy()
-    idx = np.asarray(indices, dtype=np.int64).copy()
+    """k authentication paths at once: leaves [k][4], indices [k], paths [k][depth][4] -> bool[k]
+    (pmx_merkle_verify_paths: one batched 2-to-1 hash call per level)."""
+    cur = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4)
+    idx = np.ascontiguousarray(indices, dtype=np.uint64)
     paths = np.ascontiguousarray(paths, dtype=np.uint64)
-    k, depth = cur.shape[0], paths.shape[1] if paths.ndim == 3 else 0
+    k = cur.shape[0]
+    depth = paths.shape[1] if paths.ndim == 3 else 0
+    root = np.ascontiguousarray(root, dtype=np.uint64).reshape(4)
+    ok = np.zeros(k, dtype=np.uint8)
     ctx = parameters.context(device)
-    for level in range(depth):
-        sib = paths[:, level, :]
-        right = (idx & 1).astype(bool)[:, None]             # current node is the right child
-        pair = np.empty((k, 2, 4), dtype=np.uint64)
-        pair[:, 0, :] = np.where(right, sib, cur)
-        pair[:, 1, :] = np.where(right, cur, sib)
-        cur = ctx.hash_batch(pair, 2, 1).reshape(k, 4)
-        idx >>= 1
-    return np.all(cur == np.asarray(root, dtype=np.uint64).reshape(1, 4), axis=1)
+    _lib.check(_lib.lib().pmx_merkle_verify_paths(ctx._h, ctypes.c_void_p(cur.ctypes.data), ctypes.c_void_p(idx.ctypes.data),
+                                                  ctypes.c_void_p(paths.ctypes.data) if paths.size else None, depth, k,
+                                                  ctypes.c_void_p(root.ctypes.data), ctypes.c_void_p(ok.ctypes.data)))
+    return ok.astype(bool)

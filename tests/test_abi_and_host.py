@@ -174,3 +174,31 @@ def test_unreduced_constants_are_rejected():
     rc, msg = _try_create(dict(full_rounds=8, partial_rounds=31, rate=2, capacity=1))
     if _lib.lib().pmx_device_count() == 0:            # a valid config then fails only for want of a device
         assert rc == _lib.PMX_ERR_HIP
+
+
+def test_merkle_paths_gather_is_host_only_and_matches_the_oracle_tree():
+    """pmx_merkle_paths over a node array built by the oracle's C restatement (no device involved): every sibling is
+    the node the index arithmetic says, recomputing the path with the oracle's 2-to-1 hash reaches the root."""
+    import ctypes
+    from oracle import cref
+    cr = cref.CRef(oracle_config("bls_t3_a5_8_31"))
+    m, depth = 64, 6
+    leaves = synth.random_elements(S.BLS12_381_FR, m, seed=99)
+    nodes = cr.merkle(leaves, threads=1)
+    idx = np.array([0, 1, 37, 63], dtype=np.uint64)
+    paths = np.zeros((4, depth, 4), dtype=np.uint64)
+    lib = _lib.lib()
+    _lib.check(lib.pmx_merkle_paths(ctypes.c_void_p(nodes.ctypes.data), m, ctypes.c_void_p(idx.ctypes.data), 4,
+                                    ctypes.c_void_p(paths.ctypes.data)))
+    for row, leaf_index in zip(paths, idx):
+        cur, i = leaves[int(leaf_index)], int(leaf_index)
+        for level in range(depth):
+            pair = np.stack([row[level], cur] if i & 1 else [cur, row[level]]).reshape(1, 2, 4)
+            cur = cr.hash_batch(pair, 2, 1, threads=1).reshape(4)
+            i >>= 1
+        assert np.array_equal(cur, nodes[-1])
+    bad = np.array([64], dtype=np.uint64)
+    assert lib.pmx_merkle_paths(ctypes.c_void_p(nodes.ctypes.data), m, ctypes.c_void_p(bad.ctypes.data), 1,
+                                ctypes.c_void_p(paths.ctypes.data)) == _lib.PMX_ERR_ARG
+    assert lib.pmx_merkle_paths(ctypes.c_void_p(nodes.ctypes.data), 48, ctypes.c_void_p(idx.ctypes.data), 1,
+                                ctypes.c_void_p(paths.ctypes.data)) == _lib.PMX_ERR_ARG
