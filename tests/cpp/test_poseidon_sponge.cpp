@@ -180,6 +180,56 @@ static void test_squeeze_with_sizes() {
     EXPECT(threw);
 }
 
+// Device groups straight through the C ABI (what BatchPoseidon::new_multi binds): the batch sharded over every visible GPU
+// equals the same batch on one device; the sharded tree's root equals the single-device tree's; the communicator RCCL
+// built has as many ranks as the group asked for; shard arithmetic on the host.
+static void test_device_group_on_gpu() {
+    const Field Fr = Field::bls12_381_fr();
+    auto p = get_default_poseidon_parameters(Fr, 2, false).value();
+    std::vector<uint64_t> ark, mds;
+    for (auto &row : p.ark) for (auto &x : row) ark.insert(ark.end(), x.l.begin(), x.l.end());
+    for (auto &row : p.mds) for (auto &x : row) mds.insert(mds.end(), x.l.begin(), x.l.end());
+    pmx_config c{};
+    c.full_rounds = (uint32_t)p.full_rounds; c.partial_rounds = (uint32_t)p.partial_rounds; c.alpha = p.alpha;
+    c.rate = (uint32_t)p.rate; c.capacity = (uint32_t)p.capacity;
+    std::memcpy(c.modulus, Fr.modulus.data(), 32);
+    c.ark = ark.data(); c.mds = mds.data();
+    const int ndev = pmx_device_count();
+    pmx_mgpu *g = nullptr;
+    check(pmx_mgpu_create(&c, ndev, nullptr, &g));
+    pmx_mgpu_info info{};
+    check(pmx_mgpu_get_info(g, &info));
+    EXPECT(info.world == ndev && info.n_local == ndev && info.comm_ranks == ndev && info.width == 3);
+    size_t covered = 0;
+    for (int r = 0; r < ndev; ++r) {
+        size_t start = 0, count = 0;
+        check(pmx_shard_bounds(10007, ndev, r, &start, &count));
+        EXPECT(start == covered);
+        covered += count;
+    }
+    EXPECT(covered == 10007);
+    // 10007 states: group vs one device
+    const size_t n = 10007;
+    std::vector<uint64_t> a(n * 12), b;
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (auto &w : a) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w = x; }
+    for (size_t i = 0; i < n * 3; ++i) a[i * 4 + 3] &= 0x0fffffffffffffffull;   // < 2^252 < p: a reduced residue
+    b = a;
+    check(pmx_mgpu_permute_batch(g, a.data(), n));
+    check(pmx_permute_batch(pmx_mgpu_ctx(g, 0), b.data(), n));
+    EXPECT(a == b);
+    // 2^12 leaves: sharded root vs single-device root (needs a power-of-two number of devices)
+    if ((ndev & (ndev - 1)) == 0) {
+        const size_t m = 4096;
+        std::vector<uint64_t> leaves(b.begin(), b.begin() + m * 4);
+        uint64_t r1[4], r2[4];
+        check(pmx_mgpu_merkle_2to1(g, leaves.data(), m, r1));
+        check(pmx_merkle_2to1(pmx_mgpu_ctx(g, 0), leaves.data(), m, nullptr, r2));
+        EXPECT(std::memcmp(r1, r2, 32) == 0);
+    }
+    check(pmx_mgpu_destroy(g));
+}
+
 int main(int argc, char **argv) {
     const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
     try {
@@ -190,6 +240,7 @@ int main(int argc, char **argv) {
             test_poseidon_sponge_consistency();
             test_squeeze_cast_native_and_state_roundtrip();
             test_squeeze_with_sizes();
+            test_device_group_on_gpu();
         } else {
             // without a device the data path must fail loudly, never fall back
             bool threw = false;
