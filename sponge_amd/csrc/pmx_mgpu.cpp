@@ -9,6 +9,7 @@
 // or one rank of a multi-process job (pmx_mgpu_create_rank: ncclCommInitRank with an id made by pmx_mgpu_unique_id
 // and carried to the other processes by the caller).  Either way a group holds `n_local` (device, pmx_ctx, stream,
 // communicator) slots with consecutive ranks starting at `first_rank`.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -35,8 +36,71 @@ struct pmx_mgpu {
     uint32_t t = 0;
 };
 
+// RCCL is bound when the first group is formed, not when the library is loaded: everything that runs on one GPU - the
+// whole single-device ABI - neither needs librccl nor pays for mapping it.  dlopen by SONAME: a process that already
+// holds a copy (PyTorch bundles one) gets that copy.
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl &rccl_lib() {
+    static Rccl *lib = [] {
+        Rccl *r = new Rccl();
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r->handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r->handle) break;
+        }
+        if (!r->handle) {
+            const char *e = dlerror();
+            r->error = std::string("librccl.so.1 could not be loaded: ") + (e ? e : "unknown error");
+            return r;
+        }
+        auto sym = [&](const char *name) {
+            void *p = dlsym(r->handle, name);
+            if (!p && r->error.empty()) r->error = std::string("librccl has no symbol ") + name;
+            return p;
+        };
+        r->GetVersion = (decltype(r->GetVersion))sym("ncclGetVersion");
+        r->GetUniqueId = (decltype(r->GetUniqueId))sym("ncclGetUniqueId");
+        r->CommInitAll = (decltype(r->CommInitAll))sym("ncclCommInitAll");
+        r->CommInitRank = (decltype(r->CommInitRank))sym("ncclCommInitRank");
+        r->CommDestroy = (decltype(r->CommDestroy))sym("ncclCommDestroy");
+        r->CommCount = (decltype(r->CommCount))sym("ncclCommCount");
+        r->CommUserRank = (decltype(r->CommUserRank))sym("ncclCommUserRank");
+        r->AllGather = (decltype(r->AllGather))sym("ncclAllGather");
+        r->Broadcast = (decltype(r->Broadcast))sym("ncclBroadcast");
+        r->GroupStart = (decltype(r->GroupStart))sym("ncclGroupStart");
+        r->GroupEnd = (decltype(r->GroupEnd))sym("ncclGroupEnd");
+        r->GetErrorString = (decltype(r->GetErrorString))sym("ncclGetErrorString");
+        return r;
+    }();
+    return *lib;
+}
+}  // namespace
+
+// PMX_OK, or PMX_ERR_RCCL with the loader's message
+static int rccl_ready() {
+    const Rccl &r = rccl_lib();
+    if (!r.error.empty()) return set_error(PMX_ERR_RCCL, "%s", r.error.c_str());
+    return PMX_OK;
+}
+
 static int rccl_fail(ncclResult_t r, const char *what) {
-    return set_error(PMX_ERR_RCCL, "%s: %s", what, ncclGetErrorString(r));
+    return set_error(PMX_ERR_RCCL, "%s: %s", what, rccl_lib().GetErrorString(r));
 }
 
 #define PMX_RCCL(expr)                                        \
@@ -55,8 +119,9 @@ extern "C" int pmx_shard_bounds(size_t n, int world, int rank, size_t *start, si
 
 extern "C" int pmx_mgpu_unique_id(uint8_t id[PMX_UNIQUE_ID_BYTES]) {
     if (!id) return set_error(PMX_ERR_ARG, "pmx_mgpu_unique_id: null pointer");
+    if (int rc = rccl_ready()) return rc;
     ncclUniqueId u;
-    PMX_RCCL(ncclGetUniqueId(&u));
+    PMX_RCCL(rccl_lib().GetUniqueId(&u));
     std::memcpy(id, u.internal, PMX_UNIQUE_ID_BYTES);
     return PMX_OK;
 }
@@ -65,7 +130,7 @@ static void group_free(pmx_mgpu *g) {
     for (size_t l = 0; l < g->comm.size(); ++l) {
         if (g->comm[l]) {
             DeviceGuard guard(g->device[l]);
-            (void)ncclCommDestroy(g->comm[l]);
+            (void)rccl_lib().CommDestroy(g->comm[l]);
         }
     }
     for (pmx_ctx *c : g->ctx)
@@ -89,6 +154,7 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
     *out = nullptr;
     const int visible = pmx_device_count();
     if (visible == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
+    if (int rc = rccl_ready()) return rc;
     if (n_devices <= 0 || n_devices > visible || n_devices > PMX_MAX_LOCAL_DEVICES)
         return set_error(PMX_ERR_ARG, "n_devices %d out of range [1,%d]", n_devices, visible < PMX_MAX_LOCAL_DEVICES ? visible : PMX_MAX_LOCAL_DEVICES);
     pmx_mgpu *g = new (std::nothrow) pmx_mgpu();
@@ -107,7 +173,7 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
     }
     int rc = group_contexts(g, cfg);
     if (rc) { group_free(g); return rc; }
-    ncclResult_t r = ncclCommInitAll(g->comm.data(), n_devices, g->device.data());
+    ncclResult_t r = rccl_lib().CommInitAll(g->comm.data(), n_devices, g->device.data());
     if (r != ncclSuccess) { group_free(g); return rccl_fail(r, "ncclCommInitAll"); }
     *out = g;
     return PMX_OK;
@@ -121,6 +187,7 @@ extern "C" int pmx_mgpu_create_rank(const pmx_config *cfg, int device, int rank,
     const int visible = pmx_device_count();
     if (visible == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= visible) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, visible);
+    if (int rc = rccl_ready()) return rc;
     pmx_mgpu *g = new (std::nothrow) pmx_mgpu();
     if (!g) return set_error(PMX_ERR_ARG, "out of host memory");
     g->world = world;
@@ -135,7 +202,7 @@ extern "C" int pmx_mgpu_create_rank(const pmx_config *cfg, int device, int rank,
     {
         DeviceGuard guard(device);
         if (guard.err != hipSuccess) { group_free(g); return hip_fail(guard.err, "hipSetDevice"); }
-        ncclResult_t r = ncclCommInitRank(&g->comm[0], world, u, rank);
+        ncclResult_t r = rccl_lib().CommInitRank(&g->comm[0], world, u, rank);
         if (r != ncclSuccess) { group_free(g); return rccl_fail(r, "ncclCommInitRank"); }
     }
     *out = g;
@@ -156,10 +223,10 @@ extern "C" int pmx_mgpu_get_info(const pmx_mgpu *g, pmx_mgpu_info *info) {
     info->n_local = (int)g->device.size();
     info->first_rank = g->first_rank;
     info->width = (int)g->t;
-    PMX_RCCL(ncclGetVersion(&info->rccl_version));
+    PMX_RCCL(rccl_lib().GetVersion(&info->rccl_version));
     // what the LIVE communicator says about itself (not what the group was asked for)
-    PMX_RCCL(ncclCommCount(g->comm[0], &info->comm_ranks));
-    PMX_RCCL(ncclCommUserRank(g->comm[0], &info->comm_first_rank));
+    PMX_RCCL(rccl_lib().CommCount(g->comm[0], &info->comm_ranks));
+    PMX_RCCL(rccl_lib().CommUserRank(g->comm[0], &info->comm_first_rank));
     for (size_t l = 0; l < g->device.size() && l < PMX_MAX_LOCAL_DEVICES; ++l) info->devices[l] = g->device[l];
     return PMX_OK;
 }
@@ -237,25 +304,25 @@ extern "C" int pmx_mgpu_all_gather_dev(pmx_mgpu *g, const uint64_t *const *d_sha
     if (n_total > SIZE_MAX / (row_elems * 32)) return set_error(PMX_ERR_ARG, "gather byte size overflows size_t");
     const size_t words = row_elems * 4;   // u64 words per unit
     const bool equal = n_total % (size_t)g->world == 0;
-    PMX_RCCL(ncclGroupStart());
+    PMX_RCCL(rccl_lib().GroupStart());
     ncclResult_t r = ncclSuccess;
     for (size_t l = 0; l < g->ctx.size() && r == ncclSuccess; ++l) {
         DeviceGuard guard(g->device[l]);
         hipStream_t st = g->ctx[l]->stream;
         if (equal) {
-            r = ncclAllGather(d_shards[l], d_all[l], (n_total / (size_t)g->world) * words, ncclUint64, g->comm[l], st);
+            r = rccl_lib().AllGather(d_shards[l], d_all[l], (n_total / (size_t)g->world) * words, ncclUint64, g->comm[l], st);
         } else {
             for (int root = 0; root < g->world && r == ncclSuccess; ++root) {
                 size_t start = 0, count = 0;
                 (void)pmx_shard_bounds(n_total, g->world, root, &start, &count);
                 if (count == 0) continue;
                 const bool mine = root == g->first_rank + (int)l;
-                r = ncclBroadcast(mine ? (const void *)d_shards[l] : (const void *)(d_all[l] + start * words), d_all[l] + start * words,
+                r = rccl_lib().Broadcast(mine ? (const void *)d_shards[l] : (const void *)(d_all[l] + start * words), d_all[l] + start * words,
                                   count * words, ncclUint64, root, g->comm[l], st);
             }
         }
     }
-    ncclResult_t e = ncclGroupEnd();
+    ncclResult_t e = rccl_lib().GroupEnd();
     if (r != ncclSuccess) return rccl_fail(r, equal ? "ncclAllGather" : "ncclBroadcast");
     if (e != ncclSuccess) return rccl_fail(e, "ncclGroupEnd");
     return PMX_OK;
@@ -279,13 +346,13 @@ extern "C" int pmx_mgpu_merkle_2to1_dev(pmx_mgpu *g, uint64_t *const *d_nodes, u
         PMX_HIP(hipMemcpyAsync(d_top[0], d_nodes[0] + (2 * m - 2) * 4, 32, hipMemcpyDeviceToDevice, g->ctx[0]->stream));
         return PMX_OK;
     }
-    PMX_RCCL(ncclGroupStart());
+    PMX_RCCL(rccl_lib().GroupStart());
     ncclResult_t r = ncclSuccess;
     for (size_t l = 0; l < g->ctx.size() && r == ncclSuccess; ++l) {
         DeviceGuard guard(g->device[l]);
-        r = ncclAllGather(d_nodes[l] + (2 * m - 2) * 4, d_top[l], 4, ncclUint64, g->comm[l], g->ctx[l]->stream);
+        r = rccl_lib().AllGather(d_nodes[l] + (2 * m - 2) * 4, d_top[l], 4, ncclUint64, g->comm[l], g->ctx[l]->stream);
     }
-    ncclResult_t e = ncclGroupEnd();
+    ncclResult_t e = rccl_lib().GroupEnd();
     if (r != ncclSuccess) return rccl_fail(r, "ncclAllGather");
     if (e != ncclSuccess) return rccl_fail(e, "ncclGroupEnd");
     for (size_t l = 0; l < g->ctx.size(); ++l) {
