@@ -46,10 +46,14 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 // RegEngine: t known at compile time, state in registers (internal field form).
 // LDS: [constants: n_const_words u32, rounded up to 16 B][staging: kThreads * T * 2 uint4]
 // ------------------------------------------------------------------------------------------------
+#ifndef PMX_REG_THREADS
+#define PMX_REG_THREADS 256   // workgroup size of the t = 3 engine: one wave per SIMD of a CU.  A/B (round 2): 128 threads -6 % on
+                              // C2 / hash / tree (waves land unevenly on the SIMDs), 512 threads -0.3 % C2, -3 % tree
+#endif
 template <int T, int ALPHA, bool OPT, bool TAB = false>
 struct RegEngine {
     static_assert(OPT || !TAB, "shifted tables exist for the optimised schedule");
-    static constexpr int kThreads = 256;
+    static constexpr int kThreads = PMX_REG_THREADS;
     static constexpr int kMinWaves = 1;
     static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
 
