@@ -210,3 +210,22 @@ def test_shared_context_is_safe_across_threads():
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+
+def test_group_and_path_edge_cases():
+    """Empty batches are no-ops, a tree of one leaf is its own root, a path of depth 0 compares the leaf with the root."""
+    import ctypes
+    cfg, g = _group()
+    lib = _lib.lib()
+    assert lib.pmx_mgpu_permute_batch(g._h, None, 0) == _lib.PMX_OK
+    empty = (ctypes.c_void_p * g.n_local)()
+    assert lib.pmx_mgpu_all_gather_dev(g._h, empty, empty, 0, 3) == _lib.PMX_OK
+    assert lib.pmx_mgpu_permute_shards_dev(g._h, None, 5) == _lib.PMX_ERR_ARG
+    one = synth.random_elements(cfg.field, 1, seed=5)
+    if g.world == 1:
+        assert np.array_equal(g.merkle_root(one), one[0])
+    ok = S.verify_paths(cfg, one, [0], np.zeros((1, 0, 4), dtype=np.uint64), one[0])
+    assert ok.tolist() == [True]
+    assert S.verify_paths(cfg, one, [0], np.zeros((1, 0, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64)).tolist() == [False]
+    assert S.verify_paths(cfg, np.zeros((0, 4), dtype=np.uint64), [], np.zeros((0, 3, 4), dtype=np.uint64), one[0]).tolist() == []
+    g.close()
