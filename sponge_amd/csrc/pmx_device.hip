@@ -180,11 +180,21 @@ struct RegEngine {
 // rounds their dynamic indexing (pmx_permute.hpp: permute_hybrid) and doubles as the staging area of the
 // coalesced ABI load/store.  Constants come through the scalar cache (the table is up to 80 KiB at t = 9).
 // ------------------------------------------------------------------------------------------------
+#ifndef PMX_HYB_WAVES
+#define PMX_HYB_WAVES 1   // waves per workgroup of the hybrid engines (each wave owns its own LDS region).  Four-wave workgroups -
+                          // co-resident waves in the same round, sharing its table lines in the scalar cache - were measured:
+                          // C3 -0.6 %, t = 9 hash +0.7 %: the s_waitcnt time of the wide kernels is not a cache-capacity effect
+#endif
 template <int T, int ALPHA>
 struct HybridEngine {
-    static constexpr int kThreads = 64;
+    static constexpr int kWaves = PMX_HYB_WAVES;
+    static constexpr int kThreads = 64 * kWaves;
     static constexpr int kMinWaves = 2;   // waves per SIMD the register allocation must allow (<= 256 VGPRs)
     static constexpr int kChunks = 2 * T;
+    // one wave's LDS region: scratch slots for elements 0..T-2 (2304 B each) or the ABI staging of its 64 states
+    // (2048 T B), whichever is larger
+    static constexpr size_t kScratchBytes = (size_t)(T - 1) * kN * 64 * 4, kStageBytes = (size_t)64 * kChunks * 16;
+    static constexpr size_t kWaveBytes = kScratchBytes > kStageBytes ? kScratchBytes : kStageBytes;
 
     struct Scratch {
         uint32_t *base;   // + lane
@@ -206,12 +216,10 @@ struct HybridEngine {
     Fe one;
     OptTables tb;
     Scratch sc;
+    uint4 *region;    // this wave's LDS region
+    uint32_t lane;
 
-    // scratch slots for elements 0..T-2 (2304 B each) or the ABI staging of 64 states (2048 T B), whichever is larger
-    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) {
-        const size_t scratch = (size_t)(T - 1) * kN * 64 * 4, stage = (size_t)64 * kChunks * 16;
-        return scratch > stage ? scratch : stage;
-    }
+    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes; }
 
     __device__ __forceinline__ HybridEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
         f.io = consts + d.io_offset;
@@ -222,49 +230,52 @@ struct HybridEngine {
         tb.tab_mds = consts + d.tab_mds_offset;
         tb.tab_sparse = consts + d.tab_sparse_offset;
         tb.tab_bdense = consts + d.tab_bdense_offset;
-        sc.base = reinterpret_cast<uint32_t *>(pmx_lds) + threadIdx.x;
+        lane = threadIdx.x & 63;
+        region = pmx_lds + (threadIdx.x >> 6) * (kWaveBytes / 16);
+        sc.base = reinterpret_cast<uint32_t *>(region) + lane;
     }
 
     __device__ __forceinline__ void zero() {
         static_for<0, T>([&](auto i) { s[i] = fe_zero(); });
     }
 
+    // every wave stages its own 64 contiguous states through its own region
     __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
-        const size_t first = (size_t)blockIdx.x * kThreads;
-        const size_t valid = n > first ? (n - first < (size_t)kThreads ? n - first : (size_t)kThreads) : 0;
+        const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
+        const size_t valid = n > first ? (n - first < (size_t)64 ? n - first : (size_t)64) : 0;
         const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + first * kChunks;
         const uint32_t n_chunks = (uint32_t)valid * kChunks;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kChunks; ++k) {
-            const uint32_t q = threadIdx.x + k * kThreads;
+            const uint32_t q = lane + k * 64;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (q < n_chunks) v = g[q];
-            pmx_lds[q] = v;
+            region[q] = v;
         }
         __syncthreads();
         Abi a[T];
-        static_for<0, T>([&](auto i) { a[i] = abi_from_u4(pmx_lds[threadIdx.x * kChunks + 2 * i], pmx_lds[threadIdx.x * kChunks + 2 * i + 1]); });
+        static_for<0, T>([&](auto i) { a[i] = abi_from_u4(region[lane * kChunks + 2 * i], region[lane * kChunks + 2 * i + 1]); });
         __syncthreads();   // the staging area is the scratch array: finish reading before anyone writes slots
         static_for<0, T>([&](auto i) { s[i] = fe_from_abi(a[i], f); });
     }
 
     __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {
-        const size_t first = (size_t)blockIdx.x * kThreads;
-        const size_t valid = n > first ? (n - first < (size_t)kThreads ? n - first : (size_t)kThreads) : 0;
+        const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
+        const size_t valid = n > first ? (n - first < (size_t)64 ? n - first : (size_t)64) : 0;
         uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * kChunks;
         const uint32_t n_chunks = (uint32_t)valid * kChunks;
         __syncthreads();
         static_for<0, T>([&](auto i) {
             const Abi a = fe_to_abi(s[i], f);
-            pmx_lds[threadIdx.x * kChunks + 2 * i] = abi_lo(a);
-            pmx_lds[threadIdx.x * kChunks + 2 * i + 1] = abi_hi(a);
+            region[lane * kChunks + 2 * i] = abi_lo(a);
+            region[lane * kChunks + 2 * i + 1] = abi_hi(a);
         });
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kChunks; ++k) {
-            const uint32_t q = threadIdx.x + k * kThreads;
-            if (q < n_chunks) g[q] = pmx_lds[q];
+            const uint32_t q = lane + k * 64;
+            if (q < n_chunks) g[q] = region[q];
         }
         __syncthreads();
     }
