@@ -123,6 +123,9 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
 #ifndef PMX_HYBRID_TOUCH
 #define PMX_HYBRID_TOUCH 1   // +1..4 % at t = 4..9
 #endif
+#ifndef PMX_HYBRID_TOUCH_ROW0
+#define PMX_HYBRID_TOUCH_ROW0 0   // warm-up of the element-form row 0 of t >= 6 as well: C3 -1 % (round 2 A/B)
+#endif
 #ifndef PMX_HYBRID_WIDE_ROW0_TAB
 #define PMX_HYBRID_WIDE_ROW0_TAB 0
 #endif
@@ -277,6 +280,8 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                 const uint32_t *rt = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
                 if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB) guard ^= table_touch<tab_row_words(T)>(rt);
                 if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB) guard ^= table_touch<(T - 1) * kTabOneWords>(rt + tab_row_words(T));
+                if constexpr (T > PMX_HYBRID_TAB_MAX_T && PMX_HYBRID_TOUCH_ROW0)   // the element-form row 0 of the wide engines
+                    guard ^= table_touch<T * kFeStride>(tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride);
             }
         }
         s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
