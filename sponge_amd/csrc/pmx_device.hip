@@ -46,6 +46,9 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 // RegEngine: t known at compile time, state in registers (internal field form).
 // LDS: [constants: n_const_words u32, rounded up to 16 B][staging: kThreads * T * 2 uint4]
 // ------------------------------------------------------------------------------------------------
+#ifndef PMX_REG_P_IN_VGPR
+#define PMX_REG_P_IN_VGPR 0
+#endif
 #ifndef PMX_REG_THREADS
 #define PMX_REG_THREADS 256   // workgroup size of the t = 3 engine: one wave per SIMD of a CU.  A/B (round 2): 128 threads -6 % on
                               // C2 / hash / tree (waves land unevenly on the SIMDs), 512 threads -0.3 % C2, -3 % tree
@@ -75,6 +78,13 @@ struct RegEngine {
 
     __device__ __forceinline__ RegEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
         f.io = consts + d.io_offset;
+#if PMX_REG_P_IN_VGPR
+        // the modulus limbs as VECTOR registers: the table products want every free SGPR for their operand stream
+        if constexpr (TAB) {
+#pragma unroll
+            for (int i = 0; i < kN; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(f.p[i]) : "s"(d.field.p[i]));
+        }
+#endif
         const uint32_t w0 = first_word(d);
 #if PMX_CONSTS_IN_LDS
         const uint32_t const_chunks = (last_word(d) - w0 + 3) / 4;
