@@ -47,7 +47,8 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 // LDS: [constants: n_const_words u32, rounded up to 16 B][staging: kThreads * T * 2 uint4]
 // ------------------------------------------------------------------------------------------------
 #ifndef PMX_REG_P_IN_VGPR
-#define PMX_REG_P_IN_VGPR 0
+#define PMX_REG_P_IN_VGPR 0   // modulus limbs in vector registers to free 9 SGPRs for the table stream: 46 -> 42 SGPR spills,
+                              // C2 +-0, hash -1.3 % (round 2 A/B)
 #endif
 #ifndef PMX_REG_THREADS
 #define PMX_REG_THREADS 256   // workgroup size of the t = 3 engine: one wave per SIMD of a CU.  A/B (round 2): 128 threads -6 % on
