@@ -94,6 +94,7 @@ extern "C" {
     pub fn pmx_mgpu_ctx(g: *const pmx_mgpu, local: c_int) -> *mut pmx_ctx;
     pub fn pmx_mgpu_synchronize(g: *mut pmx_mgpu) -> c_int;
     pub fn pmx_mgpu_permute_batch(g: *mut pmx_mgpu, states: *mut u64, n: usize) -> c_int;
+    pub fn pmx_mgpu_hash_batch(g: *mut pmx_mgpu, input: *const u64, in_len: usize, out: *mut u64, out_len: usize, n: usize) -> c_int;
     pub fn pmx_mgpu_permute_shards_dev(g: *mut pmx_mgpu, d_shards: *const *mut u64, n_total: usize) -> c_int;
     pub fn pmx_mgpu_all_gather_dev(g: *mut pmx_mgpu, d_shards: *const *const u64, d_all: *const *mut u64, n_total: usize,
                                    row_elems: usize) -> c_int;

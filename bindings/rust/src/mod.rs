@@ -204,7 +204,10 @@ impl<F: PrimeField> BatchPoseidon<F> {
     pub fn hash(&self, rows: &[F], in_len: usize, out_len: usize) -> Vec<F> {
         let n = if in_len == 0 { 0 } else { rows.len() / in_len };
         let mut out = vec![F::zero(); n * out_len];
-        check(unsafe { ffi::pmx_hash_batch(self.ctx.0, limbs(rows), in_len, limbs_mut(&mut out), out_len, n) });
+        match &self.group {
+            Some(g) => check(unsafe { ffi::pmx_mgpu_hash_batch(g.0, limbs(rows), in_len, limbs_mut(&mut out), out_len, n) }),
+            None => check(unsafe { ffi::pmx_hash_batch(self.ctx.0, limbs(rows), in_len, limbs_mut(&mut out), out_len, n) }),
+        }
         out
     }
     /// Authentication paths of `indices` over a node array made by `merkle`: `[k][depth]` siblings, bottom-up.

@@ -209,6 +209,9 @@ int pmx_mgpu_synchronize(pmx_mgpu *g);
 /* PoseidonSponge::permute (src/poseidon/mod.rs:95-118) on n states in host memory, in place, sharded over the
  * group's devices (single-process groups): every device pipelines its own shard over PCIe, all devices at once. */
 int pmx_mgpu_permute_batch(pmx_mgpu *g, uint64_t *states, size_t n);
+/* pmx_hash_batch (per row: new; absorb(in_len); squeeze_native(out_len)) sharded the same way: rows [start, start+count)
+ * of `in` and `out` go through device g's host path. */
+int pmx_mgpu_hash_batch(pmx_mgpu *g, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n);
 /* The same on device-resident shards: d_shards[local] = [count][t][4] on that device, count from
  * pmx_shard_bounds(n_total, world, first_rank + local).  Only enqueues. */
 int pmx_mgpu_permute_shards_dev(pmx_mgpu *g, uint64_t *const *d_shards, size_t n_total);

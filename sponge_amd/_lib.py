@@ -108,6 +108,7 @@ SIGNATURES = {
     "pmx_mgpu_ctx": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     "pmx_mgpu_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "pmx_mgpu_permute_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz]),
+    "pmx_mgpu_hash_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p, _sz, _sz]),
     "pmx_mgpu_permute_shards_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _sz]),
     "pmx_mgpu_all_gather_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
     "pmx_mgpu_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz]),

@@ -267,13 +267,13 @@ extern "C" int pmx_mgpu_permute_shards_dev(pmx_mgpu *g, uint64_t *const *d_shard
     return PMX_OK;
 }
 
-// Host batch, single-process groups: shard l goes through device l's own host path (pinned memory: chunked H2D / kernel
-// / D2H pipeline on two streams), one host thread per device so that all devices copy and compute concurrently - also
-// for pageable memory, whose copies block the calling thread.
-extern "C" int pmx_mgpu_permute_batch(pmx_mgpu *g, uint64_t *states, size_t n) {
-    if (!g || (!states && n)) return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_batch: null pointer");
+// Host batches, single-process groups: shard l goes through device l's own host path (pinned memory: chunked H2D /
+// kernel / D2H pipeline on two streams), one host thread per device so that all devices copy and compute concurrently -
+// also for pageable memory, whose copies block the calling thread.  `work(l, start, count)` runs on device l's thread.
+template <class Work>
+static int fan_out(pmx_mgpu *g, size_t n, const char *who, Work work) {
     if ((int)g->ctx.size() != g->world)
-        return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_batch needs a single-process group (this one holds %zu of %d ranks)", g->ctx.size(), g->world);
+        return set_error(PMX_ERR_ARG, "%s needs a single-process group (this one holds %zu of %d ranks)", who, g->ctx.size(), g->world);
     if (n == 0) return PMX_OK;
     const size_t L = g->ctx.size();
     std::vector<int> rcs(L, PMX_OK);
@@ -281,7 +281,7 @@ extern "C" int pmx_mgpu_permute_batch(pmx_mgpu *g, uint64_t *states, size_t n) {
     auto run = [&](size_t l) {
         size_t start = 0, count = 0;
         int rc = local_span(g, n, l, &start, &count);
-        if (!rc && count) rc = pmx_permute_batch(g->ctx[l], states + start * g->t * 4, count);
+        if (!rc && count) rc = work(l, start, count);
         rcs[l] = rc;
         if (rc) msgs[l] = pmx_last_error();   // the error text is thread-local: carry it back to the caller's thread
     };
@@ -292,6 +292,19 @@ extern "C" int pmx_mgpu_permute_batch(pmx_mgpu *g, uint64_t *states, size_t n) {
     for (size_t l = 0; l < L; ++l)
         if (rcs[l]) return set_error(rcs[l], "device %d: %s", g->device[l], msgs[l].c_str());
     return PMX_OK;
+}
+
+extern "C" int pmx_mgpu_permute_batch(pmx_mgpu *g, uint64_t *states, size_t n) {
+    if (!g || (!states && n)) return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_batch: null pointer");
+    return fan_out(g, n, "pmx_mgpu_permute_batch",
+                   [&](size_t l, size_t start, size_t count) { return pmx_permute_batch(g->ctx[l], states + start * g->t * 4, count); });
+}
+
+extern "C" int pmx_mgpu_hash_batch(pmx_mgpu *g, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n) {
+    if (!g || (!in && n && in_len) || (!out && n && out_len)) return set_error(PMX_ERR_ARG, "pmx_mgpu_hash_batch: null pointer");
+    return fan_out(g, n, "pmx_mgpu_hash_batch", [&](size_t l, size_t start, size_t count) {
+        return pmx_hash_batch(g->ctx[l], in ? in + start * in_len * 4 : nullptr, in_len, out ? out + start * out_len * 4 : nullptr, out_len, count);
+    });
 }
 
 // ---- the final gather ------------------------------------------------------------------------------------------------

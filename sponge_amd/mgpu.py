@@ -115,6 +115,15 @@ class DeviceGroup:
         _lib.check(_lib.lib().pmx_mgpu_permute_batch(self._h, ctypes.c_void_p(states.ctypes.data),
                                                      states.size // (self.cfg.t * 4)))
 
+    def hash_batch(self, msgs: np.ndarray, in_len: int, out_len: int, n: Optional[int] = None) -> np.ndarray:
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint64)
+        if n is None:
+            n = msgs.size // (in_len * 4)
+        out = np.zeros((n, out_len, 4), dtype=np.uint64)
+        _lib.check(_lib.lib().pmx_mgpu_hash_batch(self._h, ctypes.c_void_p(msgs.ctypes.data) if msgs.size else None, in_len,
+                                                  ctypes.c_void_p(out.ctypes.data), out_len, n))
+        return out
+
     def merkle_root(self, leaves: np.ndarray) -> np.ndarray:
         leaves = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4)
         root = np.zeros(4, dtype=np.uint64)

@@ -89,6 +89,7 @@ def test_hash_driver_per_shard_then_gather():
     g.all_gather_dev([t.data_ptr() for t in d_out], [t.data_ptr() for t in d_all], n_total, out_len)
     g.synchronize()
     want = c_oracle(NAME).hash_batch(msgs, in_len, out_len, threads=0)
+    assert np.array_equal(g.hash_batch(msgs, in_len, out_len), want)           # the host-batch form (pmx_mgpu_hash_batch)
     for l in range(g.n_local):
         assert np.array_equal(d_all[l].cpu().numpy().view(np.uint64), want)
     g.close()
