@@ -358,3 +358,44 @@ def test_configs_whose_round_constants_exceed_lds_fall_back_to_the_run_time_engi
     leaves = synth.random_elements(f, 256, seed=rf + 2)
     nodes, _ = ctx.merkle_2to1(leaves)
     assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
+
+
+def _random_configs():
+    import random
+    rng = random.Random(0xC0FFEE)
+    out = []
+    for _ in range(24):
+        field = rng.choice(["bls12_381_fr", "bn254_fr"])
+        rate = rng.randint(1, 11)
+        alpha = rng.choice([3, 5, 5, 7, 17, 257])
+        rf = rng.choice([2, 4, 8])
+        rp = rng.choice([0, 1, 2, 7, 22, 31, 57, 60, 70])
+        out.append((field, rate, alpha, rf, rp))
+    return out
+
+
+@pytest.mark.parametrize("field_name,rate,alpha,rf,rp", _random_configs())
+def test_random_configs_vs_c_oracle(field_name, rate, alpha, rf, rp):
+    """Two dozen seeded random (field, width, exponent, round counts): whatever engine the dispatch picks - register,
+    hybrid, run-time width, dense or optimised schedule, partial sections of 0 / 1 / 2 rounds, sections too long for the
+    uncapped identity lanes - permutation, hash driver and a small tree agree with the C restatement built from the
+    ORACLE's own constants."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.FIELDS[field_name]
+    p, bits = {"bls12_381_fr": (O.BLS12_381_FR, 255), "bn254_fr": (O.BN254_FR, 254)}[field_name]
+    cfg = S.poseidon_config_from_lfsr(f, rate, alpha, rf, rp)
+    cr = cref.CRef(O.make_config(p, bits, rate, alpha, rf, rp))
+    ctx, t = cfg.context(), rate + 1
+    n = 131
+    states = synth.random_elements(f, n * t, seed=rate * 1000 + rp).reshape(n, t, 4)
+    states[0] = 0
+    states[1] = f.from_ints([p - 1] * t)
+    assert np.array_equal(ctx.permute_batch(states), cr.permute_batch(states, threads=0))
+    L = t + 2
+    msgs = synth.random_elements(f, n * L, seed=rate * 1000 + rp + 1).reshape(n, L, 4)
+    assert np.array_equal(ctx.hash_batch(msgs, L, 2), cr.hash_batch(msgs, L, 2, threads=0))
+    if rate >= 2:
+        leaves = synth.random_elements(f, 64, seed=rate + rp)
+        nodes, _ = ctx.merkle_2to1(leaves)
+        assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
