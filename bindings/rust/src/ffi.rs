@@ -78,6 +78,12 @@ extern "C" {
     pub fn pmx_merkle_paths(nodes: *const u64, n_leaves: usize, indices: *const u64, k: usize, paths_out: *mut u64) -> c_int;
     pub fn pmx_merkle_verify_paths(ctx: *mut pmx_ctx, leaves: *const u64, indices: *const u64, paths: *const u64, depth: usize,
                                    k: usize, root: *const u64, ok_out: *mut u8) -> c_int;
+    // device memory for the *_dev entry points
+    pub fn pmx_device_alloc(device: c_int, d_ptr: *mut *mut c_void, bytes: usize) -> c_int;
+    pub fn pmx_device_free(device: c_int, d_ptr: *mut c_void) -> c_int;
+    pub fn pmx_device_upload(device: c_int, d_dst: *mut c_void, h_src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn pmx_device_download(device: c_int, h_dst: *mut c_void, d_src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn pmx_stream_synchronize(device: c_int, stream: *mut c_void) -> c_int;
     // shared contexts
     pub fn pmx_ctx_acquire(cfg: *const pmx_config, device: c_int, out: *mut *mut pmx_ctx) -> c_int;
     pub fn pmx_ctx_release(ctx: *mut pmx_ctx) -> c_int;

@@ -81,6 +81,17 @@ int pmx_device_count(void);
 int pmx_host_alloc(void **ptr, size_t bytes);
 int pmx_host_free(void *ptr);
 
+/* ---- device memory for the *_dev entry points (optional) ------------------------------------------
+ * A caller that already manages HIP memory passes its own device pointers and streams.  One that does not (a Rust
+ * crate without HIP bindings) gets what it needs here: allocation on a device, copies ordered on a stream (NULL = the
+ * device's default stream; copies from / to pageable host memory complete before the call returns, page-locked ones
+ * are asynchronous), and a stream wait. */
+int pmx_device_alloc(int device, void **d_ptr, size_t bytes);
+int pmx_device_free(int device, void *d_ptr);
+int pmx_device_upload(int device, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int pmx_device_download(int device, void *h_dst, const void *d_src, size_t bytes, void *stream);
+int pmx_stream_synchronize(int device, void *stream);
+
 /* ---- parameters (host only) -------------------------------------------------------------------
  * find_poseidon_ark_and_mds (src/poseidon/traits.rs:105-146) with PoseidonGrainLFSR
  * (src/poseidon/grain_lfsr.rs:15-189): width = rate+1.  Writes Montgomery residues:

@@ -70,6 +70,11 @@ SIGNATURES = {
     "pmx_device_count": (ctypes.c_int, []),
     "pmx_host_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _sz]),
     "pmx_host_free": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_device_alloc": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), _sz]),
+    "pmx_device_free": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    "pmx_device_upload": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "pmx_device_download": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _sz, ctypes.c_void_p]),
+    "pmx_stream_synchronize": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "pmx_find_poseidon_ark_and_mds": (ctypes.c_int, [_u64p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                                      ctypes.c_uint32, ctypes.c_uint32, _u64p, _u64p]),
     "pmx_mont_constants": (ctypes.c_int, [_u64p, _u64p, _u64p, _u64p]),

@@ -280,6 +280,59 @@ extern "C" int pmx_host_free(void *ptr) {
     return PMX_OK;
 }
 
+// ---- device memory for callers without HIP bindings ------------------------------------------------------
+static int device_ok(int device) {
+    const int ndev = pmx_device_count();
+    if (ndev == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    return PMX_OK;
+}
+
+extern "C" int pmx_device_alloc(int device, void **d_ptr, size_t bytes) {
+    if (!d_ptr) return set_error(PMX_ERR_ARG, "pmx_device_alloc: null pointer");
+    *d_ptr = nullptr;
+    if (int rc = device_ok(device)) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    PMX_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return PMX_OK;
+}
+
+extern "C" int pmx_device_free(int device, void *d_ptr) {
+    if (!d_ptr) return PMX_OK;
+    if (int rc = device_ok(device)) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    PMX_HIP(hipFree(d_ptr));
+    return PMX_OK;
+}
+
+static int device_copy(int device, void *dst, const void *src, size_t bytes, void *stream, hipMemcpyKind kind) {
+    if ((!dst || !src) && bytes) return set_error(PMX_ERR_ARG, "pmx_device_upload / download: null pointer");
+    if (bytes == 0) return PMX_OK;
+    if (int rc = device_ok(device)) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    PMX_HIP(hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_device_upload(int device, void *d_dst, const void *h_src, size_t bytes, void *stream) {
+    return device_copy(device, d_dst, h_src, bytes, stream, hipMemcpyHostToDevice);
+}
+
+extern "C" int pmx_device_download(int device, void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    return device_copy(device, h_dst, d_src, bytes, stream, hipMemcpyDeviceToHost);
+}
+
+extern "C" int pmx_stream_synchronize(int device, void *stream) {
+    if (int rc = device_ok(device)) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    PMX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PMX_OK;
+}
+
 static bool is_pinned(const void *p) {
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, p) != hipSuccess) {

@@ -227,6 +227,33 @@ static void test_device_group_on_gpu() {
         check(pmx_merkle_2to1(pmx_mgpu_ctx(g, 0), leaves.data(), m, nullptr, r2));
         EXPECT(std::memcmp(r1, r2, 32) == 0);
     }
+    // device-resident flow without a HIP header: allocate, upload, permute twice on the group's stream, gather, download
+    {
+        const size_t m = 3000;
+        size_t start = 0, count = 0;
+        check(pmx_shard_bounds(m, ndev, 0, &start, &count));
+        std::vector<uint64_t> host(b.begin(), b.begin() + m * 12), twice = host, back(m * 12);
+        check(pmx_permute_batch(pmx_mgpu_ctx(g, 0), twice.data(), m));
+        check(pmx_permute_batch(pmx_mgpu_ctx(g, 0), twice.data(), m));
+        std::vector<uint64_t *> shard(ndev, nullptr), all(ndev, nullptr);
+        for (int l = 0; l < ndev; ++l) {
+            size_t s0 = 0, c0 = 0;
+            check(pmx_shard_bounds(m, ndev, l, &s0, &c0));
+            check(pmx_device_alloc(info.devices[l], (void **)&shard[l], c0 * 96));
+            check(pmx_device_alloc(info.devices[l], (void **)&all[l], m * 96));
+            check(pmx_device_upload(info.devices[l], shard[l], host.data() + s0 * 12, c0 * 96, pmx_mgpu_stream(g, l)));
+        }
+        check(pmx_mgpu_permute_shards_dev(g, shard.data(), m));
+        check(pmx_mgpu_permute_shards_dev(g, shard.data(), m));
+        check(pmx_mgpu_all_gather_dev(g, (const uint64_t *const *)shard.data(), all.data(), m, 3));
+        check(pmx_device_download(info.devices[0], back.data(), all[0], m * 96, pmx_mgpu_stream(g, 0)));
+        check(pmx_stream_synchronize(info.devices[0], pmx_mgpu_stream(g, 0)));
+        EXPECT(back == twice);
+        for (int l = 0; l < ndev; ++l) {
+            check(pmx_device_free(info.devices[l], shard[l]));
+            check(pmx_device_free(info.devices[l], all[l]));
+        }
+    }
     check(pmx_mgpu_destroy(g));
 }
 
