@@ -234,3 +234,39 @@ impl<F: PrimeField> BatchPoseidon<F> {
         nodes
     }
 }
+
+/// A batch that stays in HBM between calls - the `_dev` entry points without any HIP binding on the Rust side
+/// (`pmx_device_alloc` / `_upload` / `_download`): upload once, permute as often as needed, download once.
+pub struct DeviceStates<F: PrimeField> {
+    ptr: *mut core::ffi::c_void,
+    n: usize,
+    t: usize,
+    device: i32,
+    ctx: Arc<Ctx>,
+    _f: core::marker::PhantomData<F>,
+}
+
+impl<F: PrimeField> DeviceStates<F> {
+    pub fn upload(p: &PoseidonConfig<F>, device: i32, states: &[F]) -> Self {
+        let t = p.rate + p.capacity;
+        assert_eq!(states.len() % t, 0);
+        let mut ptr = core::ptr::null_mut();
+        check(unsafe { ffi::pmx_device_alloc(device, &mut ptr, states.len() * 32) });
+        check(unsafe { ffi::pmx_device_upload(device, ptr, states.as_ptr() as *const _, states.len() * 32, core::ptr::null_mut()) });
+        Self { ptr, n: states.len() / t, t, device, ctx: make_ctx(p, device), _f: Default::default() }
+    }
+    /// `permute` on every state, in place in device memory (enqueued on the device's default stream).
+    pub fn permute(&mut self) {
+        check(unsafe { ffi::pmx_permute_batch_dev(self.ctx.0, self.ptr as *mut u64, self.n, core::ptr::null_mut()) });
+    }
+    pub fn download(&self) -> Vec<F> {
+        let mut out = vec![F::zero(); self.n * self.t];
+        check(unsafe { ffi::pmx_device_download(self.device, out.as_mut_ptr() as *mut _, self.ptr, out.len() * 32, core::ptr::null_mut()) });
+        check(unsafe { ffi::pmx_stream_synchronize(self.device, core::ptr::null_mut()) });
+        out
+    }
+}
+
+impl<F: PrimeField> Drop for DeviceStates<F> {
+    fn drop(&mut self) { unsafe { ffi::pmx_device_free(self.device, self.ptr); } }
+}
