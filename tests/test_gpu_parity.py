@@ -399,3 +399,33 @@ def test_random_configs_vs_c_oracle(field_name, rate, alpha, rf, rp):
         leaves = synth.random_elements(f, 64, seed=rate + rp)
         nodes, _ = ctx.merkle_2to1(leaves)
         assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
+
+
+def test_device_resident_flow_with_the_abis_own_memory_helpers():
+    """pmx_device_alloc / _upload / _download / pmx_stream_synchronize: the *_dev entry points driven without torch or
+    any HIP binding on the caller's side - permute twice in HBM, hash the result in HBM, download."""
+    import ctypes
+    from sponge_amd import _lib
+    lib = _lib.lib()
+    cfg = product_config("bls_t3_a5_8_31")
+    ctx = cfg.context()
+    n = 70000
+    states = synth.random_elements(cfg.field, n * 3, seed=0x5EED0050).reshape(n, 3, 4)
+    d_states, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.pmx_device_alloc(0, ctypes.byref(d_states), states.nbytes))
+    _lib.check(lib.pmx_device_alloc(0, ctypes.byref(d_out), n * 32))
+    _lib.check(lib.pmx_device_upload(0, d_states, ctypes.c_void_p(states.ctypes.data), states.nbytes, None))
+    ctx.permute_batch_dev(d_states.value, n, 0)
+    ctx.permute_batch_dev(d_states.value, n, 0)
+    ctx.hash_batch_dev(d_states.value, 3, d_out.value, 1, n, 0)            # every permuted state as a 3-element message
+    back, digests = np.zeros_like(states), np.zeros((n, 1, 4), dtype=np.uint64)
+    _lib.check(lib.pmx_device_download(0, ctypes.c_void_p(back.ctypes.data), d_states, back.nbytes, None))
+    _lib.check(lib.pmx_device_download(0, ctypes.c_void_p(digests.ctypes.data), d_out, digests.nbytes, None))
+    _lib.check(lib.pmx_stream_synchronize(0, None))
+    cr = c_oracle("bls_t3_a5_8_31")
+    want = cr.permute_batch(cr.permute_batch(states, threads=0), threads=0)
+    assert np.array_equal(back, want)
+    assert np.array_equal(digests, cr.hash_batch(want, 3, 1, threads=0))
+    _lib.check(lib.pmx_device_free(0, d_states))
+    _lib.check(lib.pmx_device_free(0, d_out))
+    assert lib.pmx_device_alloc(99, ctypes.byref(d_states), 16) == _lib.PMX_ERR_ARG
