@@ -218,7 +218,10 @@ extern "C" int pmx_ctx_acquire(const pmx_config *cfg, int device, pmx_ctx **out)
     }
     pmx_ctx *c = nullptr;
     int rc = pmx_ctx_create(cfg, device, &c);
-    if (rc) return rc;
+    if (rc) {
+        if (bucket.empty()) cc.by_key.erase(key);
+        return rc;
+    }
     c->cache_key = key;
     c->cache_refs = 1;
     c->cache_blob = std::move(blob);
