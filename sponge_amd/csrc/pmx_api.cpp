@@ -398,6 +398,12 @@ extern "C" int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_
     if (!aligned16(d_in) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
     PMX_BIND(ctx);
+    // two elements in, one out, rate >= 2: this IS the 2-to-1 compression (same memory layout as one tree level), whose
+    // launcher has the quad kernel for small batches - a batch of authentication paths advances one level per call
+    if (in_len == 2 && out_len == 1 && ctx->dev.rounds.rate >= 2) {
+        PMX_HIP(launch_compress(ctx->dev, ctx->t, d_in, d_out, n, (hipStream_t)stream));
+        return PMX_OK;
+    }
     PMX_HIP(launch_hash(ctx->dev, ctx->t, d_in, in_len, d_out, out_len, n, (hipStream_t)stream));
     return PMX_OK;
 }

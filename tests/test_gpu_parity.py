@@ -88,7 +88,8 @@ def test_hash_and_merkle_golden():
 
 
 @pytest.mark.parametrize("name,L,k", [("bls_t3_a5_8_31", 2, 1), ("bls_t3_a5_8_31", 7, 5), ("bls_t3_a17_8_31", 3, 3),
-                                      ("bn254_t9_a5_8_57", 8, 1), ("bn254_t9_a5_8_57", 19, 10), ("bls_t4_a5_8_56", 4, 4)])
+                                      ("bn254_t9_a5_8_57", 8, 1), ("bn254_t9_a5_8_57", 19, 10), ("bls_t4_a5_8_56", 4, 4),
+                                      ("bn254_t9_a5_8_57", 2, 1), ("bls_t4_a5_8_56", 2, 1)])   # (2, 1) takes the 2-to-1 launcher
 def test_hash_batch_vs_c_oracle(name, L, k):
     cfg = product_config(name)
     n = 333
