@@ -568,57 +568,174 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     if (active) abi_store(reinterpret_cast<uint32_t *>(out + gid * 4), digest);
 }
 
-// The same 2-to-1 compression with ONE state spread over a quad of lanes (pmx_permute.hpp, cooperative schedule;
-// t = 3, rate 2, capacity 1): lane q of a quad holds state element q (lane 3 idles), the three z values of a
-// round are exchanged with quad-broadcast DPP moves.  Used for the narrow (latency-bound) levels of a tree.
+// ------------------------------------------------------------------------------------------------
+// QuadEngine: ONE state spread over a quad of lanes (pmx_permute.hpp, cooperative schedule; t = 3): lane q of a quad
+// holds state element q, lane 3 is the spare that squares in the folded sparse rounds; the values a round exchanges
+// travel by quad-broadcast DPP moves.  For latency-bound launches - the narrow levels of a tree, a handful of sponges -
+// where what is paid is the length of one permutation's dependent chain: 32 k instructions here, 58-67 k with one lane
+// per state.  LDS: the cooperative table, staged once per workgroup (256 threads = 64 states).
+// ------------------------------------------------------------------------------------------------
+template <int ALPHA>
+struct QuadEngine {
+    Rounds c;
+    FieldRt f;
+    Fe one;
+    const uint32_t *coop;
+    uint32_t q, role;
+    Fe s;   // this lane's element of its quad's state
+
+    static size_t lds_bytes(const DevConfig &d) { return (size_t)d.rounds.total_rounds * 3 * kCoopElems * kFeStride * 4; }
+
+    __device__ __forceinline__ QuadEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
+        f.io = consts + d.io_offset;
+        const uint32_t table_chunks = c.total_rounds * 3 * kCoopElems * kFeStride / 4;
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(consts + d.coop_offset);
+        for (uint32_t k = threadIdx.x; k < table_chunks; k += 256) pmx_lds[k] = g4[k];
+        __syncthreads();
+        coop = reinterpret_cast<const uint32_t *>(pmx_lds);
+        q = threadIdx.x & 3;
+        role = q < 3 ? q : 2;   // lane 3 reads lane 2's entries; in the uniform rounds it shadows lane 2 (its result is never read)
+        s = fe_zero();
+    }
+
+    // element held by lane `lane` of this quad, in every lane
+    template <int LANE>
+    __device__ __forceinline__ static Fe quad(const Fe &v) {
+        Fe r;
+#pragma unroll
+        for (int w = 0; w < kN; ++w) r.l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[w], LANE * 0x55, 0xf, 0xf, false);   // quad_perm [l, l, l, l]
+        return r;
+    }
+
+    // callers keep whole quads active or inactive together (the DPP moves read the other lanes of the quad)
+    __device__ __forceinline__ void permute() {
+        const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
+        for (uint32_t r = 0; r < c.total_rounds; ++r) {
+            const uint32_t *entry = coop + ((size_t)r * 3 + role) * kCoopElems * kFeStride;
+            if (kCoopFolded<ALPHA> && r >= first_partial && r < last_partial) {   // sparse round, three multiplications deep
+                const Fe x = quad<0>(fe_add_lazy(s, fe_const(entry)));
+                const Fe res_a = coop_fold_a(q, x, entry, f);
+                const Fe res_b = coop_fold_b(q, s, res_a, entry, f);
+                Fe xpow = res_b;
+#pragma unroll
+                for (int k = 0; k < kCoopExtraSquarings<ALPHA>; ++k) xpow = mont_sqr(xpow, f);
+                s = coop_fold_c(q, s, quad<3>(xpow), res_a, quad<1>(res_b), quad<2>(res_b), f);
+                continue;
+            }
+            const Fe z = coop_pre<ALPHA>(s, entry, is_full_round(r, c) || q == 0, c, one, f);
+            Fe zz[3];
+            zz[0] = quad<0>(z);
+            zz[1] = quad<1>(z);
+            zz[2] = quad<2>(z);
+            s = coop_post(zz, entry, f);
+        }
+        // lane 3 carries scratch values through the rounds; keep them bounded for the next call's lazy adds
+        if (q == 3) s = fe_zero();
+    }
+};
+
+// 2-to-1 compression on the quad engine (capacity 1, rate 2): state = [0, l, r], digest = element 1.
 template <int ALPHA>
 __global__ void __launch_bounds__(256, 2)
     compress_coop_kernel(const DevConfig d, const uint32_t *__restrict__ consts, const uint64_t *__restrict__ in,
                          uint64_t *__restrict__ out, size_t n) {
-    const Rounds c(d.rounds);
-    FieldRt f(d.field);
-    f.io = consts + d.io_offset;
-    const Fe one(d.one);
-    const uint32_t table_chunks = c.total_rounds * 3 * kCoopElems * kFeStride / 4;
-    const uint4 *g4 = reinterpret_cast<const uint4 *>(consts + d.coop_offset);
-    for (uint32_t k = threadIdx.x; k < table_chunks; k += 256) pmx_lds[k] = g4[k];
-    __syncthreads();
-    const uint32_t *coop = reinterpret_cast<const uint32_t *>(pmx_lds);
-
-    const uint32_t q = threadIdx.x & 3;
+    QuadEngine<ALPHA> e(d, consts);
     const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     const bool active = g < n;
-    Fe s = fe_zero();                                        // state = [0, l, r]
-    if (active && (q == 1 || q == 2)) s = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(in + (g * 2 + (q - 1)) * 4)), f);
-    const uint32_t role = q < 3 ? q : 2;                     // lane 3 reads lane 2's entries; in the uniform rounds it shadows lane 2 (its result is never read)
-    const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
-    auto quad = [](const Fe &v, auto lane) {                 // element held by lane `lane` of this quad, in every lane
-        constexpr int sel = decltype(lane)::value * 0x55;    // quad_perm [l, l, l, l]
-        Fe r;
-#pragma unroll
-        for (int w = 0; w < kN; ++w) r.l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[w], sel, 0xf, 0xf, false);
-        return r;
-    };
-    for (uint32_t r = 0; r < c.total_rounds; ++r) {
-        const uint32_t *entry = coop + ((size_t)r * 3 + role) * kCoopElems * kFeStride;
-        if (kCoopFolded<ALPHA> && r >= first_partial && r < last_partial) {   // sparse round, three multiplications deep
-            const Fe x = quad(fe_add_lazy(s, fe_const(entry)), std::integral_constant<int, 0>{});
-            const Fe res_a = coop_fold_a(q, x, entry, f);
-            const Fe res_b = coop_fold_b(q, s, res_a, entry, f);
-            Fe xpow = res_b;
-#pragma unroll
-            for (int k = 0; k < kCoopExtraSquarings<ALPHA>; ++k) xpow = mont_sqr(xpow, f);
-            s = coop_fold_c(q, s, quad(xpow, std::integral_constant<int, 3>{}), res_a, quad(res_b, std::integral_constant<int, 1>{}),
-                            quad(res_b, std::integral_constant<int, 2>{}), f);
-            continue;
+    if (active && (e.q == 1 || e.q == 2)) e.s = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(in + (g * 2 + (e.q - 1)) * 4)), e.f);
+    e.permute();
+    const Abi digest = fe_to_abi(e.s, e.f);
+    if (active && e.q == 1) abi_store(reinterpret_cast<uint32_t *>(out + g * 4), digest);   // state[capacity]
+}
+
+// The duplex-sponge driver on the quad engine (capacity 1, rate 2), same semantics as absorb_kernel / squeeze_kernel
+// below: a handful of sponges - the single PoseidonSponge of the trait shims - is all latency.  Mode and index are
+// per-sponge values, identical in the four lanes of a quad, so quads diverge as units.
+template <int ALPHA>
+__global__ void __launch_bounds__(256, 2)
+    absorb_quad_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
+                       uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, const uint64_t *__restrict__ in,
+                       size_t in_len, size_t n) {
+    QuadEngine<ALPHA> e(d, consts);
+    const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool active = g < n;
+    uint32_t *mine = reinterpret_cast<uint32_t *>(states + ((active ? g : 0) * 3 + e.role) * 4);
+    if (active && e.q < 3) e.s = fe_from_abi(abi_load(mine), e.f);
+    uint32_t idx = 0;
+    if (active) idx = (mode_tag[g] == PMX_MODE_ABSORBING) ? mode_index[g] : e.c.rate;
+    if (idx > e.c.rate) idx = e.c.rate;                        // device-resident mode words are not validated by the host
+    const uint64_t *row = in + (active ? g : 0) * in_len * 4;
+    for (size_t k = 0; k < in_len; ++k) {
+        const bool need = active && idx == e.c.rate;           // rate filled and more input remains (mod.rs:137-148, :241-252)
+        if (__builtin_amdgcn_ballot_w64(need)) {
+            if (need) {
+                e.permute();
+                idx = 0;
+            }
         }
-        const Fe z = coop_pre<ALPHA>(s, entry, is_full_round(r, c) || q == 0, c, one, f);
-        Fe zz[3];
-        static_for<0, 3>([&](auto j) { zz[j] = quad(z, j); });
-        s = coop_post(zz, entry, f);
+        if (active) {
+            const Fe x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)), e.f);
+            if (e.q == e.c.capacity + idx) e.s = fe_normalize(fe_add_lazy(e.s, x));   // state[capacity + idx] += element (mod.rs:128,143)
+            idx += 1;
+        }
     }
-    const Abi digest = fe_to_abi(s, f);
-    if (active && q == 1) abi_store(reinterpret_cast<uint32_t *>(out + g * 4), digest);   // state[capacity]
+    const Abi v = fe_to_abi(e.s, e.f);
+    if (active && e.q < 3) abi_store(mine, v);
+    if (active && e.q == 0) {
+        mode_tag[g] = PMX_MODE_ABSORBING;                      // mod.rs:130-132
+        mode_index[g] = idx;
+    }
+}
+
+template <int ALPHA>
+__global__ void __launch_bounds__(256, 2)
+    squeeze_quad_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
+                        uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ out,
+                        size_t out_len, size_t n) {
+    QuadEngine<ALPHA> e(d, consts);
+    const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool active = g < n;
+    uint32_t *mine = reinterpret_cast<uint32_t *>(states + ((active ? g : 0) * 3 + e.role) * 4);
+    if (active && e.q < 3) e.s = fe_from_abi(abi_load(mine), e.f);
+    uint32_t idx = 0;
+    bool need = true;                                          // Absorbing -> permute, start at 0 (mod.rs:324-328)
+    if (active && mode_tag[g] == PMX_MODE_SQUEEZING) {         // mod.rs:330-336
+        idx = mode_index[g];
+        if (idx > e.c.rate) idx = e.c.rate;
+        need = idx == e.c.rate;
+        if (need) idx = 0;
+    }
+    uint64_t *row = out + (active ? g : 0) * out_len * 4;
+    size_t rem = out_len, pos = 0;
+    bool done = !active;
+    while (__builtin_amdgcn_ballot_w64(!done)) {               // squeeze_internal, mod.rs:153-182
+        const bool do_perm = !done && need;
+        if (__builtin_amdgcn_ballot_w64(do_perm)) {
+            if (do_perm) e.permute();
+        }
+        if (!done) {
+            const bool last = idx + rem <= e.c.rate;
+            const uint32_t take = last ? (uint32_t)rem : e.c.rate - idx;
+            const Abi v = fe_to_abi(e.s, e.f);                 // every lane converts its own element; the matching one stores
+            for (uint32_t k = 0; k < take; ++k)
+                if (e.q == e.c.capacity + idx + k) abi_store(reinterpret_cast<uint32_t *>(row + 4 * (pos + k)), v);
+            if (last) {
+                idx += take;
+                done = true;
+            } else {
+                need = rem != e.c.rate;                        // mod.rs:175, tested before the slice is advanced
+                rem -= take;
+                pos += take;
+                idx = 0;
+            }
+        }
+    }
+    const Abi v = fe_to_abi(e.s, e.f);
+    if (active && e.q < 3) abi_store(mine, v);
+    if (active && e.q == 0) {
+        mode_tag[g] = PMX_MODE_SQUEEZING;                      // mod.rs:162-164
+        mode_index[g] = idx;
+    }
 }
 
 template <class Engine>
@@ -825,17 +942,19 @@ static constexpr size_t kCoopMaxUnits = PMX_COOP_MAX_UNITS;
 
 template <int ALPHA>
 static hipError_t launch_compress_coop(const DevConfig &c, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
-    const size_t lds = (size_t)c.rounds.total_rounds * 3 * kCoopElems * kFeStride * 4;
-    hipLaunchKernelGGL(compress_coop_kernel<ALPHA>, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, c, c.consts, in, out, n);
+    hipLaunchKernelGGL(compress_coop_kernel<ALPHA>, dim3((unsigned)((n + 63) / 64)), dim3(256), QuadEngine<ALPHA>::lds_bytes(c), st, c, c.consts, in, out, n);
     return hipGetLastError();
 }
 
+// the quad engine hard-codes the lane of each element (capacity 1, rate 2: state [c, r0, r1]) and stages its table in LDS
+static bool quad_shape(const DevConfig &c, uint32_t t) {
+    return t == 3 && c.has_opt && c.rounds.capacity == 1 && c.rounds.rate == 2 &&
+           (size_t)c.rounds.total_rounds * 3 * kCoopElems * kFeStride * 4 <= (size_t)c.max_lds_bytes;
+}
+
 hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
-    // the cooperative kernel hard-codes state = [0, l, r] and reads lane 1: capacity 1, rate 2 only (the split
-    // (rate 3, capacity 0) of the same width takes the one-lane-per-state kernel at every level)
-    const bool coop_shape = t == 3 && c.has_opt && c.rounds.capacity == 1 && c.rounds.rate == 2 &&
-                            (size_t)c.rounds.total_rounds * 3 * kCoopElems * kFeStride * 4 <= (size_t)c.max_lds_bytes;
-    if (coop_shape && n <= kCoopMaxUnits) {
+    // (the split (rate 3, capacity 0) of the same width takes the one-lane-per-state kernel at every level)
+    if (quad_shape(c, t) && n <= kCoopMaxUnits) {
         if (c.rounds.alpha == 5) return launch_compress_coop<5>(c, in, out, n, st);
         if (c.rounds.alpha == 17) return launch_compress_coop<17>(c, in, out, n, st);
         return launch_compress_coop<0>(c, in, out, n, st);
@@ -843,13 +962,43 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
     PMX_SMALL_BATCH(kTabMinCompress, compress(c, t, in, out, n, st));
     PMX_DISPATCH(compress(c, t, in, out, n, st));
 }
+
+// Mid-stream sponges in small numbers (one, for the trait shims) are latency as well: the quad engine up to this many.
+#ifndef PMX_QUAD_MAX_SPONGES
+#define PMX_QUAD_MAX_SPONGES 16384
+#endif
+template <int ALPHA>
+static hipError_t launch_absorb_quad(const DevConfig &c, uint64_t *states, uint32_t *tag, uint32_t *index, const uint64_t *in,
+                                     size_t in_len, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(absorb_quad_kernel<ALPHA>, dim3((unsigned)((n + 63) / 64)), dim3(256), QuadEngine<ALPHA>::lds_bytes(c), st, c, c.consts,
+                       states, tag, index, in, in_len, n);
+    return hipGetLastError();
+}
+template <int ALPHA>
+static hipError_t launch_squeeze_quad(const DevConfig &c, uint64_t *states, uint32_t *tag, uint32_t *index, uint64_t *out,
+                                      size_t out_len, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(squeeze_quad_kernel<ALPHA>, dim3((unsigned)((n + 63) / 64)), dim3(256), QuadEngine<ALPHA>::lds_bytes(c), st, c, c.consts,
+                       states, tag, index, out, out_len, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {
+    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) {
+        if (c.rounds.alpha == 5) return launch_absorb_quad<5>(c, states, tag, index, in, in_len, n, st);
+        if (c.rounds.alpha == 17) return launch_absorb_quad<17>(c, states, tag, index, in, in_len, n, st);
+        return launch_absorb_quad<0>(c, states, tag, index, in, in_len, n, st);
+    }
     PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st));
     PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st));
 }
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
+    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) {
+        if (c.rounds.alpha == 5) return launch_squeeze_quad<5>(c, states, tag, index, out, out_len, n, st);
+        if (c.rounds.alpha == 17) return launch_squeeze_quad<17>(c, states, tag, index, out, out_len, n, st);
+        return launch_squeeze_quad<0>(c, states, tag, index, out, out_len, n, st);
+    }
     PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st));
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
 }

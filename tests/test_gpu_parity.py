@@ -430,3 +430,27 @@ def test_device_resident_flow_with_the_abis_own_memory_helpers():
     _lib.check(lib.pmx_device_free(0, d_states))
     _lib.check(lib.pmx_device_free(0, d_out))
     assert lib.pmx_device_alloc(99, ctypes.byref(d_states), 16) == _lib.PMX_ERR_ARG
+
+
+@pytest.mark.parametrize("n", [16384, 16385])
+def test_sponge_driver_at_the_quad_kernel_switch(n):
+    """Up to 16384 mid-stream t = 3 sponges run on the quad kernels (one state per four lanes), more on the one-lane
+    kernels: both sides of the switch, mixed modes and indices, against the C restatement."""
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    cr = c_oracle(name)
+    f = cfg.field
+    b = S.BatchPoseidonSponge.new(cfg, n)
+    b.state[:] = synth.random_elements(f, n * 3, seed=n).reshape(n, 3, 4)
+    b.mode_index[::2] = 1
+    b.mode_index[5::7] = 2
+    b.mode_tag[3::5] = 1                                  # PMX_MODE_SQUEEZING, indices 0 / 1 / 2 mixed in
+    st0, tag0, idx0 = b.state.copy(), b.mode_tag.copy(), b.mode_index.copy()
+    msgs = synth.random_elements(f, n * 3, seed=n + 1).reshape(n, 3, 4)
+    b.absorb(msgs)
+    got = b.squeeze_native_field_elements(4)
+    for i in list(range(0, 64)) + list(range(n - 64, n)) + list(range(64, n - 64, 97)):
+        s, m, x = cr.sponge_absorb(st0[i], int(tag0[i]), int(idx0[i]), msgs[i])
+        s, m, x, out = cr.sponge_squeeze(s, m, x, 4)
+        assert np.array_equal(got[i], out) and np.array_equal(b.state[i], s), i
+        assert (int(b.mode_tag[i]), int(b.mode_index[i])) == (m, x), i
