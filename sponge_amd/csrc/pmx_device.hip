@@ -648,6 +648,71 @@ __global__ void __launch_bounds__(256, 2)
     if (active && e.q == 1) abi_store(reinterpret_cast<uint32_t *>(out + g * 4), digest);   // state[capacity]
 }
 
+// The permutation itself on the quad engine (any rate / capacity split of width 3: lane q holds element q).
+template <int ALPHA>
+__global__ void __launch_bounds__(256, 2)
+    permute_quad_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states, size_t n) {
+    QuadEngine<ALPHA> e(d, consts);
+    const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool active = g < n;
+    uint32_t *mine = reinterpret_cast<uint32_t *>(states + ((active ? g : 0) * 3 + e.role) * 4);
+    if (active && e.q < 3) e.s = fe_from_abi(abi_load(mine), e.f);
+    e.permute();
+    const Abi v = fe_to_abi(e.s, e.f);
+    if (active && e.q < 3) abi_store(mine, v);
+}
+
+// The fixed-shape hash on the quad engine (capacity 1, rate 2): the same wave-uniform state machine as hash_kernel.
+template <int ALPHA>
+__global__ void __launch_bounds__(256, 2)
+    hash_quad_kernel(const DevConfig d, const uint32_t *__restrict__ consts, const uint64_t *__restrict__ in, size_t in_len,
+                     uint64_t *__restrict__ out, size_t out_len, size_t n) {
+    QuadEngine<ALPHA> e(d, consts);
+    const Rounds &c = e.c;
+    const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool active = g < n;
+    const uint64_t *row_in = in + (active ? g : 0) * in_len * 4;
+    uint64_t *row_out = out + (active ? g : 0) * out_len * 4;
+    size_t k_in = 0, rem = out_len, pos = 0;
+    uint32_t idx = 0;
+    bool squeezing = false, need = false;
+    for (;;) {
+        if (need) {
+            e.permute();
+            need = false;
+        }
+        if (k_in < in_len) {                                   // absorb_internal, mod.rs:121-150
+            if (idx == c.rate) {                               // rate full and more input remains
+                need = true;
+                idx = 0;
+                continue;
+            }
+            Fe x = fe_zero();
+            if (active) x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row_in + 4 * k_in)), e.f);
+            if (e.q == c.capacity + idx) e.s = fe_normalize(fe_add_lazy(e.s, x));
+            ++idx;
+            ++k_in;
+            continue;
+        }
+        if (!squeezing) {                                      // Absorbing -> permute, squeeze from 0 (mod.rs:324-328)
+            squeezing = true;
+            need = true;
+            idx = 0;
+            continue;
+        }
+        const bool last = idx + rem <= c.rate;                 // squeeze_internal, mod.rs:153-182
+        const uint32_t take = last ? (uint32_t)rem : c.rate - idx;
+        const Abi v = fe_to_abi(e.s, e.f);
+        for (uint32_t k = 0; k < take; ++k)
+            if (active && e.q == c.capacity + idx + k) abi_store(reinterpret_cast<uint32_t *>(row_out + 4 * (pos + k)), v);
+        if (last) break;
+        need = rem != c.rate;                                  // mod.rs:175, tested before the slice is advanced
+        rem -= take;
+        pos += take;
+        idx = 0;
+    }
+}
+
 // The duplex-sponge driver on the quad engine (capacity 1, rate 2), same semantics as absorb_kernel / squeeze_kernel
 // below: a handful of sponges - the single PoseidonSponge of the trait shims - is all latency.  Mode and index are
 // per-sponge values, identical in the four lanes of a quad, so quads diverge as units.
@@ -921,12 +986,35 @@ static constexpr size_t kTabMinPermute = PMX_TAB_MIN_PERMUTE, kTabMinCompress = 
         }                                                                                            \
     } while (0)
 
+// the quad engine's table exists (t = 3, optimised schedule) and fits LDS; the lane of each element is fixed by the
+// split only where elements are addressed through capacity / rate (quad_shape below)
+static bool quad_table(const DevConfig &c, uint32_t t) {
+    return t == 3 && c.has_opt && (size_t)c.rounds.total_rounds * 3 * kCoopElems * kFeStride * 4 <= (size_t)c.max_lds_bytes;
+}
+static bool quad_shape(const DevConfig &c, uint32_t t) { return quad_table(c, t) && c.rounds.capacity == 1 && c.rounds.rate == 2; }
+
+// Small batches are latency: the quad engine up to this many states / rows / sponges (one dependent chain of 32 k instead
+// of 58-67 k instructions; above, the one-lane kernels fill the chip better).
+#ifndef PMX_QUAD_MAX_SPONGES
+#define PMX_QUAD_MAX_SPONGES 16384
+#endif
+#define PMX_QUAD_LAUNCH(KERNEL, ...)                                                                                        \
+    do {                                                                                                                    \
+        const dim3 grid_((unsigned)((n + 63) / 64));                                                                        \
+        if (c.rounds.alpha == 5) hipLaunchKernelGGL(KERNEL<5>, grid_, dim3(256), QuadEngine<5>::lds_bytes(c), st, c, c.consts, __VA_ARGS__);        \
+        else if (c.rounds.alpha == 17) hipLaunchKernelGGL(KERNEL<17>, grid_, dim3(256), QuadEngine<17>::lds_bytes(c), st, c, c.consts, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<0>, grid_, dim3(256), QuadEngine<0>::lds_bytes(c), st, c, c.consts, __VA_ARGS__);    \
+        return hipGetLastError();                                                                                           \
+    } while (0)
+
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
+    if (quad_table(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(permute_quad_kernel, states, n);
     PMX_SMALL_BATCH(kTabMinPermute, permute(c, t, states, n, st));
     PMX_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                        size_t n, hipStream_t st) {
+    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(hash_quad_kernel, in, in_len, out, out_len, n);
     PMX_SMALL_BATCH(kTabMinPermute, hash(c, t, in, in_len, out, out_len, n, st));
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
@@ -946,12 +1034,6 @@ static hipError_t launch_compress_coop(const DevConfig &c, const uint64_t *in, u
     return hipGetLastError();
 }
 
-// the quad engine hard-codes the lane of each element (capacity 1, rate 2: state [c, r0, r1]) and stages its table in LDS
-static bool quad_shape(const DevConfig &c, uint32_t t) {
-    return t == 3 && c.has_opt && c.rounds.capacity == 1 && c.rounds.rate == 2 &&
-           (size_t)c.rounds.total_rounds * 3 * kCoopElems * kFeStride * 4 <= (size_t)c.max_lds_bytes;
-}
-
 hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
     // (the split (rate 3, capacity 0) of the same width takes the one-lane-per-state kernel at every level)
     if (quad_shape(c, t) && n <= kCoopMaxUnits) {
@@ -963,42 +1045,15 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
     PMX_DISPATCH(compress(c, t, in, out, n, st));
 }
 
-// Mid-stream sponges in small numbers (one, for the trait shims) are latency as well: the quad engine up to this many.
-#ifndef PMX_QUAD_MAX_SPONGES
-#define PMX_QUAD_MAX_SPONGES 16384
-#endif
-template <int ALPHA>
-static hipError_t launch_absorb_quad(const DevConfig &c, uint64_t *states, uint32_t *tag, uint32_t *index, const uint64_t *in,
-                                     size_t in_len, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(absorb_quad_kernel<ALPHA>, dim3((unsigned)((n + 63) / 64)), dim3(256), QuadEngine<ALPHA>::lds_bytes(c), st, c, c.consts,
-                       states, tag, index, in, in_len, n);
-    return hipGetLastError();
-}
-template <int ALPHA>
-static hipError_t launch_squeeze_quad(const DevConfig &c, uint64_t *states, uint32_t *tag, uint32_t *index, uint64_t *out,
-                                      size_t out_len, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(squeeze_quad_kernel<ALPHA>, dim3((unsigned)((n + 63) / 64)), dim3(256), QuadEngine<ALPHA>::lds_bytes(c), st, c, c.consts,
-                       states, tag, index, out, out_len, n);
-    return hipGetLastError();
-}
-
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {
-    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) {
-        if (c.rounds.alpha == 5) return launch_absorb_quad<5>(c, states, tag, index, in, in_len, n, st);
-        if (c.rounds.alpha == 17) return launch_absorb_quad<17>(c, states, tag, index, in, in_len, n, st);
-        return launch_absorb_quad<0>(c, states, tag, index, in, in_len, n, st);
-    }
+    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(absorb_quad_kernel, states, tag, index, in, in_len, n);
     PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st));
     PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st));
 }
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
-    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) {
-        if (c.rounds.alpha == 5) return launch_squeeze_quad<5>(c, states, tag, index, out, out_len, n, st);
-        if (c.rounds.alpha == 17) return launch_squeeze_quad<17>(c, states, tag, index, out, out_len, n, st);
-        return launch_squeeze_quad<0>(c, states, tag, index, out, out_len, n, st);
-    }
+    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
     PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st));
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
 }

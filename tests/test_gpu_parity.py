@@ -454,3 +454,16 @@ def test_sponge_driver_at_the_quad_kernel_switch(n):
         s, m, x, out = cr.sponge_squeeze(s, m, x, 4)
         assert np.array_equal(got[i], out) and np.array_equal(b.state[i], s), i
         assert (int(b.mode_tag[i]), int(b.mode_index[i])) == (m, x), i
+
+
+@pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31"])
+def test_one_lane_element_form_kernels_between_the_switches(name):
+    """t = 3 launches of 16385 .. 2^17 - 1 units take the one-lane-per-state kernels in their element form (below: the
+    quad kernels, above: the table form).  20000 units through permute and the hash driver, whole batch against the C port."""
+    cfg = product_config(name)
+    cr = c_oracle(name)
+    n = 20000
+    states = synth.random_elements(cfg.field, n * 3, seed=0x5EED0060).reshape(n, 3, 4)
+    assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0))
+    msgs = synth.random_elements(cfg.field, n * 5, seed=0x5EED0061).reshape(n, 5, 4)
+    assert np.array_equal(cfg.context().hash_batch(msgs, 5, 3), cr.hash_batch(msgs, 5, 3, threads=0))
