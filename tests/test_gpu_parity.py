@@ -432,9 +432,9 @@ def test_device_resident_flow_with_the_abis_own_memory_helpers():
     assert lib.pmx_device_alloc(99, ctypes.byref(d_states), 16) == _lib.PMX_ERR_ARG
 
 
-@pytest.mark.parametrize("n", [16384, 16385])
+@pytest.mark.parametrize("n", [32768, 32769])
 def test_sponge_driver_at_the_quad_kernel_switch(n):
-    """Up to 16384 mid-stream t = 3 sponges run on the quad kernels (one state per four lanes), more on the one-lane
+    """Up to 32768 mid-stream t = 3 sponges run on the quad kernels (one state per four lanes), more on the one-lane
     kernels: both sides of the switch, mixed modes and indices, against the C restatement."""
     name = "bls_t3_a5_8_31"
     cfg = product_config(name)
@@ -458,11 +458,11 @@ def test_sponge_driver_at_the_quad_kernel_switch(n):
 
 @pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31"])
 def test_one_lane_element_form_kernels_between_the_switches(name):
-    """t = 3 launches of 16385 .. 2^17 - 1 units take the one-lane-per-state kernels in their element form (below: the
-    quad kernels, above: the table form).  20000 units through permute and the hash driver, whole batch against the C port."""
+    """t = 3 launches of 32769 .. 2^17 - 1 units take the one-lane-per-state kernels in their element form (below: the
+    quad kernels, above: the table form).  40000 units through permute and the hash driver, whole batch against the C port."""
     cfg = product_config(name)
     cr = c_oracle(name)
-    n = 20000
+    n = 40000
     states = synth.random_elements(cfg.field, n * 3, seed=0x5EED0060).reshape(n, 3, 4)
     assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0))
     msgs = synth.random_elements(cfg.field, n * 5, seed=0x5EED0061).reshape(n, 5, 4)
