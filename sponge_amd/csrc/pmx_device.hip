@@ -13,7 +13,8 @@
 //                              (shifted tables for everything at t <= 5, for the identity lanes above).
 //   LdsEngine<ALPHA>           any width at run time (t = 2, 10..16, or no partial section): state kept in LDS as
 //                              [element][limb][lane] (conflict-free 4-byte accesses), element loops rolled.
-// plus compress_coop_kernel: 2-to-1 compression with one state per quad of lanes, for latency-bound tree levels.
+//   QuadEngine<ALPHA>          t = 3, launches of <= 32768 units (latency-bound: narrow tree levels, a handful of sponges):
+//                              one state per quad of lanes, sparse rounds three multiplications deep.
 //
 // Reference semantics implemented here (file:line in /root/reference):
 //   permute        src/poseidon/mod.rs:95-118   (apply_ark :76-80, apply_s_box :63-74, apply_mds :82-93)
