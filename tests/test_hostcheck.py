@@ -231,6 +231,21 @@ def test_identity_lane_magnitudes_stay_inside_their_bounds(hc):
             worst[(name, tag)] = float(b[0])
     # the lanes really do run uncapped for tens of rounds (the check above is not vacuous)
     assert worst[("bls_t9_a5_8_57", 1)] > 8.0
+    # the quad engine's folded sparse rounds (t = 3, alpha 5 / 17) accumulate their lanes the same way; row 0 there is
+    # x^4 (x m00) + (v_1 s_1 + v_2 s_2): below 6 p, limbs normalised
+    for name, f in [("bls_t3_a5_8_31", S.BLS12_381_FR), ("bls_t3_a17_8_31", S.BLS12_381_FR), ("bn254_t3_a5_8_57", S.BN254_FR)]:
+        cfg = oracle_config(name)
+        states = synth.random_elements(f, 96 * 3, seed=6).reshape(96, 3, 4)
+        edge = cref.elems_to_limbs([cfg.p - 1] * 3 + [0] * 3 + [1] * 3, cfg.p).reshape(3, 3, 4)
+        states = np.concatenate([states, edge])
+        hc.hc_track_reset()
+        assert np.array_equal(run_permute(hc, name, states, coop=True), cref.CRef(cfg).permute_batch(states, threads=0))
+        for tag, limit in [(0, 6.0), (1, 2.2 + 1.0204 * (cfg.partial_rounds - 1))]:
+            limb = np.zeros(1, dtype=np.uint32)
+            b = np.zeros(1, dtype=np.float64)
+            hc.hc_track_get(tag, limb.ctypes.data, b.ctypes.data)
+            assert 0 < int(limb[0]) < (1 << 29), (name, tag, int(limb[0]))
+            assert 0 < float(b[0]) < limit, (name, tag, float(b[0]))
 
 
 def test_long_partial_sections_leave_the_optimised_schedule(hc):
