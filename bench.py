@@ -446,6 +446,7 @@ def run_verification(env):
         in_len, out_len = env["in_len"], env["out_len"]
         host, d_in = env["fresh_inputs"]()
         d_out = torch.zeros((n, out_len, 4), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()     # the fills above ran on torch's stream; the library's stream is non-blocking
         ctx.hash_batch_dev(d_in.data_ptr(), in_len, d_out.data_ptr(), out_len, n, stream.cuda_stream)
         torch.cuda.synchronize()
         idx = sample_indices(n, 2048)
@@ -457,12 +458,15 @@ def run_verification(env):
         nodes = torch.zeros((2 * n - 1, 4), dtype=torch.int64, device=dev)
         nodes[:n] = d_leaves.reshape(n, 4)
         top = torch.zeros((max(2 * world - 1, 1), 4), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()     # leaves copied and buffers zeroed (torch's stream) before the library's stream reads them
         if group is not None:
             group.merkle_2to1_dev([nodes.data_ptr()], [top.data_ptr()], n_total)
         else:
             ctx.merkle_2to1_dev(nodes.data_ptr(), n, stream.cuda_stream)
             if world > 1:
+                torch.cuda.synchronize()
                 env["torch_all_gather"](nodes[2 * n - 2:2 * n - 1], top[:world])
+                torch.cuda.synchronize()
                 ctx.merkle_2to1_dev(top.data_ptr(), world, stream.cuda_stream)
         torch.cuda.synchronize()
         got = to_np(nodes)
@@ -487,16 +491,19 @@ def run_verification(env):
     else:
         host, fresh = env["fresh_inputs"]()
         fresh = fresh.reshape(n, t, 4)
+        gathered = env.get("gathered")
+        if world > 1 and gathered is not None:
+            gathered.zero_()
+        torch.cuda.synchronize()     # upload and fill (torch's stream) complete before the library's non-blocking stream starts
         if group is not None:
             group.permute_shards_dev([fresh.data_ptr()], n_total)
         else:
             ctx.permute_batch_dev(fresh.data_ptr(), n, stream.cuda_stream)
-        gathered = env.get("gathered")
         if world > 1 and gathered is not None:
-            gathered.zero_()
             if group is not None:
                 group.all_gather_dev([fresh.data_ptr()], [gathered.data_ptr()], n_total, t)
             else:
+                torch.cuda.synchronize()
                 env["torch_all_gather"](fresh, gathered)
             torch.cuda.synchronize()
             ok, checked = True, 0

@@ -78,6 +78,9 @@ extern "C" {
     pub fn pmx_merkle_paths(nodes: *const u64, n_leaves: usize, indices: *const u64, k: usize, paths_out: *mut u64) -> c_int;
     pub fn pmx_merkle_verify_paths(ctx: *mut pmx_ctx, leaves: *const u64, indices: *const u64, paths: *const u64, depth: usize,
                                    k: usize, root: *const u64, ok_out: *mut u8) -> c_int;
+    pub fn pmx_merkle_verify_paths_dev(ctx: *mut pmx_ctx, d_leaves: *const u64, d_indices: *const u64, d_paths: *const u64,
+                                       depth: usize, k: usize, d_root: *const u64, d_ok: *mut u8, d_work: *mut u64,
+                                       stream: *mut c_void) -> c_int;
     // device memory for the *_dev entry points
     pub fn pmx_device_alloc(device: c_int, d_ptr: *mut *mut c_void, bytes: usize) -> c_int;
     pub fn pmx_device_free(device: c_int, d_ptr: *mut c_void) -> c_int;
@@ -106,6 +109,7 @@ extern "C" {
                                    row_elems: usize) -> c_int;
     pub fn pmx_mgpu_merkle_2to1_dev(g: *mut pmx_mgpu, d_nodes: *const *mut u64, d_top: *const *mut u64, n_leaves: usize) -> c_int;
     pub fn pmx_mgpu_merkle_2to1(g: *mut pmx_mgpu, leaves: *const u64, n_leaves: usize, root: *mut u64) -> c_int;
+    pub fn pmx_mgpu_test_fault(fail_local: c_int, no_threads: c_int) -> c_int;
     // diagnostics
     pub fn pmx_diag_int_valu_peak(device: c_int, seconds: f64, out: *mut pmx_valu_peak) -> c_int;
 }

@@ -213,14 +213,18 @@ impl<F: PrimeField> BatchPoseidon<F> {
     /// Authentication paths of `indices` over a node array made by `merkle`: `[k][depth]` siblings, bottom-up.
     pub fn merkle_paths(&self, nodes: &[F], indices: &[u64]) -> Vec<F> {
         let n_leaves = (nodes.len() + 1) / 2;
+        assert!(n_leaves.is_power_of_two() && nodes.len() == 2 * n_leaves - 1, "nodes is not a node array made by merkle()");
         let depth = n_leaves.trailing_zeros() as usize;
         let mut paths = vec![F::zero(); indices.len() * depth];
         check(unsafe { ffi::pmx_merkle_paths(limbs(nodes), n_leaves, indices.as_ptr(), indices.len(), limbs_mut(&mut paths)) });
         paths
     }
-    /// `k` paths checked at once (one batched 2-to-1 hash per level): `true` where `leaves[i]` hashes up to `root`.
+    /// `k` paths checked at once (one upload, one device step per level, one download): `true` where `leaves[i]` hashes up
+    /// to `root` along `paths[i]` and `indices[i]` names a leaf of a tree of that depth.
     pub fn verify_paths(&self, leaves: &[F], indices: &[u64], paths: &[F], root: &F) -> Vec<bool> {
         let k = leaves.len();
+        assert_eq!(indices.len(), k, "one index per leaf");
+        assert!(k == 0 || paths.len() % k == 0, "paths is not [k][depth]");
         let depth = if k == 0 { 0 } else { paths.len() / k };
         let mut ok = vec![0u8; k];
         check(unsafe { ffi::pmx_merkle_verify_paths(self.ctx.0, limbs(leaves), indices.as_ptr(), limbs(paths), depth, k,

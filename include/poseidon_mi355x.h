@@ -16,7 +16,8 @@
  *
  * All functions return PMX_OK (0) or a negative pmx_status; pmx_last_error() gives the message of the
  * calling thread's last failure.  Nothing throws or aborts across the boundary (the reference panics:
- * src/poseidon/mod.rs:196-203).  There is NO CPU fallback: without a usable HIP device every data-path
+ * src/poseidon/mod.rs:196-203): every entry point that allocates, locks or spawns runs inside a catch-all that turns
+ * std::bad_alloc / std::system_error / anything else into PMX_ERR_HOST.  There is NO CPU fallback: without a usable HIP device every data-path
  * call fails with PMX_ERR_HIP.
  *
  * Threading: the host-buffer entry points of one pmx_ctx serialise on a lock inside the context (they share its
@@ -44,7 +45,8 @@ typedef enum pmx_status {
     PMX_ERR_ARG = -2,         /* null pointer / bad size / bad mode word */
     PMX_ERR_HIP = -3,         /* HIP runtime failure or no device */
     PMX_ERR_UNSUPPORTED = -4, /* width without a compiled kernel */
-    PMX_ERR_RCCL = -5         /* RCCL failure in a device group (pmx_mgpu_*) */
+    PMX_ERR_RCCL = -5,        /* RCCL failure in a device group (pmx_mgpu_*) */
+    PMX_ERR_HOST = -6         /* host resource failure inside the library: out of memory, a lock or a thread could not be made */
 } pmx_status;
 
 /* DuplexSpongeMode (src/lib.rs:198-210) as two words per sponge: tag + index. */
@@ -56,7 +58,7 @@ typedef enum pmx_status {
  * duration of pmx_ctx_create only.
  */
 typedef struct pmx_config {
-    uint32_t full_rounds;            /* PoseidonConfig::full_rounds (even; RF/2 before and after the partial rounds) */
+    uint32_t full_rounds;            /* PoseidonConfig::full_rounds (RF/2 before the partial rounds, RF - RF/2 after, mod.rs:96-116) */
     uint32_t partial_rounds;         /* PoseidonConfig::partial_rounds */
     uint64_t alpha;                  /* PoseidonConfig::alpha, S-box exponent */
     uint32_t rate;                   /* PoseidonConfig::rate */
@@ -167,11 +169,15 @@ int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_leaves, void *
  * (new; absorb([left, right]); squeeze_native(1))[0] as above.  depth = log2(n_leaves).
  * pmx_merkle_paths: host-only gather - paths_out [k][depth][4] receives, for each indices[i], the sibling of the leaf and
  * of each ancestor, bottom-up.
- * pmx_merkle_verify_paths: k paths at once, one batched 2-to-1 hash call per level: ok_out[i] = 1 iff hashing leaves[i]
- * up its path (indices[i] says left / right at each level) gives `root`. */
+ * pmx_merkle_verify_paths: k paths at once - one upload, `depth` level steps on the device (each a batched 2-to-1
+ * compression of all k running nodes), one download: ok_out[i] = 1 iff hashing leaves[i] up its path (indices[i] says
+ * left / right at each level) gives `root` and indices[i] < 2^depth.
+ * pmx_merkle_verify_paths_dev: the same on device-resident buffers, enqueue only; d_work is [k][12] u64 of scratch. */
 int pmx_merkle_paths(const uint64_t *nodes, size_t n_leaves, const uint64_t *indices, size_t k, uint64_t *paths_out);
 int pmx_merkle_verify_paths(pmx_ctx *ctx, const uint64_t *leaves, const uint64_t *indices, const uint64_t *paths, size_t depth,
                             size_t k, const uint64_t root[PMX_LIMBS], uint8_t *ok_out);
+int pmx_merkle_verify_paths_dev(pmx_ctx *ctx, const uint64_t *d_leaves, const uint64_t *d_indices, const uint64_t *d_paths,
+                                size_t depth, size_t k, const uint64_t *d_root, uint8_t *d_ok, uint64_t *d_work, void *stream);
 
 /* ---- device groups: the batch sharded over the GPUs of one node -------------------------------------
  * The reference is single-threaded and has no distributed code; nothing in src/poseidon/mod.rs:62-183 couples one
@@ -237,6 +243,11 @@ int pmx_mgpu_all_gather_dev(pmx_mgpu *g, const uint64_t *const *d_shards, uint64
 int pmx_mgpu_merkle_2to1_dev(pmx_mgpu *g, uint64_t *const *d_nodes, uint64_t *const *d_top, size_t n_leaves);
 /* Host leaves [n_leaves][4] -> root [4] (single-process groups). */
 int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t n_leaves, uint64_t *root);
+
+/* Test hook: the host fan-out of pmx_mgpu_permute_batch / _hash_batch fails on local device `fail_local` (-1: off) and,
+ * with no_threads != 0, runs as if no worker thread could be started (the shards then go one after the other on the
+ * calling thread).  Process-wide; for the library's own tests. */
+int pmx_mgpu_test_fault(int fail_local, int no_threads);
 
 /* ---- diagnostics ---------------------------------------------------------------------------------------
  * The binding roofline of these kernels is the issue rate of v_mad_u64_u32 (one per 32x32-bit limb product), not

@@ -17,6 +17,7 @@ PMX_ERR_ARG = -2
 PMX_ERR_HIP = -3
 PMX_ERR_UNSUPPORTED = -4
 PMX_ERR_RCCL = -5
+PMX_ERR_HOST = -6
 
 ABI_VERSION = 2
 UNIQUE_ID_BYTES = 128
@@ -100,6 +101,8 @@ SIGNATURES = {
     "pmx_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, ctypes.c_void_p]),
     "pmx_merkle_paths": (ctypes.c_int, [_u64p, _sz, _u64p, _sz, _u64p]),
     "pmx_merkle_verify_paths": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u64p, _u64p, _sz, _sz, _u64p, ctypes.c_void_p]),
+    "pmx_merkle_verify_paths_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u64p, _u64p, _sz, _sz, _u64p, ctypes.c_void_p, _u64p,
+                                                   ctypes.c_void_p]),
     # device groups
     "pmx_shard_bounds": (ctypes.c_int, [_sz, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "pmx_mgpu_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
@@ -118,6 +121,7 @@ SIGNATURES = {
     "pmx_mgpu_all_gather_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
     "pmx_mgpu_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz]),
     "pmx_mgpu_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p]),
+    "pmx_mgpu_test_fault": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     # diagnostics
     "pmx_diag_int_valu_peak": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.POINTER(PmxValuPeak)]),
 }

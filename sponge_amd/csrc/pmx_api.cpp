@@ -82,6 +82,7 @@ extern "C" int pmx_device_count(void) {
 }
 
 extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) {
+    PMX_ABI_BEGIN("pmx_ctx_create")
     if (!cfg || !out) return set_error(PMX_ERR_ARG, "pmx_ctx_create: null pointer");
     *out = nullptr;
     if (!cfg->ark || !cfg->mds) return set_error(PMX_ERR_ARG, "pmx_ctx_create: null ark/mds");
@@ -95,7 +96,7 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     if (device < 0 || device >= ndev) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
 
     pmx_ctx *ctx = new (std::nothrow) pmx_ctx();
-    if (!ctx) return set_error(PMX_ERR_ARG, "out of host memory");
+    if (!ctx) return set_error(PMX_ERR_HOST, "pmx_ctx_create: out of host memory");
     ctx->device = device;
     ctx->t = pp.t;
     DeviceGuard guard(device);
@@ -135,6 +136,7 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.one = pp.one;
     *out = ctx;
     return PMX_OK;
+    PMX_ABI_END
 }
 
 static int ctx_free(pmx_ctx *ctx) {
@@ -195,7 +197,27 @@ uint64_t fnv1a(const std::string &b) {
 }
 }  // namespace
 
+// The cache lock is held only for the bookkeeping: a context is created (table derivation, hipMalloc, upload) and freed
+// (stream synchronise, hipFree) outside it, so one thread building or evicting a context never stalls another thread's
+// acquire or release.  Two threads that miss on the same new config both build one; the second to come back finds the
+// first one's entry, takes a reference on it and frees its own.
+static pmx_ctx *cache_find(CtxCache &cc, uint64_t key, const std::string &blob) {
+    auto it = cc.by_key.find(key);
+    if (it == cc.by_key.end()) return nullptr;
+    for (pmx_ctx *c : it->second) {
+        if (c->cache_blob == blob) {
+            if (c->cache_refs++ == 0) {
+                for (auto d = cc.idle.begin(); d != cc.idle.end(); ++d)
+                    if (*d == c) { cc.idle.erase(d); break; }
+            }
+            return c;
+        }
+    }
+    return nullptr;
+}
+
 extern "C" int pmx_ctx_acquire(const pmx_config *cfg, int device, pmx_ctx **out) {
+    PMX_ABI_BEGIN("pmx_ctx_acquire")
     if (!cfg || !out) return set_error(PMX_ERR_ARG, "pmx_ctx_acquire: null pointer");
     *out = nullptr;
     if (!cfg->ark || !cfg->mds) return set_error(PMX_ERR_ARG, "pmx_ctx_acquire: null ark/mds");
@@ -204,66 +226,90 @@ extern "C" int pmx_ctx_acquire(const pmx_config *cfg, int device, pmx_ctx **out)
     std::string blob = config_blob(cfg, device);
     const uint64_t key = fnv1a(blob);
     CtxCache &cc = ctx_cache();
-    std::lock_guard<std::mutex> lock(cc.lock);
-    auto &bucket = cc.by_key[key];
-    for (pmx_ctx *c : bucket) {
-        if (c->cache_blob == blob) {
-            if (c->cache_refs++ == 0) {
-                for (auto it = cc.idle.begin(); it != cc.idle.end(); ++it)
-                    if (*it == c) { cc.idle.erase(it); break; }
-            }
-            *out = c;
-            return PMX_OK;
+    {
+        std::lock_guard<std::mutex> lock(cc.lock);
+        if (pmx_ctx *c = cache_find(cc, key, blob)) { *out = c; return PMX_OK; }
+    }
+    pmx_ctx *fresh = nullptr;
+    int rc = pmx_ctx_create(cfg, device, &fresh);   // not under the lock
+    if (rc) return rc;
+    pmx_ctx *winner = nullptr;
+    try {
+        std::lock_guard<std::mutex> lock(cc.lock);
+        winner = cache_find(cc, key, blob);
+        if (!winner) {
+            fresh->cache_blob = std::move(blob);
+            cc.by_key[key].push_back(fresh);
+            fresh->cache_key = key;      // set last: from here on the context belongs to the cache
+            fresh->cache_refs = 1;
         }
+    } catch (...) {
+        auto it = cc.by_key.find(key);   // (a bucket the failed insert may have left empty)
+        if (it != cc.by_key.end() && it->second.empty()) cc.by_key.erase(it);
+        (void)ctx_free(fresh);
+        throw;
     }
-    pmx_ctx *c = nullptr;
-    int rc = pmx_ctx_create(cfg, device, &c);
-    if (rc) {
-        if (bucket.empty()) cc.by_key.erase(key);
-        return rc;
+    if (winner) {
+        (void)ctx_free(fresh);
+        *out = winner;
+    } else {
+        *out = fresh;
     }
-    c->cache_key = key;
-    c->cache_refs = 1;
-    c->cache_blob = std::move(blob);
-    bucket.push_back(c);
-    *out = c;
     return PMX_OK;
+    PMX_ABI_END
 }
 
-static void cache_evict(CtxCache &cc, pmx_ctx *c) {
-    auto &bucket = cc.by_key[c->cache_key];
-    for (auto it = bucket.begin(); it != bucket.end(); ++it)
-        if (*it == c) { bucket.erase(it); break; }
-    if (bucket.empty()) cc.by_key.erase(c->cache_key);
-    (void)ctx_free(c);
+// unlinks a context from its bucket (the caller holds the lock and frees it after letting go)
+static void cache_unlink(CtxCache &cc, pmx_ctx *c) {
+    auto b = cc.by_key.find(c->cache_key);
+    if (b == cc.by_key.end()) return;
+    for (auto it = b->second.begin(); it != b->second.end(); ++it)
+        if (*it == c) { b->second.erase(it); break; }
+    if (b->second.empty()) cc.by_key.erase(b);
 }
 
 extern "C" int pmx_ctx_release(pmx_ctx *ctx) {
+    PMX_ABI_BEGIN("pmx_ctx_release")
     if (!ctx) return PMX_OK;
     if (!ctx->cache_key) return set_error(PMX_ERR_ARG, "pmx_ctx_release: this context came from pmx_ctx_create; use pmx_ctx_destroy");
     CtxCache &cc = ctx_cache();
-    std::lock_guard<std::mutex> lock(cc.lock);
-    if (ctx->cache_refs <= 0) return set_error(PMX_ERR_ARG, "pmx_ctx_release: released more often than acquired");
-    if (--ctx->cache_refs == 0) {
-        cc.idle.push_back(ctx);
-        while (cc.idle.size() > kMaxIdle) {
-            pmx_ctx *old = cc.idle.front();
-            cc.idle.pop_front();
-            cache_evict(cc, old);
+    std::vector<pmx_ctx *> evicted;
+    evicted.reserve(2);   // (nothing below may fail between unlinking a context and remembering it)
+    {
+        std::lock_guard<std::mutex> lock(cc.lock);
+        if (ctx->cache_refs <= 0) return set_error(PMX_ERR_ARG, "pmx_ctx_release: released more often than acquired");
+        if (--ctx->cache_refs == 0) {
+            cc.idle.push_back(ctx);
+            while (cc.idle.size() > kMaxIdle) {
+                pmx_ctx *old = cc.idle.front();
+                cc.idle.pop_front();
+                cache_unlink(cc, old);
+                evicted.push_back(old);
+            }
         }
     }
+    for (pmx_ctx *old : evicted) (void)ctx_free(old);   // stream synchronise + hipFree: not under the lock
     return PMX_OK;
+    PMX_ABI_END
 }
 
 extern "C" int pmx_ctx_cache_clear(void) {
+    PMX_ABI_BEGIN("pmx_ctx_cache_clear")
     CtxCache &cc = ctx_cache();
-    std::lock_guard<std::mutex> lock(cc.lock);
-    while (!cc.idle.empty()) {
-        pmx_ctx *old = cc.idle.front();
-        cc.idle.pop_front();
-        cache_evict(cc, old);
+    std::vector<pmx_ctx *> evicted;
+    {
+        std::lock_guard<std::mutex> lock(cc.lock);
+        evicted.reserve(cc.idle.size());
+        while (!cc.idle.empty()) {
+            pmx_ctx *old = cc.idle.front();
+            cc.idle.pop_front();
+            cache_unlink(cc, old);
+            evicted.push_back(old);
+        }
     }
+    for (pmx_ctx *old : evicted) (void)ctx_free(old);
     return PMX_OK;
+    PMX_ABI_END
 }
 
 extern "C" int pmx_ctx_width(const pmx_ctx *ctx) { return ctx ? (int)ctx->t : 0; }
@@ -364,6 +410,7 @@ extern "C" int pmx_permute_batch_dev(pmx_ctx *ctx, uint64_t *d_states, size_t n,
 }
 
 extern "C" int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n) {
+    PMX_ABI_BEGIN("pmx_permute_batch")
     if (!ctx || (!states && n)) return set_error(PMX_ERR_ARG, "pmx_permute_batch: null pointer");
     if (n == 0) return PMX_OK;
     PMX_BIND(ctx);
@@ -388,6 +435,7 @@ extern "C" int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n) {
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream2));
     return PMX_OK;
+    PMX_ABI_END
 }
 
 // ---- hash ----------------------------------------------------------------------------------------
@@ -409,6 +457,7 @@ extern "C" int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_
 }
 
 extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n) {
+    PMX_ABI_BEGIN("pmx_hash_batch")
     if (!ctx || (!in && n && in_len) || (!out && n && out_len)) return set_error(PMX_ERR_ARG, "pmx_hash_batch: null pointer");
     if (n == 0) return PMX_OK;
     PMX_BIND(ctx);
@@ -435,6 +484,7 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream2));
     return PMX_OK;
+    PMX_ABI_END
 }
 
 // ---- duplex sponge driver ------------------------------------------------------------------------
@@ -474,6 +524,7 @@ static int check_modes(const pmx_ctx *ctx, const uint32_t *tag, const uint32_t *
 
 static int sponge_host(pmx_ctx *ctx, uint64_t *states, uint32_t *tag, uint32_t *index, const uint64_t *in, uint64_t *out,
                        size_t len, size_t n, bool absorb) {
+    PMX_ABI_BEGIN("pmx_sponge_*_batch")
     if (!ctx || ((!states || !tag || !index) && n)) return set_error(PMX_ERR_ARG, "pmx_sponge_*_batch: null pointer");
     if (n == 0) return PMX_OK;
     if (absorb && len == 0) return PMX_OK;
@@ -533,6 +584,7 @@ static int sponge_host(pmx_ctx *ctx, uint64_t *states, uint32_t *tag, uint32_t *
     if (!absorb && io_bytes) PMX_HIP(hipMemcpyAsync(out, d_io, io_bytes, hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
+    PMX_ABI_END
 }
 
 extern "C" int pmx_sponge_absorb_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
@@ -565,6 +617,7 @@ extern "C" int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_lea
 }
 
 extern "C" int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint64_t *nodes, uint64_t *root) {
+    PMX_ABI_BEGIN("pmx_merkle_2to1")
     if (!ctx || !leaves) return set_error(PMX_ERR_ARG, "pmx_merkle_2to1: null pointer");
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return set_error(PMX_ERR_ARG, "n_leaves must be a power of two");
     PMX_BIND(ctx);
@@ -581,6 +634,7 @@ extern "C" int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_le
     if (root) PMX_HIP(hipMemcpyAsync(root, (uint64_t *)d + (n_nodes - 1) * 4, 32, hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
+    PMX_ABI_END
 }
 
 // ---- authentication paths ---------------------------------------------------------------------------------------------
@@ -602,25 +656,60 @@ extern "C" int pmx_merkle_paths(const uint64_t *nodes, size_t n_leaves, const ui
     return PMX_OK;
 }
 
+// k authentication paths advance one level per launch, everything resident on the device: cur[i] starts as leaves[i];
+// per level a gather kernel lays (cur[i], sibling) out as the pair array one tree level has - left / right by bit `level`
+// of indices[i] - and the 2-to-1 compression launcher (quad kernel for k <= 32768) writes the parents back into cur.
+// d_work: [k][12] u64 of scratch (cur [k][4], then pairs [k][8]).  d_ok[i] = 1 iff cur[i] == root after `depth` levels and
+// indices[i] < 2^depth (an index with bits at or above `depth` names no leaf of this tree).
+extern "C" int pmx_merkle_verify_paths_dev(pmx_ctx *ctx, const uint64_t *d_leaves, const uint64_t *d_indices, const uint64_t *d_paths,
+                                           size_t depth, size_t k, const uint64_t *d_root, uint8_t *d_ok, uint64_t *d_work, void *stream) {
+    if (!ctx || ((!d_leaves || !d_indices || !d_ok || !d_work) && k) || (!d_paths && k && depth) || !d_root)
+        return set_error(PMX_ERR_ARG, "pmx_merkle_verify_paths_dev: null pointer");
+    if (ctx->dev.rounds.rate < 2) return set_error(PMX_ERR_CONFIG, "2-to-1 compression needs rate >= 2");
+    if (depth >= 64) return set_error(PMX_ERR_ARG, "depth out of range");
+    if (k == 0) return PMX_OK;
+    if (k > (size_t)0x7fffffff * 64 || (depth && k > (SIZE_MAX / 32) / depth)) return set_error(PMX_ERR_ARG, "batch too large");
+    if (!aligned16(d_leaves) || !aligned16(d_paths) || !aligned16(d_work) || !aligned16(d_root)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    PMX_BIND(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t *cur = d_work, *pairs = d_work + k * 4;
+    PMX_HIP(hipMemcpyAsync(cur, d_leaves, k * 32, hipMemcpyDeviceToDevice, st));
+    for (size_t level = 0; level < depth; ++level) {
+        PMX_HIP(launch_path_pairs(cur, d_paths, d_indices, depth, level, pairs, k, st));
+        PMX_HIP(launch_compress(ctx->dev, ctx->t, pairs, cur, k, st));
+    }
+    PMX_HIP(launch_path_check(cur, d_root, d_indices, depth, d_ok, k, st));
+    return PMX_OK;
+}
+
+// Host buffers: one upload of (leaves, indices, paths, root), `depth` level steps on the device, one download of ok.
 extern "C" int pmx_merkle_verify_paths(pmx_ctx *ctx, const uint64_t *leaves, const uint64_t *indices, const uint64_t *paths,
                                        size_t depth, size_t k, const uint64_t root[PMX_LIMBS], uint8_t *ok_out) {
+    PMX_ABI_BEGIN("pmx_merkle_verify_paths")
     if (!ctx || ((!leaves || !indices || !ok_out) && k) || (!paths && k && depth) || !root)
         return set_error(PMX_ERR_ARG, "pmx_merkle_verify_paths: null pointer");
     if (ctx->dev.rounds.rate < 2) return set_error(PMX_ERR_CONFIG, "2-to-1 compression needs rate >= 2");
     if (depth >= 64) return set_error(PMX_ERR_ARG, "depth out of range");
     if (k == 0) return PMX_OK;
-    if (k > SIZE_MAX / 64) return set_error(PMX_ERR_ARG, "batch byte size overflows size_t");
-    std::vector<uint64_t> cur(leaves, leaves + k * 4), pairs(k * 8);
-    for (size_t level = 0; level < depth; ++level) {
-        for (size_t i = 0; i < k; ++i) {
-            const bool right = (indices[i] >> level) & 1;   // the running node is the right child at this level
-            const uint64_t *sib = paths + (i * depth + level) * 4;
-            std::memcpy(&pairs[i * 8 + (right ? 4 : 0)], &cur[i * 4], 32);
-            std::memcpy(&pairs[i * 8 + (right ? 0 : 4)], sib, 32);
-        }
-        int rc = pmx_hash_batch(ctx, pairs.data(), 2, cur.data(), 1, k);
-        if (rc) return rc;
-    }
-    for (size_t i = 0; i < k; ++i) ok_out[i] = std::memcmp(&cur[i * 4], root, 32) == 0 ? 1 : 0;
+    if (k > SIZE_MAX / 128 || (depth && k > (SIZE_MAX / 32) / depth)) return set_error(PMX_ERR_ARG, "batch byte size overflows size_t");
+    PMX_BIND(ctx);
+    int rc = PMX_OK;
+    std::lock_guard<std::mutex> lock(ctx->host_lock);
+    // slot 0: leaves [k][4] | work [k][12];  slot 1: paths [k][depth][4];  slot 2: root [4] | indices [k];  slot 3: ok [k]
+    void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
+    if ((rc = ctx_scratch(ctx, 0, k * 128, &d0))) return rc;
+    if ((rc = ctx_scratch(ctx, 1, k * depth * 32, &d1))) return rc;
+    if ((rc = ctx_scratch(ctx, 2, 32 + k * 8, &d2))) return rc;
+    if ((rc = ctx_scratch(ctx, 3, k, &d3))) return rc;
+    uint64_t *d_leaves = (uint64_t *)d0, *d_work = d_leaves + k * 4, *d_root = (uint64_t *)d2, *d_idx = d_root + 4;
+    StreamDrain drain{ctx};
+    PMX_HIP(hipMemcpyAsync(d_leaves, leaves, k * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (depth) PMX_HIP(hipMemcpyAsync(d1, paths, k * depth * 32, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_root, root, 32, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_idx, indices, k * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pmx_merkle_verify_paths_dev(ctx, d_leaves, d_idx, (const uint64_t *)d1, depth, k, d_root, (uint8_t *)d3, d_work, ctx->stream))) return rc;
+    PMX_HIP(hipMemcpyAsync(ok_out, d3, k, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
+    PMX_ABI_END
 }

@@ -1059,6 +1059,42 @@ hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint
     PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st));
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
 }
+
+// ---- authentication paths (pmx_merkle_verify_paths_dev) --------------------------------------------------------------
+// Pure data movement: four lanes per path, one 16-byte quarter of the 64-byte pair each.
+__global__ void __launch_bounds__(256) path_pairs_kernel(const uint4 *__restrict__ cur, const uint4 *__restrict__ paths,
+                                                         const uint64_t *__restrict__ indices, size_t depth, size_t level,
+                                                         uint4 *__restrict__ pairs, size_t k) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, i = gid >> 2;
+    if (i >= k) return;
+    const uint32_t quarter = gid & 3, half = quarter & 1;
+    const bool right = (indices[i] >> level) & 1;          // the running node is the right child at this level
+    const bool from_cur = (quarter >> 1) == (right ? 1u : 0u);
+    pairs[gid] = from_cur ? cur[i * 2 + half] : paths[(i * depth + level) * 2 + half];
+}
+
+__global__ void __launch_bounds__(256) path_check_kernel(const uint4 *__restrict__ cur, const uint4 *__restrict__ root,
+                                                         const uint64_t *__restrict__ indices, size_t depth,
+                                                         uint8_t *__restrict__ ok, size_t k) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    const uint4 a = cur[i * 2], b = cur[i * 2 + 1], ra = root[0], rb = root[1];
+    const bool same = a.x == ra.x && a.y == ra.y && a.z == ra.z && a.w == ra.w && b.x == rb.x && b.y == rb.y && b.z == rb.z && b.w == rb.w;
+    ok[i] = (same && (indices[i] >> depth) == 0) ? 1 : 0;   // depth < 64 (checked by the caller)
+}
+
+hipError_t launch_path_pairs(const uint64_t *cur, const uint64_t *paths, const uint64_t *indices, size_t depth, size_t level,
+                             uint64_t *pairs, size_t k, hipStream_t st) {
+    hipLaunchKernelGGL(path_pairs_kernel, dim3((unsigned)((k * 4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(cur),
+                       reinterpret_cast<const uint4 *>(paths), indices, depth, level, reinterpret_cast<uint4 *>(pairs), k);
+    return hipGetLastError();
+}
+hipError_t launch_path_check(const uint64_t *cur, const uint64_t *root, const uint64_t *indices, size_t depth, uint8_t *ok,
+                             size_t k, hipStream_t st) {
+    hipLaunchKernelGGL(path_check_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(cur),
+                       reinterpret_cast<const uint4 *>(root), indices, depth, ok, k);
+    return hipGetLastError();
+}
 #endif  // PMX_TU
 
 }  // namespace pmx

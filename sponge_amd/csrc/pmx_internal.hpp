@@ -2,6 +2,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <exception>
+#include <new>
 
 #include "pmx_permute.hpp"
 
@@ -9,6 +11,25 @@ namespace pmx {
 
 // Records a printf-style message for pmx_last_error() (thread-local) and returns `code`.
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Nothing may unwind through the C ABI (include/poseidon_mi355x.h: "nothing throws or aborts across the boundary"; the
+// caller is Rust, where a foreign exception is undefined behaviour).  Every extern "C" body that can allocate, take a
+// lock or start a thread is written between PMX_ABI_BEGIN / PMX_ABI_END: the body becomes a lambda run under a
+// catch-all, so `return code;` inside it keeps its meaning.
+template <class F>
+int abi_guard(const char *who, F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return set_error(PMX_ERR_HOST, "%s: out of host memory", who);
+    } catch (const std::exception &e) {
+        return set_error(PMX_ERR_HOST, "%s: %s", who, e.what());
+    } catch (...) {
+        return set_error(PMX_ERR_HOST, "%s: unknown exception", who);
+    }
+}
+#define PMX_ABI_BEGIN(who) return ::pmx::abi_guard(who, [&]() -> int {
+#define PMX_ABI_END });
 
 // Kernel-argument block of a validated config (see pmx_prepare.hpp).  The constant table lives in device
 // memory in the internal field form: ark [rounds][t][kFeStride] words, then mds [t][t][kFeStride] words.

@@ -16,4 +16,11 @@ hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint3
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st);
 
+// Authentication paths, one level per step (pmx_merkle_verify_paths_dev): pairs[i] = (cur[i], sibling) or (sibling, cur[i])
+// by bit `level` of indices[i], sibling = paths[i][level]; then ok[i] = (cur[i] == root) && indices[i] < 2^depth.
+hipError_t launch_path_pairs(const uint64_t *cur, const uint64_t *paths, const uint64_t *indices, size_t depth, size_t level,
+                             uint64_t *pairs, size_t k, hipStream_t st);
+hipError_t launch_path_check(const uint64_t *cur, const uint64_t *root, const uint64_t *indices, size_t depth, uint8_t *ok,
+                             size_t k, hipStream_t st);
+
 }  // namespace pmx

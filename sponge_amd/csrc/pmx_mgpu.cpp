@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -118,12 +119,14 @@ extern "C" int pmx_shard_bounds(size_t n, int world, int rank, size_t *start, si
 }
 
 extern "C" int pmx_mgpu_unique_id(uint8_t id[PMX_UNIQUE_ID_BYTES]) {
+    PMX_ABI_BEGIN("pmx_mgpu_unique_id")
     if (!id) return set_error(PMX_ERR_ARG, "pmx_mgpu_unique_id: null pointer");
     if (int rc = rccl_ready()) return rc;
     ncclUniqueId u;
     PMX_RCCL(rccl_lib().GetUniqueId(&u));
     std::memcpy(id, u.internal, PMX_UNIQUE_ID_BYTES);
     return PMX_OK;
+    PMX_ABI_END
 }
 
 static void group_free(pmx_mgpu *g) {
@@ -138,6 +141,14 @@ static void group_free(pmx_mgpu *g) {
     delete g;
 }
 
+// owns a group under construction: whatever way the constructor leaves (error code or exception), the half-built group
+// is torn down unless release() was reached
+struct GroupHolder {
+    pmx_mgpu *g;
+    ~GroupHolder() { if (g) group_free(g); }
+    pmx_mgpu *release() { pmx_mgpu *r = g; g = nullptr; return r; }
+};
+
 static int group_contexts(pmx_mgpu *g, const pmx_config *cfg) {
     for (size_t l = 0; l < g->device.size(); ++l) {
         pmx_ctx *c = nullptr;
@@ -150,6 +161,7 @@ static int group_contexts(pmx_mgpu *g, const pmx_config *cfg) {
 }
 
 extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *devices, pmx_mgpu **out) {
+    PMX_ABI_BEGIN("pmx_mgpu_create")
     if (!cfg || !out) return set_error(PMX_ERR_ARG, "pmx_mgpu_create: null pointer");
     *out = nullptr;
     const int visible = pmx_device_count();
@@ -157,8 +169,9 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
     if (int rc = rccl_ready()) return rc;
     if (n_devices <= 0 || n_devices > visible || n_devices > PMX_MAX_LOCAL_DEVICES)
         return set_error(PMX_ERR_ARG, "n_devices %d out of range [1,%d]", n_devices, visible < PMX_MAX_LOCAL_DEVICES ? visible : PMX_MAX_LOCAL_DEVICES);
-    pmx_mgpu *g = new (std::nothrow) pmx_mgpu();
-    if (!g) return set_error(PMX_ERR_ARG, "out of host memory");
+    GroupHolder hold{new (std::nothrow) pmx_mgpu()};
+    pmx_mgpu *g = hold.g;
+    if (!g) return set_error(PMX_ERR_HOST, "out of host memory");
     g->world = n_devices;
     g->first_rank = 0;
     g->device.resize(n_devices);
@@ -167,20 +180,22 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
     for (int l = 0; l < n_devices; ++l) {
         const int d = devices ? devices[l] : l;
         g->device[l] = d;
-        if (d < 0 || d >= visible) { group_free(g); return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", d, visible); }
+        if (d < 0 || d >= visible) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", d, visible);
         for (int k = 0; k < l; ++k)
-            if (g->device[k] == d) { group_free(g); return set_error(PMX_ERR_ARG, "device %d listed twice", d); }
+            if (g->device[k] == d) return set_error(PMX_ERR_ARG, "device %d listed twice", d);
     }
     int rc = group_contexts(g, cfg);
-    if (rc) { group_free(g); return rc; }
+    if (rc) return rc;
     ncclResult_t r = rccl_lib().CommInitAll(g->comm.data(), n_devices, g->device.data());
-    if (r != ncclSuccess) { group_free(g); return rccl_fail(r, "ncclCommInitAll"); }
-    *out = g;
+    if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitAll");
+    *out = hold.release();
     return PMX_OK;
+    PMX_ABI_END
 }
 
 extern "C" int pmx_mgpu_create_rank(const pmx_config *cfg, int device, int rank, int world,
                                     const uint8_t id[PMX_UNIQUE_ID_BYTES], pmx_mgpu **out) {
+    PMX_ABI_BEGIN("pmx_mgpu_create_rank")
     if (!cfg || !out || !id) return set_error(PMX_ERR_ARG, "pmx_mgpu_create_rank: null pointer");
     *out = nullptr;
     if (world <= 0 || rank < 0 || rank >= world) return set_error(PMX_ERR_ARG, "rank %d / world %d out of range", rank, world);
@@ -188,35 +203,40 @@ extern "C" int pmx_mgpu_create_rank(const pmx_config *cfg, int device, int rank,
     if (visible == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= visible) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, visible);
     if (int rc = rccl_ready()) return rc;
-    pmx_mgpu *g = new (std::nothrow) pmx_mgpu();
-    if (!g) return set_error(PMX_ERR_ARG, "out of host memory");
+    GroupHolder hold{new (std::nothrow) pmx_mgpu()};
+    pmx_mgpu *g = hold.g;
+    if (!g) return set_error(PMX_ERR_HOST, "out of host memory");
     g->world = world;
     g->first_rank = rank;
     g->device.assign(1, device);
     g->ctx.assign(1, nullptr);
     g->comm.assign(1, nullptr);
     int rc = group_contexts(g, cfg);
-    if (rc) { group_free(g); return rc; }
+    if (rc) return rc;
     ncclUniqueId u;
     std::memcpy(u.internal, id, PMX_UNIQUE_ID_BYTES);
     {
         DeviceGuard guard(device);
-        if (guard.err != hipSuccess) { group_free(g); return hip_fail(guard.err, "hipSetDevice"); }
+        if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
         ncclResult_t r = rccl_lib().CommInitRank(&g->comm[0], world, u, rank);
-        if (r != ncclSuccess) { group_free(g); return rccl_fail(r, "ncclCommInitRank"); }
+        if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitRank");
     }
-    *out = g;
+    *out = hold.release();
     return PMX_OK;
+    PMX_ABI_END
 }
 
 extern "C" int pmx_mgpu_destroy(pmx_mgpu *g) {
+    PMX_ABI_BEGIN("pmx_mgpu_destroy")
     if (!g) return PMX_OK;
     (void)pmx_mgpu_synchronize(g);
     group_free(g);
     return PMX_OK;
+    PMX_ABI_END
 }
 
 extern "C" int pmx_mgpu_get_info(const pmx_mgpu *g, pmx_mgpu_info *info) {
+    PMX_ABI_BEGIN("pmx_mgpu_get_info")
     if (!g || !info) return set_error(PMX_ERR_ARG, "pmx_mgpu_get_info: null pointer");
     std::memset(info, 0, sizeof *info);
     info->world = g->world;
@@ -229,6 +249,7 @@ extern "C" int pmx_mgpu_get_info(const pmx_mgpu *g, pmx_mgpu_info *info) {
     PMX_RCCL(rccl_lib().CommUserRank(g->comm[0], &info->comm_first_rank));
     for (size_t l = 0; l < g->device.size() && l < PMX_MAX_LOCAL_DEVICES; ++l) info->devices[l] = g->device[l];
     return PMX_OK;
+    PMX_ABI_END
 }
 
 extern "C" void *pmx_mgpu_stream(const pmx_mgpu *g, int local) {
@@ -242,12 +263,29 @@ extern "C" pmx_ctx *pmx_mgpu_ctx(const pmx_mgpu *g, int local) {
 }
 
 extern "C" int pmx_mgpu_synchronize(pmx_mgpu *g) {
+    PMX_ABI_BEGIN("pmx_mgpu_synchronize")
     if (!g) return set_error(PMX_ERR_ARG, "pmx_mgpu_synchronize: null pointer");
     for (size_t l = 0; l < g->ctx.size(); ++l) {
         if (!g->ctx[l]) continue;
         PMX_BIND(g->ctx[l]);
         PMX_HIP(hipStreamSynchronize(g->ctx[l]->stream));
     }
+    return PMX_OK;
+    PMX_ABI_END
+}
+
+// Test hook (tests/test_gpu_mgpu.py): makes the host fan-out of the next calls fail on one local device and / or behave
+// as if no worker thread could be started, so that the error carry-back and the serial path run on a one-GPU box too.
+namespace {
+struct Fault {
+    int fail_local = -1;
+    bool no_threads = false;
+};
+Fault g_fault;
+}  // namespace
+extern "C" int pmx_mgpu_test_fault(int fail_local, int no_threads) {
+    g_fault.fail_local = fail_local;
+    g_fault.no_threads = no_threads != 0;
     return PMX_OK;
 }
 
@@ -257,6 +295,7 @@ static int local_span(const pmx_mgpu *g, size_t n_total, size_t l, size_t *start
 
 // ---- permutation ---------------------------------------------------------------------------------------------------
 extern "C" int pmx_mgpu_permute_shards_dev(pmx_mgpu *g, uint64_t *const *d_shards, size_t n_total) {
+    PMX_ABI_BEGIN("pmx_mgpu_permute_shards_dev")
     if (!g || !d_shards) return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_shards_dev: null pointer");
     for (size_t l = 0; l < g->ctx.size(); ++l) {
         size_t start = 0, count = 0;
@@ -265,6 +304,7 @@ extern "C" int pmx_mgpu_permute_shards_dev(pmx_mgpu *g, uint64_t *const *d_shard
         if ((rc = pmx_permute_batch_dev(g->ctx[l], d_shards[l], count, g->ctx[l]->stream))) return rc;   // no collective on the data path
     }
     return PMX_OK;
+    PMX_ABI_END
 }
 
 // Host batches, single-process groups: shard l goes through device l's own host path (pinned memory: chunked H2D /
@@ -281,13 +321,29 @@ static int fan_out(pmx_mgpu *g, size_t n, const char *who, Work work) {
     auto run = [&](size_t l) {
         size_t start = 0, count = 0;
         int rc = local_span(g, n, l, &start, &count);
-        if (!rc && count) rc = work(l, start, count);
+        if (!rc && count) {
+            if (g_fault.fail_local == (int)l) rc = set_error(PMX_ERR_HIP, "injected failure (pmx_mgpu_test_fault)");
+            else rc = work(l, start, count);
+        }
         rcs[l] = rc;
         if (rc) msgs[l] = pmx_last_error();   // the error text is thread-local: carry it back to the caller's thread
     };
+    // one host thread per further device; a thread that cannot be started (std::system_error) is not fatal: its shard
+    // runs on the calling thread instead, after the ones that did start
     std::vector<std::thread> workers;
-    for (size_t l = 1; l < L; ++l) workers.emplace_back(run, l);
+    std::vector<size_t> serial;
+    workers.reserve(L);
+    serial.reserve(L);
+    for (size_t l = 1; l < L; ++l) {
+        try {
+            if (g_fault.no_threads) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+            workers.emplace_back(run, l);
+        } catch (const std::system_error &) {
+            serial.push_back(l);
+        }
+    }
     run(0);
+    for (size_t l : serial) run(l);
     for (auto &w : workers) w.join();
     for (size_t l = 0; l < L; ++l)
         if (rcs[l]) return set_error(rcs[l], "device %d: %s", g->device[l], msgs[l].c_str());
@@ -295,16 +351,20 @@ static int fan_out(pmx_mgpu *g, size_t n, const char *who, Work work) {
 }
 
 extern "C" int pmx_mgpu_permute_batch(pmx_mgpu *g, uint64_t *states, size_t n) {
+    PMX_ABI_BEGIN("pmx_mgpu_permute_batch")
     if (!g || (!states && n)) return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_batch: null pointer");
     return fan_out(g, n, "pmx_mgpu_permute_batch",
                    [&](size_t l, size_t start, size_t count) { return pmx_permute_batch(g->ctx[l], states + start * g->t * 4, count); });
+    PMX_ABI_END
 }
 
 extern "C" int pmx_mgpu_hash_batch(pmx_mgpu *g, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len, size_t n) {
+    PMX_ABI_BEGIN("pmx_mgpu_hash_batch")
     if (!g || (!in && n && in_len) || (!out && n && out_len)) return set_error(PMX_ERR_ARG, "pmx_mgpu_hash_batch: null pointer");
     return fan_out(g, n, "pmx_mgpu_hash_batch", [&](size_t l, size_t start, size_t count) {
         return pmx_hash_batch(g->ctx[l], in ? in + start * in_len * 4 : nullptr, in_len, out ? out + start * out_len * 4 : nullptr, out_len, count);
     });
+    PMX_ABI_END
 }
 
 // ---- the final gather ------------------------------------------------------------------------------------------------
@@ -312,6 +372,7 @@ extern "C" int pmx_mgpu_hash_batch(pmx_mgpu *g, const uint64_t *in, size_t in_le
 // multiple of the world size): one ncclBroadcast per rank inside a group call, each into its own span of the output.
 extern "C" int pmx_mgpu_all_gather_dev(pmx_mgpu *g, const uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total,
                                        size_t row_elems) {
+    PMX_ABI_BEGIN("pmx_mgpu_all_gather_dev")
     if (!g || !d_shards || !d_all) return set_error(PMX_ERR_ARG, "pmx_mgpu_all_gather_dev: null pointer");
     if (row_elems == 0 || n_total == 0) return PMX_OK;
     if (n_total > SIZE_MAX / (row_elems * 32)) return set_error(PMX_ERR_ARG, "gather byte size overflows size_t");
@@ -339,12 +400,14 @@ extern "C" int pmx_mgpu_all_gather_dev(pmx_mgpu *g, const uint64_t *const *d_sha
     if (r != ncclSuccess) return rccl_fail(r, equal ? "ncclAllGather" : "ncclBroadcast");
     if (e != ncclSuccess) return rccl_fail(e, "ncclGroupEnd");
     return PMX_OK;
+    PMX_ABI_END
 }
 
 // ---- Merkle 2-to-1 ---------------------------------------------------------------------------------------------------
 // Each rank reduces its own contiguous subtree of m = n_leaves / world leaves (level by level, pmx_merkle_2to1_dev), the
 // `world` subtree roots - 32 bytes each - are all-gathered, and every rank finishes the top log2(world) levels itself.
 extern "C" int pmx_mgpu_merkle_2to1_dev(pmx_mgpu *g, uint64_t *const *d_nodes, uint64_t *const *d_top, size_t n_leaves) {
+    PMX_ABI_BEGIN("pmx_mgpu_merkle_2to1_dev")
     if (!g || !d_nodes || !d_top) return set_error(PMX_ERR_ARG, "pmx_mgpu_merkle_2to1_dev: null pointer");
     const size_t W = (size_t)g->world;
     if (W & (W - 1)) return set_error(PMX_ERR_ARG, "the sharded tree needs a power-of-two number of ranks (have %d)", g->world);
@@ -373,10 +436,12 @@ extern "C" int pmx_mgpu_merkle_2to1_dev(pmx_mgpu *g, uint64_t *const *d_nodes, u
         if (rc) return rc;
     }
     return PMX_OK;
+    PMX_ABI_END
 }
 
 // Host leaves, single-process groups.  root: [4].
 extern "C" int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t n_leaves, uint64_t *root) {
+    PMX_ABI_BEGIN("pmx_mgpu_merkle_2to1")
     if (!g || !leaves || !root) return set_error(PMX_ERR_ARG, "pmx_mgpu_merkle_2to1: null pointer");
     if ((int)g->ctx.size() != g->world)
         return set_error(PMX_ERR_ARG, "pmx_mgpu_merkle_2to1 needs a single-process group (this one holds %zu of %d ranks)", g->ctx.size(), g->world);
@@ -411,4 +476,5 @@ extern "C" int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t 
     }
     cleanup();
     return rc;
+    PMX_ABI_END
 }

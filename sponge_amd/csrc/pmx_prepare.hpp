@@ -210,7 +210,6 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     const uint64_t t64 = (uint64_t)cfg->rate + cfg->capacity;
     if (cfg->rate == 0) { err = "rate must be >= 1"; return PMX_ERR_CONFIG; }
     if (t64 > PMX_MAX_WIDTH) { err = "width exceeds PMX_MAX_WIDTH"; return PMX_ERR_UNSUPPORTED; }
-    if (cfg->full_rounds % 2) { err = "full_rounds must be even (RF/2 rounds on each side, mod.rs:96)"; return PMX_ERR_CONFIG; }
     const uint64_t rounds = (uint64_t)cfg->full_rounds + cfg->partial_rounds;
     if (rounds == 0 || rounds > 4096) { err = "round count out of range"; return PMX_ERR_CONFIG; }
     HostField &hf = out.hf;
@@ -340,7 +339,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     to_limbs29(times_pow2(hf, hf.r, 5), out.one.l);     // 2^261 mod p
     out.c.rate = cfg->rate;
     out.c.capacity = cfg->capacity;
-    out.c.half_full = cfg->full_rounds / 2;
+    out.c.half_full = cfg->full_rounds / 2;   // odd RF: RF/2 full rounds before the partial section, RF - RF/2 after (mod.rs:96-116)
     out.c.partial_rounds = cfg->partial_rounds;
     out.c.total_rounds = (uint32_t)rounds;
     out.c.alpha = cfg->alpha;

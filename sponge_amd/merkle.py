@@ -57,7 +57,8 @@ class MerkleTree:
 def verify_paths(parameters: PoseidonConfig, leaves: np.ndarray, indices, paths: np.ndarray, root: np.ndarray,
                  device: int = 0) -> np.ndarray:
     """k authentication paths at once: leaves [k][4], indices [k], paths [k][depth][4] -> bool[k]
-    (pmx_merkle_verify_paths: one batched 2-to-1 hash call per level)."""
+    (pmx_merkle_verify_paths: one upload, one device step per level, one download; an index with bits at or above
+    `depth` names no leaf and verifies as False)."""
     cur = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4)
     idx = np.ascontiguousarray(indices, dtype=np.uint64)
     paths = np.ascontiguousarray(paths, dtype=np.uint64)

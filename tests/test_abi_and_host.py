@@ -153,7 +153,6 @@ def _try_create(cfg_kwargs):
 
 
 @pytest.mark.parametrize("kwargs,code,needle", [
-    (dict(full_rounds=7, partial_rounds=31, rate=2, capacity=1), _lib.PMX_ERR_CONFIG, "even"),
     (dict(full_rounds=8, partial_rounds=31, rate=0, capacity=1), _lib.PMX_ERR_CONFIG, "rate"),
     (dict(full_rounds=8, partial_rounds=31, rate=16, capacity=1), _lib.PMX_ERR_UNSUPPORTED, "width"),
     (dict(full_rounds=0, partial_rounds=0, rate=2, capacity=1), _lib.PMX_ERR_CONFIG, "round"),
@@ -202,3 +201,40 @@ def test_merkle_paths_gather_is_host_only_and_matches_the_oracle_tree():
                                 ctypes.c_void_p(paths.ctypes.data)) == _lib.PMX_ERR_ARG
     assert lib.pmx_merkle_paths(ctypes.c_void_p(nodes.ctypes.data), 48, ctypes.c_void_p(idx.ctypes.data), 1,
                                 ctypes.c_void_p(paths.ctypes.data)) == _lib.PMX_ERR_ARG
+
+
+def test_host_allocation_failure_becomes_a_status_code():
+    """include/poseidon_mi355x.h: "nothing throws or aborts across the boundary".  A child process loads the library,
+    then caps its address space just above what it already uses and asks for a context whose tables need a few MB
+    (4000 rounds of width 16): the std::bad_alloc inside prepare() must come back as PMX_ERR_HOST with a message, not as
+    std::terminate (which would kill the child with SIGABRT)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from sponge_amd import _lib
+import sponge_amd as S
+lib = _lib.lib()
+f = S.BLS12_381_FR
+rounds, t = 4000, 16
+ark = np.zeros((rounds, t, 4), dtype=np.uint64)
+mds = np.zeros((t, t, 4), dtype=np.uint64)
+c = _lib.PmxConfig()
+c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = 8, rounds - 8, 5, t - 1, 1
+for i in range(4):
+    c.modulus[i] = (f.modulus >> (64 * i)) & (2**64 - 1)
+c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+h = ctypes.c_void_p()
+vm = [int(l.split()[1]) * 1024 for l in open("/proc/self/status") if l.startswith("VmSize")][0]
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+resource.setrlimit(resource.RLIMIT_AS, (vm + (1 << 20), hard))
+rc = lib.pmx_ctx_create(ctypes.byref(c), 0, ctypes.byref(h))
+resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+msg = lib.pmx_last_error().decode()
+print(rc, "|", msg)
+sys.exit(0 if (rc == _lib.PMX_ERR_HOST and "out of host memory" in msg) else 1)
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-2000:])

@@ -194,3 +194,35 @@ def test_c5_whole_tree_2e24_leaves_on_one_gpu():
     assert np.array_equal(top, got[-1])
     want = c_oracle(name).merkle(leaves, threads=0)
     assert np.array_equal(got, want)
+
+
+def test_c4_whole_batch_2e24_states_through_the_device_group():
+    """BASELINE configs[3] at its total size in ONE batch: 2^24 states (1.5 GiB) cut into world = pmx_device_count()
+    contiguous shards, pmx_mgpu_permute_shards_dev on the group's streams, pmx_mgpu_all_gather_dev (RCCL) into one
+    buffer per device, and that gathered buffer against the C restatement IN FULL (16 M permutations on the host cores).
+    One GPU: one 2^24-state launch and a one-rank ncclAllGather; N GPUs: the real C4."""
+    from sponge_amd import _lib, mgpu
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    g = mgpu.DeviceGroup.single_process(cfg, _lib.lib().pmx_device_count())
+    n_total = 1 << 24
+    whole = synth.random_elements(cfg.field, n_total * 3, seed=0x5EED0002).reshape(n_total, 3, 4)
+    shards, alls = [], []
+    for l, dev in enumerate(g.devices):
+        start, count = g.local_span(n_total, l)
+        shards.append(torch.from_numpy(whole[start:start + count].view(np.int64)).to(f"cuda:{dev}"))
+        alls.append(torch.zeros((n_total, 3, 4), dtype=torch.int64, device=f"cuda:{dev}"))
+    for dev in g.devices:
+        torch.cuda.synchronize(dev)
+    g.permute_shards_dev([s.data_ptr() for s in shards], n_total)
+    g.all_gather_dev([s.data_ptr() for s in shards], [a.data_ptr() for a in alls], n_total, 3)
+    g.synchronize()
+    cr = c_oracle(name)
+    chunk = 1 << 21
+    for first in range(0, n_total, chunk):          # the checker in slices: bounded host memory
+        want = cr.permute_batch(whole[first:first + chunk], threads=0)
+        for l in range(g.n_local):
+            if l == 0 or first % (4 * chunk) == 0:  # device 0's copy in full, the other copies on a quarter of the slices
+                got = alls[l][first:first + chunk].cpu().numpy().view(np.uint64)
+                assert np.array_equal(got, want), (l, first)
+    g.close()

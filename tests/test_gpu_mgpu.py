@@ -48,8 +48,11 @@ def test_host_batch_sharded_over_all_devices(n):
     g.close()
 
 
-@pytest.mark.parametrize("n_total", [1 << 16, (1 << 16) + 5])     # equal shards: ncclAllGather; ragged: grouped ncclBroadcast
+@pytest.mark.parametrize("n_total", [1 << 16, (1 << 16) + 5])
 def test_device_resident_shards_and_rccl_gather(n_total):
+    """With W ranks the first size gathers with ncclAllGather (equal shards) and the second with the grouped ncclBroadcast
+    (ragged shards: n_total % W != 0).  On a ONE-GPU box both sizes divide by the world size, so both take the equal
+    branch: the ragged branch is only reached from two GPUs up (test_ragged_gather_needs_two_gpus says so out loud)."""
     cfg, g = _group()
     world = g.world
     whole = synth.random_elements(cfg.field, n_total * 3, seed=0x5EED0041).reshape(n_total, 3, 4)
@@ -66,6 +69,101 @@ def test_device_resident_shards_and_rccl_gather(n_total):
     want = c_oracle(NAME).permute_batch(whole, threads=0)
     for l in range(world):
         assert np.array_equal(alls[l].cpu().numpy().view(np.uint64), want), f"gathered copy on local device {l}"
+    g.close()
+
+
+def test_ragged_gather_needs_two_gpus():
+    """The grouped-ncclBroadcast branch of pmx_mgpu_all_gather_dev (n_total % world != 0) cannot be reached with one rank.
+    An explicit skip on a one-GPU box, not a silent pass through the equal-shard branch."""
+    ndev = _lib.lib().pmx_device_count()
+    if ndev < 2:
+        pytest.skip("one GPU: every n_total divides by world = 1, the ragged ncclBroadcast branch needs >= 2 ranks")
+    cfg, g = _group()
+    n_total = (1 << 14) * ndev + 1
+    whole = synth.random_elements(cfg.field, n_total * 3, seed=0x5EED0047).reshape(n_total, 3, 4)
+    shards, alls = [], []
+    for l, dev in enumerate(g.devices):
+        start, count = g.local_span(n_total, l)
+        shards.append(torch.from_numpy(whole[start:start + count].view(np.int64).copy()).to(f"cuda:{dev}"))
+        alls.append(torch.zeros((n_total, 3, 4), dtype=torch.int64, device=f"cuda:{dev}"))
+    for dev in g.devices:
+        torch.cuda.synchronize(dev)
+    g.permute_shards_dev([s.data_ptr() for s in shards], n_total)
+    g.all_gather_dev([s.data_ptr() for s in shards], [a.data_ptr() for a in alls], n_total, 3)
+    g.synchronize()
+    want = c_oracle(NAME).permute_batch(whole, threads=0)
+    for l in range(g.world):
+        assert np.array_equal(alls[l].cpu().numpy().view(np.uint64), want), f"gathered copy on local device {l}"
+    g.close()
+
+
+@pytest.mark.parametrize("shape", ["equal", "ragged"])
+def test_one_process_per_gpu_with_create_rank(shape, tmp_path):
+    """The multi-process form (what bench.py --gpus N and a Rust job with one process per GPU use): one FRESH child
+    process per visible GPU, no torch in them, the communicator id made by rank 0 (pmx_mgpu_unique_id) and handed over
+    through a file, pmx_mgpu_create_rank (ncclCommInitRank) in every child.  Every rank checks the whole of its own
+    gathered copy and the sharded Merkle root against the C restatement (tests/mgpu_rank_worker.py).  world =
+    pmx_device_count(): one rank on the development box (which still runs the whole script: id hand-over, one-rank
+    communicator, gather, tree), N ranks with RCCL over xGMI on a multi-GPU node."""
+    import json
+    import os
+    import subprocess
+    import sys
+    world = _lib.lib().pmx_device_count()
+    if shape == "ragged" and world < 2:
+        pytest.skip("one GPU: no ragged split of the batch exists for world = 1")
+    n_total = (1 << 14) * world + (3 if shape == "ragged" else 0)
+    here = os.path.dirname(os.path.abspath(__file__))
+    uid_file = str(tmp_path / "uid.bin")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(world):
+        out = str(tmp_path / f"rank{r}.json")
+        procs.append((out, subprocess.Popen([sys.executable, os.path.join(here, "mgpu_rank_worker.py"), str(r), str(world), str(r),
+                                             uid_file, str(n_total), "10", out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    results = []
+    for out, p in procs:
+        try:
+            log, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for _, q in procs:
+                q.kill()
+            raise
+        assert os.path.exists(out), log.decode(errors="replace")[-3000:]
+        results.append(json.load(open(out)))
+    for res in results:
+        assert res["ok"], res
+        assert res["info"]["comm_ranks"] == world and res["gather_bad_spans"] == []
+        if world & (world - 1) == 0:
+            assert res["tree_ok"] is True
+
+
+def test_fan_out_carries_a_device_failure_back_to_the_caller():
+    """pmx_mgpu_permute_batch / _hash_batch run one host thread per device; a failure on any device must come back to the
+    calling thread with that device's message (the error text is thread-local), and a thread that cannot be started must
+    not take the process down: its shard runs on the calling thread.  pmx_mgpu_test_fault injects both."""
+    cfg, g = _group()
+    lib = _lib.lib()
+    n = 3000
+    states = synth.random_elements(cfg.field, n * 3, seed=0x5EED0048).reshape(n, 3, 4)
+    want = c_oracle(NAME).permute_batch(states, threads=0)
+    last = g.n_local - 1
+    try:
+        _lib.check(lib.pmx_mgpu_test_fault(last, 0))
+        with pytest.raises(S.PmxError) as ei:
+            g.permute_batch(states)
+        assert ei.value.code == _lib.PMX_ERR_HIP and f"device {g.devices[last]}: injected failure" in str(ei.value)
+        msgs = synth.random_elements(cfg.field, 100 * 4, seed=1).reshape(100, 4, 4)
+        with pytest.raises(S.PmxError, match="injected failure"):
+            g.hash_batch(msgs, 4, 1)
+        _lib.check(lib.pmx_mgpu_test_fault(-1, 1))              # no worker threads: every shard on the calling thread
+        assert np.array_equal(g.permute_batch(states), want)
+        _lib.check(lib.pmx_mgpu_test_fault(0, 1))
+        with pytest.raises(S.PmxError, match="injected failure"):
+            g.permute_batch(states)
+    finally:
+        _lib.check(lib.pmx_mgpu_test_fault(-1, 0))
+    assert np.array_equal(g.permute_batch(states), want)       # the group is intact afterwards
     g.close()
 
 

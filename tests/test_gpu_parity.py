@@ -248,6 +248,32 @@ def test_run_time_width_engine_vs_c_oracle(rate, alpha, rf, rp):
         assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
 
 
+@pytest.mark.parametrize("rate", [2, 4, 8, 11])
+@pytest.mark.parametrize("rf", [1, 3, 7])
+@pytest.mark.parametrize("rp", [0, 5])
+def test_odd_full_rounds_vs_c_oracle(rate, rf, rp):
+    """The reference accepts an odd full_rounds (PoseidonConfig::new asserts shapes only, src/poseidon/mod.rs:196-203) and
+    runs RF/2 full rounds before the partial section, RF - RF/2 after it (:96-116).  Every engine (registers / quad for
+    t = 3, hybrid for t = 5 and 9, run-time width for t = 12; dense schedule where RF/2 = 0) through permutation, hash
+    driver and tree, sizes on both sides of the small-launch switches, against the C port."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    cfg = S.poseidon_config_from_lfsr(f, rate, 5, rf, rp)
+    cr = cref.CRef(O.make_config(O.BLS12_381_FR, 255, rate, 5, rf, rp))
+    t = rate + 1
+    sizes = (1, 130, (1 << 15) + 70, (1 << 17) + 3) if rate == 2 else (1, 130)
+    for n in sizes:
+        states = synth.random_elements(f, n * t, seed=31 * rf + rp + n).reshape(n, t, 4)
+        assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0)), (rate, rf, rp, n)
+    L = rate + 2
+    msgs = synth.random_elements(f, 70 * L, seed=rf).reshape(70, L, 4)
+    assert np.array_equal(cfg.context().hash_batch(msgs, L, 2), cr.hash_batch(msgs, L, 2, threads=0))
+    leaves = synth.random_elements(f, 256, seed=rp)
+    nodes, _ = cfg.context().merkle_2to1(leaves)
+    assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
+
+
 def test_merkle_tree_paths():
     """Tree container + batch path verification (2-to-1 compression mode) against the oracle's tree."""
     from oracle import poseidon_oracle as O
@@ -269,6 +295,47 @@ def test_merkle_tree_paths():
     bad[2, 3, 0] ^= np.uint64(1)                      # corrupt one sibling of the third path
     assert list(S.verify_paths(cfg, leaves[idx], idx, bad, tree.root)) == [True, True, False, True]
     assert not S.verify_paths(cfg, leaves[[1, 0]], [0, 1], paths[:2], tree.root).any()   # wrong leaves
+
+
+def test_many_paths_verify_on_the_device():
+    """pmx_merkle_verify_paths keeps the k running nodes on the device for all `depth` levels (one upload, one download):
+    4096 paths of a 2^16-leaf tree built by the oracle-checked tree kernel, with corrupted siblings, wrong leaves and
+    indices that name no leaf mixed in; the expected verdicts come from the oracle's own walk up each path."""
+    import ctypes
+    from sponge_amd import _lib
+    cfg = product_config("bls_t3_a5_8_31")
+    cr = c_oracle("bls_t3_a5_8_31")
+    f = cfg.field
+    depth, k = 16, 4096
+    m = 1 << depth
+    leaves = synth.random_elements(f, m, seed=0x5EED0060)
+    tree = S.MerkleTree(cfg, leaves)
+    assert np.array_equal(tree.nodes, cr.merkle(leaves, threads=0))
+    rng = np.random.default_rng(7)
+    idx = rng.integers(0, m, size=k).astype(np.uint64)
+    paths = np.stack([tree.path(int(i)) for i in idx])
+    lv = leaves[idx.astype(np.int64)].copy()
+    expect = np.ones(k, dtype=bool)
+    for j in range(0, k, 7):                           # a corrupted sibling somewhere on the path
+        paths[j, int(rng.integers(0, depth)), int(rng.integers(0, 3))] ^= np.uint64(1) << np.uint64(int(rng.integers(0, 60)))
+        expect[j] = False
+    for j in range(3, k, 11):                          # somebody else's leaf
+        lv[j] = leaves[(int(idx[j]) + 1) % m]
+        expect[j] = False
+    for j in range(5, k, 13):                          # right walk, but the index claims a position outside the tree
+        idx[j] += np.uint64(m) << np.uint64(int(rng.integers(0, 8)))
+        expect[j] = False
+    got = S.verify_paths(cfg, lv, idx, paths, tree.root)
+    assert np.array_equal(got, expect)
+    # the oracle's walk for a sample, bad ones included (left / right by the index bits below `depth`)
+    for j in list(range(0, 64)) + [k - 1]:
+        cur = lv[j:j + 1].copy()
+        for level in range(depth):
+            pair = np.zeros((1, 2, 4), dtype=np.uint64)
+            right = (int(idx[j]) >> level) & 1
+            pair[0, right], pair[0, 1 - right] = cur[0], paths[j, level]
+            cur = cr.hash_batch(pair, 2, 1, threads=1).reshape(1, 4)
+        assert bool(np.array_equal(cur[0], tree.root) and int(idx[j]) < m) == bool(got[j]), j
 
 
 def test_pinned_host_buffers_take_the_pipelined_path_and_agree():

@@ -317,3 +317,37 @@ def test_other_255_bit_prime(hc, p):
         out = limbs.copy()
         assert fn(ctypes.byref(c), out.ctypes.data, len(states)) == 0
         assert cref.limbs_to_elems(out, p) == want, fn.__name__
+
+
+@pytest.mark.parametrize("rate", [2, 4])
+@pytest.mark.parametrize("rf,rp", [(1, 0), (1, 5), (3, 0), (3, 5), (7, 0), (7, 5), (3, 1), (3, 2)])
+def test_odd_full_rounds_follow_the_reference_split(hc, rate, rf, rp):
+    """PoseidonConfig::new asserts shapes only (src/poseidon/mod.rs:196-203) and permute runs RF/2 full rounds before the
+    partial section and RF - RF/2 after it (:96-116): an odd full_rounds is a legal config.  Every schedule that accepts
+    the config (RF = 1 has no full round in front of the partial section, so the optimised tables do not exist and those
+    entry points answer PMX_ERR_UNSUPPORTED) against the big-integer oracle."""
+    p, t = O.BLS12_381_FR, rate + 1
+    cfg = O.make_config(p, 255, rate, 5, rf, rp)
+    rng = random.Random(rf * 100 + rp * 10 + rate)
+    states = [[rng.randrange(p) for _ in range(t)] for _ in range(6)] + [[p - 1] * t, [0] * t]
+    want = [x for st in states for x in O.permute(cfg, st)]
+    limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), t, 4)
+    ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+    mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+    c = PmxConfig()
+    c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = rf, rp, 5, rate, 1
+    for i, l in enumerate(O.to_limbs(p)):
+        c.modulus[i] = l
+    c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+    has_opt = rf >= 2 and rp >= 1
+    fns = [hc.hc_permute, hc.hc_permute_rt, hc.hc_permute_opt, hc.hc_permute_opt_tab, hc.hc_permute_hybrid]
+    if t == 3:
+        fns.append(hc.hc_permute_coop)
+    for fn in fns:
+        out = limbs.copy()
+        rc = fn(ctypes.byref(c), out.ctypes.data, len(states))
+        if fn in (hc.hc_permute, hc.hc_permute_rt) or has_opt:
+            assert rc == 0, (fn.__name__, rc)
+            assert cref.limbs_to_elems(out, p) == want, fn.__name__
+        else:
+            assert rc != 0, fn.__name__
