@@ -46,6 +46,12 @@ WORKLOADS = {
     # the absorb/squeeze batch driver (pmx_hash_batch_dev): per row new; absorb(L); squeeze_native(1)
     "h3": ("bls12_381_fr", 2, 5, 8, 31, 20, None, 0x5EED0006, "bls12_381_fr t=3 alpha=5 hash of 4 elements -> 1 (2 permutations/row)"),
     "h9": ("bn254_fr", 8, 5, 8, 57, 18, None, 0x5EED0007, "bn254_fr t=9 alpha=5 hash of 8 elements -> 1 (1 permutation/row)"),
+    # the other widths of the reference's default table (src/test.rs:14-31), for tuning the wide-state engines
+    "w4": ("bls12_381_fr", 3, 5, 8, 56, 19, None, 0x5EED0014, "bls12_381_fr t=4 alpha=5 RF=8 RP=56 permutation batch"),
+    "w5": ("bls12_381_fr", 4, 5, 8, 56, 19, None, 0x5EED0015, "bls12_381_fr t=5 alpha=5 RF=8 RP=56 permutation batch"),
+    "w6": ("bls12_381_fr", 5, 5, 8, 57, 18, None, 0x5EED0016, "bls12_381_fr t=6 alpha=5 RF=8 RP=57 permutation batch"),
+    "w7": ("bls12_381_fr", 6, 5, 8, 57, 18, None, 0x5EED0017, "bls12_381_fr t=7 alpha=5 RF=8 RP=57 permutation batch"),
+    "w8": ("bls12_381_fr", 7, 5, 8, 57, 18, None, 0x5EED0018, "bls12_381_fr t=8 alpha=5 RF=8 RP=57 permutation batch"),
 }
 HASH_SHAPES = {"h3": (4, 1, 2), "h9": (8, 1, 1)}     # workload -> (in_len, out_len, permutations per row)
 BASELINE_CONFIG = {("c2", False): "BASELINE.json configs[1] (C2)", ("c2", True): "BASELINE.json configs[3] (C4)",

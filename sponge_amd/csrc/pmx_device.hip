@@ -55,11 +55,14 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 #define PMX_REG_THREADS 256   // workgroup size of the t = 3 engine: one wave per SIMD of a CU.  A/B (round 2): 128 threads -6 % on
                               // C2 / hash / tree (waves land unevenly on the SIMDs), 512 threads -0.3 % C2, -3 % tree
 #endif
+#ifndef PMX_REG_DRIVER_MIN_WAVES
+#define PMX_REG_DRIVER_MIN_WAVES 1   // absorb / squeeze kernels of the t = 3 engine: left alone they take 135 / 149 VGPRs (3 waves per SIMD)
+#endif
 template <int T, int ALPHA, bool OPT, bool TAB = false>
 struct RegEngine {
     static_assert(OPT || !TAB, "shifted tables exist for the optimised schedule");
     static constexpr int kThreads = PMX_REG_THREADS;
-    static constexpr int kMinWaves = 1;
+    static constexpr int kMinWaves = 1, kMinWavesDriver = PMX_REG_DRIVER_MIN_WAVES;
     static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
 
     Fe s[T];
@@ -197,11 +200,20 @@ struct RegEngine {
                           // co-resident waves in the same round, sharing its table lines in the scalar cache - were measured:
                           // C3 -0.6 %, t = 9 hash +0.7 %: the s_waitcnt time of the wide kernels is not a cache-capacity effect
 #endif
+#ifndef PMX_HYB_3WAVE_MAX_T
+#define PMX_HYB_3WAVE_MAX_T 6   // widths up to this one must fit three waves per SIMD: t = 4, 5 do so on their own; t = 6 (176 VGPRs
+                                // when left alone) is +6 % when held to 168; t = 7, 8, 9 spill and lose 23 / 46 / 68 % (round 3 A/B)
+#endif
+#ifndef PMX_HYB_4WAVE_MAX_T
+#define PMX_HYB_4WAVE_MAX_T 4   // t = 4 (133 VGPRs when left alone) held to 128: four waves per SIMD, +3.8 % (round 3 A/B)
+#endif
 template <int T, int ALPHA>
 struct HybridEngine {
     static constexpr int kWaves = PMX_HYB_WAVES;
     static constexpr int kThreads = 64 * kWaves;
-    static constexpr int kMinWaves = 2;   // waves per SIMD the register allocation must allow (<= 256 VGPRs)
+    // waves per SIMD the register allocation must allow (4: <= 128 VGPRs, 3: <= 168, 2: <= 256)
+    static constexpr int kMinWaves = T <= PMX_HYB_4WAVE_MAX_T ? 4 : T <= PMX_HYB_3WAVE_MAX_T ? 3 : 2;
+    static constexpr int kMinWavesDriver = 2;   // absorb / squeeze kernels (per-lane modes: more live state) spill under the tighter bounds
     static constexpr int kChunks = 2 * T;
     // one wave's LDS region: scratch slots for elements 0..T-2 (2304 B each) or the ABI staging of its 64 states
     // (2048 T B), whichever is larger
@@ -319,7 +331,7 @@ struct HybridEngine {
 template <int ALPHA>
 struct LdsEngine {
     static constexpr int kThreads = 128;
-    static constexpr int kMinWaves = 1;
+    static constexpr int kMinWaves = 1, kMinWavesDriver = 1;
 
     Rounds c;
     FieldRt f;
@@ -435,26 +447,36 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves) permute_k
 
 // absorb `in_len` elements into this lane's sponge; idx is the next absorb index, or `rate` to force the
 // permutation a Squeezing sponge performs first (mod.rs:247-252).  Returns the final next_absorb_index.
+// The reference walks the input element by element and permutes whenever the rate is full and more input remains
+// (mod.rs:137-148).  Sponges of one wave may stand at different positions, and a permutation costs the wave the same
+// whether one lane needs it or all 64: so every lane keeps its OWN input cursor, and a pass of the loop is "every lane
+// absorbs until its rate is full or its input ends, then the lanes that are full and have input left permute together".
+// A wave then executes max-over-lanes permutations (2 for absorb(4) at rate 2 whatever the positions) instead of one per
+// input position at which some lane happens to be full (4).
 template <class Engine>
 __device__ __forceinline__ uint32_t absorb_elements(Engine &e, const uint64_t *row, size_t in_len, uint32_t idx,
                                                     bool active) {
     const Rounds &c = e.c;
-    for (size_t k = 0; k < in_len; ++k) {
-        // rate filled and more input remains -> permute (mod.rs:137-148; also the :241-244 case)
-        const bool need = active && idx == c.rate;
+    size_t k = active ? 0 : in_len;   // this lane's cursor into its input row
+    while (__builtin_amdgcn_ballot_w64(k < in_len)) {
+        for (uint32_t j = 0; j < c.rate; ++j) {   // wave-uniform trip count; lanes drop out as they fill up or run dry
+            if (k < in_len && idx < c.rate) {
+                const Fe x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)), e.f);
+                const uint32_t pos = c.capacity + idx;
+                // state[capacity + idx] += element (mod.rs:128,143); normalised so the permutation's own lazy
+                // round-constant add stays within the limb bounds
+                e.set(pos, fe_normalize(fe_add_lazy(e.get(pos), x)));
+                idx += 1;
+                k += 1;
+            }
+        }
+        // rate filled and more input remains -> permute (mod.rs:137-148; also the :241-252 cases)
+        const bool need = k < in_len && idx == c.rate;
         if (__builtin_amdgcn_ballot_w64(need)) {
             if (need) {
                 e.permute();
                 idx = 0;
             }
-        }
-        if (active) {
-            const Fe x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)), e.f);
-            const uint32_t pos = c.capacity + idx;
-            // state[capacity + idx] += element (mod.rs:128,143); normalised so the permutation's own lazy
-            // round-constant add stays within the limb bounds
-            e.set(pos, fe_normalize(fe_add_lazy(e.get(pos), x)));
-            idx += 1;
         }
     }
     return idx;
@@ -731,18 +753,22 @@ __global__ void __launch_bounds__(256, 2)
     if (active) idx = (mode_tag[g] == PMX_MODE_ABSORBING) ? mode_index[g] : e.c.rate;
     if (idx > e.c.rate) idx = e.c.rate;                        // device-resident mode words are not validated by the host
     const uint64_t *row = in + (active ? g : 0) * in_len * 4;
-    for (size_t k = 0; k < in_len; ++k) {
-        const bool need = active && idx == e.c.rate;           // rate filled and more input remains (mod.rs:137-148, :241-252)
+    size_t k = active ? 0 : in_len;                            // per-sponge input cursor (see absorb_elements)
+    while (__builtin_amdgcn_ballot_w64(k < in_len)) {
+        for (uint32_t j = 0; j < e.c.rate; ++j) {
+            if (k < in_len && idx < e.c.rate) {
+                const Fe x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)), e.f);
+                if (e.q == e.c.capacity + idx) e.s = fe_normalize(fe_add_lazy(e.s, x));   // state[capacity + idx] += element (mod.rs:128,143)
+                idx += 1;
+                k += 1;
+            }
+        }
+        const bool need = k < in_len && idx == e.c.rate;       // rate filled and more input remains (mod.rs:137-148, :241-252)
         if (__builtin_amdgcn_ballot_w64(need)) {
             if (need) {
                 e.permute();
                 idx = 0;
             }
-        }
-        if (active) {
-            const Fe x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)), e.f);
-            if (e.q == e.c.capacity + idx) e.s = fe_normalize(fe_add_lazy(e.s, x));   // state[capacity + idx] += element (mod.rs:128,143)
-            idx += 1;
         }
     }
     const Abi v = fe_to_abi(e.s, e.f);
@@ -805,7 +831,7 @@ __global__ void __launch_bounds__(256, 2)
 }
 
 template <class Engine>
-__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
     absorb_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
                   uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, const uint64_t *__restrict__ in,
                   size_t in_len, size_t n) {
@@ -825,7 +851,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
 }
 
 template <class Engine>
-__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
     squeeze_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
                    uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ out,
                    size_t out_len, size_t n) {
