@@ -626,7 +626,9 @@ struct QuadEngine {
     __device__ __forceinline__ static Fe quad(const Fe &v) {
         Fe r;
 #pragma unroll
-        for (int w = 0; w < kN; ++w) r.l[w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[w], LANE * 0x55, 0xf, 0xf, false);   // quad_perm [l, l, l, l]
+        // quad_perm [l, l, l, l]; every lane reads a live lane of its own quad, so there is no "old" value to keep: mov_dpp,
+        // not update_dpp(0, ...), which costs a v_mov_b32 of the 0 before every move (27 per round on a lone wave's chain)
+        for (int w = 0; w < kN; ++w) r.l[w] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[w], LANE * 0x55, 0xf, 0xf, false);
         return r;
     }
 

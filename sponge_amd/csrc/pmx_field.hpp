@@ -175,8 +175,10 @@ PMX_FN Fe fe_normalize(const Fe &a) {
 // in 64-bit accumulators; one accumulator takes at most 3 terms (27 products * 2^59 + 9 * 2^58 + carry
 // < 2^64, checked in tests/test_hostcheck.py), so wider dots use ceil(T/3) accumulators whose low 29 bits
 // and carries are combined once per column.
-template <int T>
-PMX_FN Fe mont_dot(const Fe *a, const Fe *b, const FieldRt &f) {
+// ADD: + s, the addend entering the upper columns (as s * 2^261 before the reduction) like in mont_mul_add below: the sum
+// comes out with normalised limbs, B < sum / (p 2^261) + Bs + 1.
+template <int T, bool ADD>
+PMX_FN Fe mont_dot_impl(const Fe *a, const Fe *b, const Fe &s, const FieldRt &f) {
     constexpr int G = (T + 2) / 3;
     uint32_t m[kN];
     Fe out;
@@ -200,11 +202,15 @@ PMX_FN Fe mont_dot(const Fe *a, const Fe *b, const FieldRt &f) {
             if (k < kN) {
                 m[k] = mont_step(acc[0], f);
             } else {
+                if constexpr (ADD) acc[0] += (uint64_t)s.l[k - kN] * f.unit;
                 out.l[k - kN] = (uint32_t)acc[0] & kMask;
                 acc[0] >>= kW;
             }
         } else {
             uint32_t low = (uint32_t)acc[0] & kMask;
+            if constexpr (ADD) {
+                if (k >= kN) low += s.l[k - kN];
+            }
             uint64_t carry = acc[0] >> kW;
 #pragma unroll
             for (int g = 1; g < G; ++g) {
@@ -223,8 +229,14 @@ PMX_FN Fe mont_dot(const Fe *a, const Fe *b, const FieldRt &f) {
         }
     }
     out.l[kN - 1] = (uint32_t)acc[0];
+    if constexpr (ADD) out.l[kN - 1] += s.l[kN - 1];
     return out;
 }
+
+template <int T>
+PMX_FN Fe mont_dot(const Fe *a, const Fe *b, const FieldRt &f) { return mont_dot_impl<T, false>(a, b, a[0], f); }
+template <int T>
+PMX_FN Fe mont_dot_add(const Fe *a, const Fe *b, const Fe &s, const FieldRt &f) { return mont_dot_impl<T, true>(a, b, s, f); }
 
 PMX_FN Fe mont_mul(const Fe &a, const Fe &b, const FieldRt &f) { return mont_dot<1>(&a, &b, f); }
 
@@ -300,7 +312,7 @@ PMX_FN Fe mont_sqr(const Fe &a, const FieldRt &f) {
 // 81 N + 81; the price is 10x the table size (pmx_prepare.hpp), streamed through the scalar cache.
 // Operands z must be norm (limbs < 2^29): a column then holds 9 products per term, at most 6 terms (+ 2 reduction
 // products + carry < 2^64) per accumulator; wider dots use two accumulators combined once per column.
-// ADD (N = 1 only): returns z * C + s, the addend entering two columns up (s * 2^58 before the two steps), as in
+// ADD: returns sum_i z_i * C_i + s, the addend entering two columns up (s * 2^58 before the two steps), as in
 // mont_mul_add; s norm, result norm with B < Bs + 1 + 2^-20.
 constexpr int kTabSteps = 2;
 // Table layout (pmx_prepare.hpp: put_shifted_row).  The words are grouped into CHUNKS of 27 padded to 32, in the
@@ -340,7 +352,10 @@ PMX_FN void tab_col_end(int k, uint64_t (&acc)[G], uint32_t (&m)[kTabSteps], Fe 
             }
         }
     } else {
-        const uint32_t low = ((uint32_t)acc[0] & kMask) + ((uint32_t)acc[1] & kMask);
+        uint32_t low = ((uint32_t)acc[0] & kMask) + ((uint32_t)acc[1] & kMask);
+        if constexpr (ADD) {
+            if (k >= kTabSteps && k < kN + kTabSteps - 1) low += s.l[k - kTabSteps];   // three 29-bit values: < 2^31
+        }
         const uint64_t carry = (acc[0] >> kW) + (acc[1] >> kW);
         acc[1] = 0;
         if (k < kTabSteps) {
@@ -352,13 +367,14 @@ PMX_FN void tab_col_end(int k, uint64_t (&acc)[G], uint32_t (&m)[kTabSteps], Fe 
             acc[0] = carry + (low >> kW);
         } else {
             out.l[k - kTabSteps] = (uint32_t)acc[0];   // top limb: no products this high, acc[1] is empty
+            if constexpr (ADD) out.l[k - kTabSteps] += s.l[k - kTabSteps];
         }
     }
 }
 
 template <int N, bool ADD>
 PMX_FN Fe tab_dot(const Fe *z, const uint32_t *tab, const Fe &s, const FieldRt &f) {
-    static_assert(!ADD || N == 1, "the addend form exists for single products");
+
     static_assert(N <= 12, "two accumulators");
     constexpr int G = N <= 6 ? 1 : 2;
     constexpr int kSplit = G == 1 ? N : (N + 1) / 2;   // terms [0, kSplit) -> acc[0], the rest -> acc[1]

@@ -48,9 +48,14 @@ PMX_FN void permute_dense(Fe (&s)[T], const uint32_t *ark, const uint32_t *mds, 
 // constants of lanes 1..t-1 out of the partial section.  The host derives the tables (pmx_prepare.hpp):
 //   ark      [total_rounds][T]  as before, except: partial round k keeps only lane 0 (= e_k), and the first
 //            full round after the partial section has the deferred constants folded in
-//   sparse   [RP-1][2T-1]       per partial round k < RP-1: row0[T] = (m00, v), then w[T-1]
+//   sparse   [RP-1][2T-1]       per partial round k < RP-1: row0[T] = (ONE, v), then w[T-1]
 //   bdense   [T][T]             matrix of the last partial round (M times the accumulated basis change)
-// Outputs are identical mod p to the dense schedule.
+// The S-box inputs of the partial section are SCALED (pmx_prepare.hpp: derive_opt_tables): round k works on mu_k x_k with
+// mu_{k+1} = mu_k^alpha / m00_k, which makes the coefficient of the S-box output in row 0 exactly one,
+//     s_0' = z_0 + v . (s_1 .. s_{T-1}),        s_i' = s_i + w_i z_0,
+// a (T-1)-term dot product plus an addend - 2T-2 products per sparse round instead of 2T-1 - with v, w, e and column 0 of
+// bdense rescaled on the host.  (The table keeps the slot of m00, holding ONE = 2^261 mod p: the quad engine's per-lane
+// rows multiply by it.)  Outputs are identical mod p to the dense schedule.
 struct OptTables {
     const uint32_t *ark, *mds, *sparse, *bdense;         // elements, kFeStride words each
     const uint32_t *tab_mds, *tab_sparse, *tab_bdense;   // the same matrices as shifted tables (pmx_prepare.hpp layout)
@@ -95,8 +100,8 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
         if (r < last_partial) {
             const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
             Fe row[T];
-            static_for<0, T>([&](auto j) { row[j] = fe_const(sp + j * kFeStride); });
-            s[0] = mont_dot<T>(z, row, f);
+            static_for<1, T>([&](auto j) { row[j] = fe_const(sp + j * kFeStride); });
+            if constexpr (T > 1) s[0] = mont_dot_add<T - 1>(&z[1], &row[1], z[0], f);   // z_0 + v . (s_1 ..): the coefficient of z_0 is one
             PMX_TRACK(0, s[0], f);
             static_for<1, T>([&](auto i) { s[i] = mont_mul_add(z[0], fe_const(sp + (T + i - 1) * kFeStride), s[i], f); });
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
@@ -148,6 +153,8 @@ PMX_FN uint32_t table_touch(const uint32_t *tab) {
 #else
 #define PMX_OPT_TAB_ROW(z, tab) tab_dot<T, false>(z, tab, (z)[0], f)
 #endif
+// shifted tables of one sparse round: row 0 over its T-1 constants v, then the T-1 single constants w
+PMX_FN constexpr int sparse_tab_words(int t) { return tab_row_words(t - 1) + (t - 1) * kTabOneWords; }
 template <int T, int ALPHA>
 PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
@@ -164,19 +171,18 @@ PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, co
         }
         Fe z[T];
         if constexpr (PMX_OPT_TAB_TOUCH) {
-            if (r < last_partial)
-                guard ^= table_touch<tab_row_words(T) + (T - 1) * kTabOneWords>(tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords));
+            if (r < last_partial) guard ^= table_touch<sparse_tab_words(T)>(tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T));
         }
         z[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         static_for<1, T>([&](auto i) { z[i] = s[i]; });
         if (r < last_partial) {
-            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
-            s[0] = PMX_OPT_TAB_ROW(z, sp);
+            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T);
+            s[0] = tab_dot<T - 1, true>(&z[1], sp, z[0], f);   // z_0 + v . (s_1 ..)
             PMX_TRACK(0, s[0], f);
 #if PMX_OPT_TAB_STREAM
-            tab_lanes_stream<T - 1>(z[0], sp + tab_row_words(T), &s[1], f);
+            tab_lanes_stream<T - 1>(z[0], sp + tab_row_words(T - 1), &s[1], f);
 #else
-            static_for<1, T>([&](auto i) { s[i] = tab_dot<1, true>(z, sp + tab_row_words(T) + (i - 1) * kTabOneWords, s[i], f); });
+            static_for<1, T>([&](auto i) { s[i] = tab_dot<1, true>(z, sp + tab_row_words(T - 1) + (i - 1) * kTabOneWords, s[i], f); });
 #endif
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else {   // last partial round: dense matrix B
@@ -211,6 +217,22 @@ PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
     static_for<0, T>([&](auto j) {
         cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
         if constexpr (T > kRowFreeTerms && j == kRowMidTerm - 1) cols_compress_range<kRowMidLo, kRowMidHi>(acc);
+    });
+    return cols_redc(acc, f);
+}
+
+// Row 0 of a sparse round on the wide engines:  addend + sum_{j < N} s[j] * row[j]  (N = T-1 terms; the addend is the
+// S-box output, whose coefficient is one): the addend enters the upper nine columns as addend * 2^261 before the reduction.
+template <int N>
+PMX_FN Fe matrix_row_add(const Fe *s, const uint32_t *row, const Fe &addend, const FieldRt &f) {
+    static_assert(N <= 9, "one mid-row compression covers up to 9 terms");
+    Cols acc;
+    cols_zero(acc);
+#pragma unroll
+    for (int k = 0; k < kN; ++k) acc.c[kN + k] = addend.l[k];
+    static_for<0, N>([&](auto j) {
+        cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
+        if constexpr (N > kRowFreeTerms && j == kRowMidTerm - 1) cols_compress_range<kRowMidLo, kRowMidHi>(acc);
     });
     return cols_redc(acc, f);
 }
@@ -277,48 +299,46 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
         // every round
         if constexpr (PMX_HYBRID_TOUCH) {
             if (r < last_partial) {
-                const uint32_t *rt = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
-                if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB) guard ^= table_touch<tab_row_words(T)>(rt);
-                if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB) guard ^= table_touch<(T - 1) * kTabOneWords>(rt + tab_row_words(T));
+                const uint32_t *rt = tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T);
+                if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB) guard ^= table_touch<tab_row_words(T - 1)>(rt);
+                if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB) guard ^= table_touch<(T - 1) * kTabOneWords>(rt + tab_row_words(T - 1));
                 if constexpr (T > PMX_HYBRID_TAB_MAX_T && PMX_HYBRID_TOUCH_ROW0)   // the element-form row 0 of the wide engines
                     guard ^= table_touch<T * kFeStride>(tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride);
             }
         }
         s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         if (r < last_partial && T <= PMX_HYBRID_TAB_MAX_T) {
-            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords);
+            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T);
             const Fe z0 = s[0];
             PMX_SCHED_FENCE();
-#if PMX_HYBRID_TAB_AUTO
-            s[0] = tab_dot<T, false>(s, sp, z0, f);
+            s[0] = tab_dot<T - 1, true>(&s[1], sp, z0, f);   // z_0 + v . (s_1 ..)
             PMX_TRACK(0, s[0], f);
+#if PMX_HYBRID_TAB_AUTO
             static_for<1, T>([&](auto i) {
                 PMX_SCHED_FENCE();
-                s[i] = tab_dot<1, true>(&z0, sp + tab_row_words(T) + (i - 1) * kTabOneWords, s[i], f);
+                s[i] = tab_dot<1, true>(&z0, sp + tab_row_words(T - 1) + (i - 1) * kTabOneWords, s[i], f);
             });
             PMX_SCHED_FENCE();
 #else
-            s[0] = tab_dot_stream<T>(s, sp, f);
-            PMX_TRACK(0, s[0], f);
-            tab_lanes_stream<T - 1>(z0, sp + tab_row_words(T), &s[1], f);
+            tab_lanes_stream<T - 1>(z0, sp + tab_row_words(T - 1), &s[1], f);
 #endif
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else if (r < last_partial) {
             const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
             const Fe z0 = s[0];
-            if constexpr (PMX_HYBRID_WIDE_ROW0_TAB) {
+            if constexpr (PMX_HYBRID_WIDE_ROW0_TAB && T - 1 <= 6) {
                 PMX_SCHED_FENCE();
-                s[0] = tab_dot<T, false>(s, tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords), z0, f);
+                s[0] = tab_dot<T - 1, true>(&s[1], tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T), z0, f);
                 PMX_SCHED_FENCE();
             } else {
-                s[0] = matrix_row<T>(s, sp, f);
+                s[0] = matrix_row_add<T - 1>(&s[1], sp + kFeStride, z0, f);   // z_0 + v . (s_1 ..)
             }
             PMX_TRACK(0, s[0], f);
             if constexpr (PMX_HYBRID_WIDE_LANES_TAB) {
                 // wide states: only the identity lanes take tables - that is where they pay (108 instead of 171 multiplies
                 // each); a 9-term row saves 63 of 810 and would double the constant stream
                 PMX_SCHED_FENCE();
-                tab_lanes_stream<T - 1>(z0, tb.tab_sparse + (size_t)(r - first_partial) * (tab_row_words(T) + (T - 1) * kTabOneWords) + tab_row_words(T), &s[1], f);
+                tab_lanes_stream<T - 1>(z0, tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T) + tab_row_words(T - 1), &s[1], f);
             } else {
                 static_for<1, T>([&](auto i) {
                     PMX_SCHED_FENCE();

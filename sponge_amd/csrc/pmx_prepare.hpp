@@ -49,7 +49,8 @@ struct Prepared {
     size_t coop_offset;
     //   -- only when has_opt: shifted tables (pmx_field.hpp: tab_dot); R = tab_row_words(t) --
     //   tab_mds_offset             mds      [t] rows of R words
-    //   tab_sparse_offset          sparse   [RP-1] x (row 0: R words, then t-1 single constants of kTabOneWords)
+    //   tab_sparse_offset          sparse   [RP-1] x (row 0 over its t-1 constants v: tab_row_words(t-1) words, then t-1 single
+    //                                       constants w of kTabOneWords)
     //   tab_bdense_offset          bdense   [t] rows of R words
     size_t tab_mds_offset, tab_sparse_offset, tab_bdense_offset;
     size_t io_offset;   // kIoWords words behind FieldRt::io
@@ -146,7 +147,16 @@ inline bool opt_schedule_lane_headroom(long double two_261_over_p, uint32_t part
 // basis change N_k = diag(1, Nh_k) on lanes 1..t-1, Nh_0 = I;  B_k = M N_k;  for k < RP-1: Nh_{k+1} = lower-right
 // block of B_k, sparse_k = N_{k+1}^-1 B_k = [[b00, bv],[Bh^-1 bw, I]].  Round constants of lanes 1.. are deferred
 // (vector D) and re-enter through lane 0 (e_k) and through the first full round after the partial section.
-inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full, uint32_t rp, uint32_t rounds,
+inline U256 host_pow(const HostField &f, const U256 &x, uint64_t e) {   // x^e in the Montgomery domain
+    U256 acc = f.r;
+    for (int bit = 63; bit >= 0; --bit) {
+        acc = f.mul(acc, acc);
+        if ((e >> bit) & 1) acc = f.mul(acc, x);
+    }
+    return acc;
+}
+
+inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full, uint32_t rp, uint32_t rounds, uint64_t alpha,
                               const std::vector<U256> &ark, const HostMat &M, std::vector<U256> &ark_opt,
                               std::vector<U256> &sparse, std::vector<U256> &bdense) {
     if (rp == 0 || half_full == 0 || t < 2 || half_full + rp >= rounds) return false;
@@ -195,6 +205,30 @@ inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full
     bdense.assign((size_t)t * t, zero);
     for (size_t i = 0; i < t; ++i)
         for (size_t j = 0; j < t; ++j) bdense[i * t + j] = B[i][j];
+    // Scaled S-box inputs (exact): the partial rounds run on  x~_k = mu_k x_k  instead of x_k, with mu_0 = 1 and
+    // mu_{k+1} = mu_k^alpha / m00_k.  Then z~_k = x~_k^alpha = mu_k^alpha z_k and
+    //     x~_{k+1} = mu_{k+1} (m00_k z_k + v_k . u + e_{k+1}) = z~_k + (mu_{k+1} v_k) . u + mu_{k+1} e_{k+1}:
+    // the coefficient of the S-box output in row 0 is exactly ONE, so that product disappears from every sparse round
+    // (row 0 is a (t-1)-term dot product plus an addend).  The identity lanes take  u += (w_k / mu_k^alpha) z~_k,  and the
+    // dense matrix of the last partial round absorbs 1 / mu^alpha in its column 0.  Only constants change.
+    {
+        U256 mu_alpha = f.r;                                    // mu_k^alpha, mu_0 = 1
+        for (uint32_t k = 0; k + 1 < rp; ++k) {
+            U256 *sp = &sparse[(size_t)k * (2 * t - 1)];
+            if (u256_is_zero(sp[0]) || u256_is_zero(mu_alpha)) return false;
+            const U256 inv_mu_alpha = f.inverse(mu_alpha);
+            for (size_t i = 0; i < n; ++i) sp[t + i] = f.mul(sp[t + i], inv_mu_alpha);   // w~_k
+            const U256 mu_next = f.mul(mu_alpha, f.inverse(sp[0]));                       // mu_{k+1}
+            for (size_t j = 1; j < t; ++j) sp[j] = f.mul(sp[j], mu_next);                 // v~_k
+            sp[0] = f.r;                                                                  // the coefficient of z~_k: one
+            const size_t rn = (size_t)(half_full + k + 1) * t;
+            ark_opt[rn] = f.mul(ark_opt[rn], mu_next);                                    // e~_{k+1}
+            mu_alpha = host_pow(f, mu_next, alpha);
+        }
+        if (u256_is_zero(mu_alpha)) return false;
+        const U256 inv_mu_alpha = f.inverse(mu_alpha);
+        for (size_t i = 0; i < t; ++i) bdense[i * t] = f.mul(bdense[i * t], inv_mu_alpha);
+    }
     // E = B [0; D] joins the constants of the first full round after the partial section
     const size_t rf = (size_t)(half_full + rp) * t;
     for (size_t i = 0; i < t; ++i) {
@@ -245,7 +279,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         long double two_261 = 1;
         for (int i = 0; i < 261; ++i) two_261 *= 2;
         out.has_opt = opt_schedule_lane_headroom(two_261 / pv, cfg->partial_rounds, cfg->alpha) &&
-                      derive_opt_tables(hf, t, cfg->full_rounds / 2, cfg->partial_rounds, (uint32_t)rounds, ark, M,
+                      derive_opt_tables(hf, t, cfg->full_rounds / 2, cfg->partial_rounds, (uint32_t)rounds, cfg->alpha, ark, M,
                                         ark_opt, sparse, bdense);
         out.opt_offset = out.consts.size();
         out.opt_sparse_offset = out.opt_bdense_offset = out.opt_offset;
@@ -312,7 +346,8 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     // product; a sparse round is its row 0 (t terms) followed by t-1 single products
     out.tab_mds_offset = out.tab_sparse_offset = out.tab_bdense_offset = out.consts.size();
     if (out.has_opt) {
-        const size_t row = (size_t)tab_row_words((int)t), per_round = row + (t - 1) * kTabOneWords, src_per_round = 2 * t - 1;
+        const size_t row = (size_t)tab_row_words((int)t), row0 = (size_t)tab_row_words((int)t - 1), per_round = (size_t)sparse_tab_words((int)t),
+                     src_per_round = 2 * t - 1;
         const size_t n_sparse = tab_src_sparse.size() / src_per_round;
         out.tab_sparse_offset = out.tab_mds_offset + t * row;
         out.tab_bdense_offset = out.tab_sparse_offset + n_sparse * per_round;
@@ -321,8 +356,8 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         for (size_t i = 0; i < t; ++i) put_shifted_row(hf, &tab_src_bdense[i * t], t, &out.consts[out.tab_bdense_offset + i * row]);
         for (size_t r = 0; r < n_sparse; ++r) {
             uint32_t *dst = &out.consts[out.tab_sparse_offset + r * per_round];
-            put_shifted_row(hf, &tab_src_sparse[r * src_per_round], t, dst);
-            for (size_t l = 0; l + 1 < t; ++l) put_shifted_row(hf, &tab_src_sparse[r * src_per_round + t + l], 1, dst + row + l * kTabOneWords);
+            put_shifted_row(hf, &tab_src_sparse[r * src_per_round + 1], t - 1, dst);   // row 0 without its first entry (ONE: the addend)
+            for (size_t l = 0; l + 1 < t; ++l) put_shifted_row(hf, &tab_src_sparse[r * src_per_round + t + l], 1, dst + row0 + l * kTabOneWords);
         }
     }
     FieldRt &f = out.f;
