@@ -64,15 +64,14 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     products; one reduction per S-box step and per matrix row.  With shifted tables (tab_dot) a row of N constants
     costs 81 N + 18 instead of 81 N + 81 (`row_tables`) and an identity-lane update 81 + 18 + 9 instead of 162 + 9
     (`lane_tables`).  Row 0 of a sparse round has t - 1 terms plus an addend (the S-box inputs of the partial section are
-    scaled so that the coefficient of the S-box output is one, pmx_prepare.hpp): 9 multiply-by-one injections in the
-    table form, none in the element form (the addend initialises the upper columns)."""
+    scaled so that the coefficient of the S-box output is one, pmx_prepare.hpp): + 9 multiply-by-one injections of the addend."""
     sqr, mul = 45 + 81, 81 + 81
     chain = {5: 2 * sqr + mul, 17: 4 * sqr + mul}.get(alpha)
     if chain is None:
         bits = bin(alpha)[3:]
         chain = len(bits) * sqr + bits.count("1") * mul
     dot = 81 * t + (18 if row_tables else 81)
-    row0 = 81 * (t - 1) + (18 + 9 if row_tables else 81)
+    row0 = 81 * (t - 1) + (18 if row_tables else 81) + 9
     lane = (81 + 18 + 9) if lane_tables else (mul + 9)     # + 9 multiply-by-one injections of the addend
     full = t * chain + t * dot
     if optimised:

@@ -523,7 +523,10 @@ PMX_FN void cols_compress_range(Cols &t) {
 // the only requirement is that no column overflows 64 bits once its up to nine m_j p_i products and the carry (< 2^35)
 // are added - callers bound their column sums accordingly (matrix_row; tests/test_hostcheck.py replays the worst case).
 // Norm result, B < value / (p 2^261) + 1.
-PMX_FN Fe cols_redc(Cols &t, const FieldRt &f) {
+// ADD: + s, entering the upper columns (s * 2^261) on their way out - one multiply-by-one v_mad per limb, nothing live
+// before the reduction; s norm, B grows by Bs.
+template <bool ADD = false>
+PMX_FN Fe cols_redc(Cols &t, const FieldRt &f, const Fe *s = nullptr) {
 #pragma unroll
     for (int k = 0; k < kN; ++k) {
         const uint32_t m = ((uint32_t)t.c[k] * f.pinv) & kMask;
@@ -534,10 +537,12 @@ PMX_FN Fe cols_redc(Cols &t, const FieldRt &f) {
     Fe out;
 #pragma unroll
     for (int k = kN; k < 2 * kN - 1; ++k) {
+        if constexpr (ADD) t.c[k] += (uint64_t)s->l[k - kN] * f.unit;
         out.l[k - kN] = (uint32_t)t.c[k] & kMask;
         t.c[k + 1] += t.c[k] >> kW;
     }
     out.l[kN - 1] = (uint32_t)t.c[2 * kN - 1];
+    if constexpr (ADD) out.l[kN - 1] += s->l[kN - 1];
     return out;
 }
 

@@ -222,19 +222,17 @@ PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
 }
 
 // Row 0 of a sparse round on the wide engines:  addend + sum_{j < N} s[j] * row[j]  (N = T-1 terms; the addend is the
-// S-box output, whose coefficient is one): the addend enters the upper nine columns as addend * 2^261 before the reduction.
+// S-box output, whose coefficient is one): the addend enters the upper nine columns (addend * 2^261) inside the reduction.
 template <int N>
 PMX_FN Fe matrix_row_add(const Fe *s, const uint32_t *row, const Fe &addend, const FieldRt &f) {
     static_assert(N <= 9, "one mid-row compression covers up to 9 terms");
     Cols acc;
     cols_zero(acc);
-#pragma unroll
-    for (int k = 0; k < kN; ++k) acc.c[kN + k] = addend.l[k];
     static_for<0, N>([&](auto j) {
         cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
         if constexpr (N > kRowFreeTerms && j == kRowMidTerm - 1) cols_compress_range<kRowMidLo, kRowMidHi>(acc);
     });
-    return cols_redc(acc, f);
+    return cols_redc<true>(acc, f, &addend);
 }
 
 // Which products of the hybrid engines take shifted tables (pmx_field.hpp: tab_dot, or streamed: tab_dot_stream /
