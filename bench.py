@@ -63,22 +63,24 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     """v_mad_u64_u32 count of one permutation as implemented (pmx_field.hpp): product 81, square 45, reduction 81 limb
     products; one reduction per S-box step and per matrix row.  With shifted tables (tab_dot) a row of N constants
     costs 81 N + 18 instead of 81 N + 81 (`row_tables`) and an identity-lane update 81 + 18 + 9 instead of 162 + 9
-    (`lane_tables`).  Row 0 of a sparse round has t - 1 terms plus an addend (the S-box inputs of the partial section are
-    scaled so that the coefficient of the S-box output is one, pmx_prepare.hpp): + 9 multiply-by-one injections of the addend."""
+    (`lane_tables`).  The optimised schedule carries the state scaled lane by lane so that one entry per row of every
+    matrix but the last round's is exactly one (pmx_prepare.hpp: derive_opt_tables)."""
     sqr, mul = 45 + 81, 81 + 81
     chain = {5: 2 * sqr + mul, 17: 4 * sqr + mul}.get(alpha)
     if chain is None:
         bits = bin(alpha)[3:]
         chain = len(bits) * sqr + bits.count("1") * mul
-    dot = 81 * t + (18 if row_tables else 81)
-    row0 = 81 * (t - 1) + (18 if row_tables else 81) + 9
-    lane = (81 + 18 + 9) if lane_tables else (mul + 9)     # + 9 multiply-by-one injections of the addend
-    full = t * chain + t * dot
+    red = 18 if row_tables else 81
+    dot = 81 * t + red                                      # a t-term row
+    norm = 81 * (t - 1) + red + 9                           # a normalised row: t - 1 terms + 9 multiply-by-one injections of the addend
+    lane = (81 + 18 + 9) if lane_tables else (mul + 9)
+    sparse = norm + (t - 1) * lane                          # a sparse layer: row 0 and the identity lanes
     if optimised:
-        partial = (rp - 1) * (chain + row0 + (t - 1) * lane) + (chain + t * dot)
-    else:
-        partial = rp * (chain + t * dot)
-    return rf * full + partial
+        # S-box layers: RF full, RP partial.  Linear layers: RF - 2 normalised dense (every full round but the entrance and the
+        # last one) + 1 dense (last round) + RP sparse (after the entrance round and after every partial round but the last)
+        # + 1 normalised dense (after the last partial round)
+        return rf * t * chain + rp * chain + (rf - 2) * t * norm + t * dot + rp * sparse + t * norm
+    return (rf * t + rp) * chain + (rf + rp) * t * dot
 
 
 def parse_args():

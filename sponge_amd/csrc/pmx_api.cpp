@@ -117,10 +117,11 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.n_const_words = (uint32_t)pp.consts.size();
     d.mds_offset = (uint32_t)pp.mds_offset;
     d.opt_offset = (uint32_t)pp.opt_offset;
+    d.opt_full_offset = (uint32_t)pp.opt_full_offset;
     d.opt_sparse_offset = (uint32_t)pp.opt_sparse_offset;
     d.opt_bdense_offset = (uint32_t)pp.opt_bdense_offset;
     d.coop_offset = (uint32_t)pp.coop_offset;
-    d.tab_mds_offset = (uint32_t)pp.tab_mds_offset;
+    d.tab_full_offset = (uint32_t)pp.tab_full_offset;
     d.tab_sparse_offset = (uint32_t)pp.tab_sparse_offset;
     d.tab_bdense_offset = (uint32_t)pp.tab_bdense_offset;
     d.io_offset = (uint32_t)pp.io_offset;

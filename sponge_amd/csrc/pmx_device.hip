@@ -55,6 +55,9 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 #define PMX_REG_THREADS 256   // workgroup size of the t = 3 engine: one wave per SIMD of a CU.  A/B (round 2): 128 threads -6 % on
                               // C2 / hash / tree (waves land unevenly on the SIMDs), 512 threads -0.3 % C2, -3 % tree
 #endif
+#ifndef PMX_REG_TAB_MIN_WAVES
+#define PMX_REG_TAB_MIN_WAVES 4
+#endif
 #ifndef PMX_REG_DRIVER_MIN_WAVES
 #define PMX_REG_DRIVER_MIN_WAVES 1   // absorb / squeeze kernels of the t = 3 engine: left alone they take 135 / 149 VGPRs (3 waves per SIMD)
 #endif
@@ -62,7 +65,9 @@ template <int T, int ALPHA, bool OPT, bool TAB = false>
 struct RegEngine {
     static_assert(OPT || !TAB, "shifted tables exist for the optimised schedule");
     static constexpr int kThreads = PMX_REG_THREADS;
-    static constexpr int kMinWaves = 1, kMinWavesDriver = PMX_REG_DRIVER_MIN_WAVES;
+    // the large-batch (table) kernels live on four waves per SIMD: held to 128 VGPRs (left alone the allocator has taken
+    // anything between 105 and 138 for the same source); the element-form kernels serve launches that cannot fill the chip
+    static constexpr int kMinWaves = TAB ? PMX_REG_TAB_MIN_WAVES : 1, kMinWavesDriver = PMX_REG_DRIVER_MIN_WAVES;
     static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
 
     Fe s[T];
@@ -72,10 +77,10 @@ struct RegEngine {
     OptTables tb;         // constants (LDS or global)
     uint4 *stage;         // LDS staging for coalesced state I/O
 
-    // words of the constant table staged in LDS: [mds | ark' | sparse | bdense] of the optimised schedule - only ark'
+    // words of the constant table staged in LDS: [ark' | full | sparse | bdense] of the optimised schedule - only ark'
     // when its matrices are shifted tables, which stream through the scalar cache - or [ark | mds] of the dense one
-    __host__ __device__ __forceinline__ static uint32_t first_word(const DevConfig &d) { return TAB ? d.opt_offset : OPT ? d.mds_offset : 0; }
-    __host__ __device__ __forceinline__ static uint32_t last_word(const DevConfig &d) { return TAB ? d.opt_sparse_offset : OPT ? d.coop_offset : d.opt_offset; }
+    __host__ __device__ __forceinline__ static uint32_t first_word(const DevConfig &d) { return OPT ? d.opt_offset : 0; }
+    __host__ __device__ __forceinline__ static uint32_t last_word(const DevConfig &d) { return TAB ? d.opt_full_offset : OPT ? d.coop_offset : d.opt_offset; }
 
     static size_t lds_bytes(const DevConfig &d, uint32_t /*t*/) {
         return (PMX_CONSTS_IN_LDS ? (size_t)((last_word(d) - first_word(d) + 3) / 4) * 16 : 0) + (size_t)kThreads * kChunks * 16;
@@ -102,16 +107,19 @@ struct RegEngine {
         const uint32_t *base = consts;
         stage = pmx_lds;
 #endif
-        tb.mds = base + d.mds_offset;
-        tb.tab_mds = consts + d.tab_mds_offset;
+        tb.tab_full = consts + d.tab_full_offset;
         tb.tab_sparse = consts + d.tab_sparse_offset;
         tb.tab_bdense = consts + d.tab_bdense_offset;
         if constexpr (OPT) {
             tb.ark = base + d.opt_offset;
+            tb.full = base + d.opt_full_offset;     // (the element tables past ark' are staged only when !TAB, and only read then)
             tb.sparse = base + d.opt_sparse_offset;
             tb.bdense = base + d.opt_bdense_offset;
+            tb.mds = nullptr;
         } else {
             tb.ark = base;
+            tb.mds = base + d.mds_offset;
+            tb.full = nullptr;
             tb.sparse = nullptr;
             tb.bdense = nullptr;
         }
@@ -249,9 +257,10 @@ struct HybridEngine {
         f.io = consts + d.io_offset;
         tb.mds = consts + d.mds_offset;
         tb.ark = consts + d.opt_offset;
+        tb.full = consts + d.opt_full_offset;
         tb.sparse = consts + d.opt_sparse_offset;
         tb.bdense = consts + d.opt_bdense_offset;
-        tb.tab_mds = consts + d.tab_mds_offset;
+        tb.tab_full = consts + d.tab_full_offset;
         tb.tab_sparse = consts + d.tab_sparse_offset;
         tb.tab_bdense = consts + d.tab_bdense_offset;
         lane = threadIdx.x & 63;
@@ -652,7 +661,7 @@ struct QuadEngine {
             zz[0] = quad<0>(z);
             zz[1] = quad<1>(z);
             zz[2] = quad<2>(z);
-            s = coop_post(zz, entry, f);
+            s = coop_layer_is_norm(r, c) ? coop_post_norm(zz, entry, f) : coop_post(zz, entry, f);
         }
         // lane 3 carries scratch values through the rounds; keep them bounded for the next call's lazy adds
         if (q == 3) s = fe_zero();

@@ -37,8 +37,8 @@ struct DevConfig {
     const uint32_t *consts;   // device; layout: pmx_prepare.hpp Prepared::consts
     uint32_t n_const_words;   // words in consts
     uint32_t mds_offset;      // word offsets inside consts
-    uint32_t opt_offset, opt_sparse_offset, opt_bdense_offset, coop_offset;
-    uint32_t tab_mds_offset, tab_sparse_offset, tab_bdense_offset;   // shifted tables (pmx_field.hpp: tab_dot)
+    uint32_t opt_offset, opt_full_offset, opt_sparse_offset, opt_bdense_offset, coop_offset;
+    uint32_t tab_full_offset, tab_sparse_offset, tab_bdense_offset;   // shifted tables (pmx_field.hpp: tab_dot)
     uint32_t io_offset;       // FieldRt::io block; `field.io` itself holds a HOST address and is re-pointed by the engines
     uint32_t has_opt;         // optimised schedule tables present (and, for t = 3, the cooperative table)
     uint32_t max_lds_bytes;   // LDS one workgroup may ask for on this device (launcher-side engine choice only)

@@ -42,75 +42,81 @@ PMX_FN void permute_dense(Fe (&s)[T], const uint32_t *ark, const uint32_t *mds, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Optimised schedule (exact algebraic rewrite of the same permutation; Poseidon paper, appendix B):
-// the RP partial rounds only touch state[0] non-linearly, so a change of basis on lanes 1..t-1 turns each
-// partial-round matrix into  [[m00, v^T], [w, I]]  (2t-1 products instead of t^2) and moves the round
-// constants of lanes 1..t-1 out of the partial section.  The host derives the tables (pmx_prepare.hpp):
-//   ark      [total_rounds][T]  as before, except: partial round k keeps only lane 0 (= e_k), and the first
-//            full round after the partial section has the deferred constants folded in
-//   sparse   [RP-1][2T-1]       per partial round k < RP-1: row0[T] = (ONE, v), then w[T-1]
-//   bdense   [T][T]             matrix of the last partial round (M times the accumulated basis change)
-// The S-box inputs of the partial section are SCALED (pmx_prepare.hpp: derive_opt_tables): round k works on mu_k x_k with
-// mu_{k+1} = mu_k^alpha / m00_k, which makes the coefficient of the S-box output in row 0 exactly one,
-//     s_0' = z_0 + v . (s_1 .. s_{T-1}),        s_i' = s_i + w_i z_0,
-// a (T-1)-term dot product plus an addend - 2T-2 products per sparse round instead of 2T-1 - with v, w, e and column 0 of
-// bdense rescaled on the host.  (The table keeps the slot of m00, holding ONE = 2^261 mod p: the quad engine's per-lane
-// rows multiply by it.)  Outputs are identical mod p to the dense schedule.
+// Optimised schedule: two exact algebraic rewrites of the same permutation, both done on the constants by the host
+// (pmx_prepare.hpp: derive_opt_tables has the derivation).
+//  (1) Basis change (Poseidon paper, appendix B): the RP partial rounds only touch state[0] non-linearly, so lanes 1..t-1
+//      are carried in a rotated basis in which every linear layer from the one after the last full round of the first
+//      half (the "entrance" round) to the one after the second-to-last partial round is SPARSE,
+//          s_0' = ONE z_0 + v . u,      u_i' = u_i + w_i z_0         (z_0: S-box output of lane 0, u: lanes 1..t-1),
+//      and the round constants of lanes 1..t-1 leave the partial section (they re-enter through lane 0 and through the
+//      first full round after it).
+//  (2) Diagonal scalings: x -> x^alpha commutes with a diagonal matrix up to its alpha-th power, so the state between two
+//      rounds is carried scaled lane by lane, chosen so that one entry per row is exactly ONE: column 0 of every dense
+//      layer that feeds a full S-box layer, the coefficient of z_0 in row 0 of every sparse layer.  A NORMALISED row is
+//      z_0 + sum_{j>=1} c_j z_j: an addend and t-1 products.  Only the last round's matrix stays fully dense.
+// Tables (elements, kFeStride words each; the same matrices as shifted tables next to them):
+//   ark      [total_rounds][T]   scaled constants; partial round k keeps only lane 0, the first full round after the
+//                                partial section has the deferred constants folded in
+//   full     [RF-1][T][T]        one matrix per full round except the entrance round, in round order (full_ordinal);
+//                                column 0 is ONE except in the last one
+//   sparse   [RP][2T-1]          layer 0 follows the entrance round, layer j partial round j-1: row0[T] = (ONE, v), then w[T-1]
+//   bdense   [T][T]              layer after the last partial round (normalised)
+// Products by constants per permutation at t = 3, 8 + 31: 175 (reference schedule: 351).  Outputs are identical mod p.
 struct OptTables {
-    const uint32_t *ark, *mds, *sparse, *bdense;         // elements, kFeStride words each
-    const uint32_t *tab_mds, *tab_sparse, *tab_bdense;   // the same matrices as shifted tables (pmx_prepare.hpp layout)
+    const uint32_t *ark, *mds, *full, *sparse, *bdense;   // elements (mds: the reference matrix, dense schedule only)
+    const uint32_t *tab_full, *tab_sparse, *tab_bdense;   // shifted tables (pmx_prepare.hpp layout)
 };
 
-template <int T, int ALPHA>
-PMX_FN void full_round(Fe (&s)[T], const uint32_t *rk, const uint32_t *mat, const Rounds &c, const Fe &one,
-                       const FieldRt &f) {
-    Fe y[T];
-    static_for<0, T>([&](auto i) {
-        y[i] = fe_sbox<ALPHA>(fe_add_lazy(s[i], fe_const(rk + i * kFeStride)), c.alpha, one, f);
-    });
-    static_for<0, T>([&](auto i) {
-        Fe row[T];
-        static_for<0, T>([&](auto j) { row[j] = fe_const(mat + ((size_t)i * T + j) * kFeStride); });
-        s[i] = mont_dot<T>(y, row, f);
-    });
-}
+PMX_FN uint32_t full_ordinal(uint32_t r, const Rounds &c) { return r < c.half_full ? r : r - c.partial_rounds - 1; }
 
-// Identity lanes of the sparse partial rounds:  s_i <- s_i + w_i * z0  is one mont_mul_add, which leaves the
-// magnitude of s_i uncapped: it grows by at most (1 + B_z p / 2^261) p per round (1.02 p for the usual S-boxes) from
-// B < 2.2 at the start of the partial section.  Nothing downstream depends on B being small - the lanes are only
+// Identity lanes of the sparse layers:  s_i <- s_i + w_i * z0  is one mont_mul_add, which leaves the
+// magnitude of s_i uncapped: it grows by at most (1 + B_z p / 2^261) p per layer (1.02 p for the usual S-boxes) from
+// B < 1.3 at the entrance round.  Nothing downstream depends on B being small - the lanes are only
 // ever multiplied by constants inside reductions that return  T / 2^261 + p  - except that s_i must stay below
 // 2^261 (nine normalised limbs).  pmx_prepare.hpp (opt_schedule_lane_headroom) evaluates that condition per config,
 // and configs with more partial rounds than it allows (61 to 66 for a 255-bit modulus, depending on 2^261 / p)
 // run on the dense schedule instead.
 
+// one row of a dense layer in element form; NORM: column 0 is ONE, the row is z_0 + sum_{j>=1} c_j z_j
+template <int T, bool NORM>
+PMX_FN Fe row_elem(const Fe (&z)[T], const uint32_t *row, const FieldRt &f) {
+    Fe c[T];
+    static_for<(NORM ? 1 : 0), T>([&](auto j) { c[j] = fe_const(row + j * kFeStride); });
+    if constexpr (NORM && T > 1) return mont_dot_add<T - 1>(&z[1], &c[1], z[0], f);
+    else return mont_dot<T>(z, c, f);
+}
+
+// a sparse layer in element form: s = (z_0, u) in, the next state out
+template <int T>
+PMX_FN void sparse_layer_elem(Fe (&s)[T], const uint32_t *sp, const FieldRt &f) {
+    const Fe z0 = s[0];
+    Fe v[T];
+    static_for<1, T>([&](auto j) { v[j] = fe_const(sp + j * kFeStride); });
+    if constexpr (T > 1) s[0] = mont_dot_add<T - 1>(&s[1], &v[1], z0, f);   // z_0 + v . u
+    PMX_TRACK(0, s[0], f);
+    static_for<1, T>([&](auto i) { s[i] = mont_mul_add(z0, fe_const(sp + (T + i - 1) * kFeStride), s[i], f); });
+    static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
+}
+
+// One loop over the rounds: a non-linear stage (every lane, or lane 0 alone) followed by the round's linear layer - sparse,
+// normalised dense, or the last round's dense one - so that each block of code exists once in a kernel.
 template <int T, int ALPHA>
 PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
-        if (r < first_partial || r > last_partial) {
-            full_round<T, ALPHA>(s, rk, tb.mds, c, one, f);
-            continue;
-        }
-        // partial round: lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom); lane 0 is re-derived
-        // every round
-        Fe z[T];
-        z[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
-        static_for<1, T>([&](auto i) { z[i] = s[i]; });
-        if (r < last_partial) {
-            const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
-            Fe row[T];
-            static_for<1, T>([&](auto j) { row[j] = fe_const(sp + j * kFeStride); });
-            if constexpr (T > 1) s[0] = mont_dot_add<T - 1>(&z[1], &row[1], z[0], f);   // z_0 + v . (s_1 ..): the coefficient of z_0 is one
-            PMX_TRACK(0, s[0], f);
-            static_for<1, T>([&](auto i) { s[i] = mont_mul_add(z[0], fe_const(sp + (T + i - 1) * kFeStride), s[i], f); });
-            static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
-        } else {   // last partial round: dense matrix B
-            static_for<0, T>([&](auto i) {
-                Fe row[T];
-                static_for<0, T>([&](auto j) { row[j] = fe_const(tb.bdense + ((size_t)i * T + j) * kFeStride); });
-                s[i] = mont_dot<T>(z, row, f);
-            });
+        const bool full = r < first_partial || r > last_partial;
+        // lanes 1..T-1 of a partial round stay norm (mont_mul_add, see opt_schedule_lane_headroom); lane 0 is re-derived every round
+        s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
+        if (full) static_for<1, T>([&](auto i) { s[i] = fe_sbox<ALPHA>(fe_add_lazy(s[i], fe_const(rk + i * kFeStride)), c.alpha, one, f); });
+        if (r + 1 >= first_partial && r < last_partial) {   // sparse layer: after the entrance round and every partial round but the last
+            sparse_layer_elem<T>(s, tb.sparse + (size_t)(r + 1 - first_partial) * (2 * T - 1) * kFeStride, f);
+        } else {
+            const uint32_t *mat = full ? tb.full + (size_t)full_ordinal(r, c) * T * T * kFeStride : tb.bdense;
+            Fe z[T];
+            static_for<0, T>([&](auto i) { z[i] = s[i]; });
+            if (r + 1 == c.total_rounds) static_for<0, T>([&](auto i) { s[i] = row_elem<T, false>(z, mat + (size_t)i * T * kFeStride, f); });
+            else static_for<0, T>([&](auto i) { s[i] = row_elem<T, true>(z, mat + (size_t)i * T * kFeStride, f); });
         }
     }
 }
@@ -148,45 +154,50 @@ PMX_FN uint32_t table_touch(const uint32_t *tab) {
 #ifndef PMX_OPT_TAB_STREAM
 #define PMX_OPT_TAB_STREAM 0   // 1: permute_opt_tab consumes its tables through the explicitly pipelined stream forms
 #endif
-#if PMX_OPT_TAB_STREAM
-#define PMX_OPT_TAB_ROW(z, tab) tab_dot_stream<T>(z, tab, f)
-#else
-#define PMX_OPT_TAB_ROW(z, tab) tab_dot<T, false>(z, tab, (z)[0], f)
-#endif
 // shifted tables of one sparse round: row 0 over its T-1 constants v, then the T-1 single constants w
 PMX_FN constexpr int sparse_tab_words(int t) { return tab_row_words(t - 1) + (t - 1) * kTabOneWords; }
+// one row of a dense layer as a shifted table; NORM: z_0 + sum_{j>=1} z_j c_j (the table holds c_1 ..)
+template <int T, bool NORM>
+PMX_FN Fe row_tab(const Fe (&z)[T], const uint32_t *tab, const FieldRt &f) {
+    if constexpr (NORM && T > 1) return tab_dot<T - 1, true>(&z[1], tab, z[0], f);
+    else return tab_dot<T, false>(z, tab, z[0], f);
+}
+
+// a sparse layer on shifted tables: s = (z_0, u) in, the next state out
+template <int T>
+PMX_FN void sparse_layer_tab(Fe (&s)[T], const uint32_t *sp, const FieldRt &f) {
+    const Fe z0 = s[0];
+    if constexpr (T > 1) s[0] = tab_dot<T - 1, true>(&s[1], sp, z0, f);   // z_0 + v . u
+    PMX_TRACK(0, s[0], f);
+#if PMX_OPT_TAB_STREAM
+    tab_lanes_stream<T - 1>(z0, sp + tab_row_words(T - 1), &s[1], f);
+#else
+    static_for<1, T>([&](auto i) { s[i] = tab_dot<1, true>(&z0, sp + tab_row_words(T - 1) + (i - 1) * kTabOneWords, s[i], f); });
+#endif
+    static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
+}
+
 template <int T, int ALPHA>
 PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
     uint32_t guard = 0;   // keeps table_touch's loads alive
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
-        if (r < first_partial || r > last_partial) {
-            Fe y[T];
-            static_for<0, T>([&](auto i) {
-                y[i] = fe_sbox<ALPHA>(fe_add_lazy(s[i], fe_const(rk + i * kFeStride)), c.alpha, one, f);
-            });
-            static_for<0, T>([&](auto i) { s[i] = PMX_OPT_TAB_ROW(y, tb.tab_mds + (size_t)i * tab_row_words(T)); });
-            continue;
-        }
-        Fe z[T];
+        const bool full = r < first_partial || r > last_partial;
+        const bool sparse_layer = r + 1 >= first_partial && r < last_partial;
         if constexpr (PMX_OPT_TAB_TOUCH) {
-            if (r < last_partial) guard ^= table_touch<sparse_tab_words(T)>(tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T));
+            if (sparse_layer) guard ^= table_touch<sparse_tab_words(T)>(tb.tab_sparse + (size_t)(r + 1 - first_partial) * sparse_tab_words(T));
         }
-        z[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
-        static_for<1, T>([&](auto i) { z[i] = s[i]; });
-        if (r < last_partial) {
-            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T);
-            s[0] = tab_dot<T - 1, true>(&z[1], sp, z[0], f);   // z_0 + v . (s_1 ..)
-            PMX_TRACK(0, s[0], f);
-#if PMX_OPT_TAB_STREAM
-            tab_lanes_stream<T - 1>(z[0], sp + tab_row_words(T - 1), &s[1], f);
-#else
-            static_for<1, T>([&](auto i) { s[i] = tab_dot<1, true>(z, sp + tab_row_words(T - 1) + (i - 1) * kTabOneWords, s[i], f); });
-#endif
-            static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
-        } else {   // last partial round: dense matrix B
-            static_for<0, T>([&](auto i) { s[i] = PMX_OPT_TAB_ROW(z, tb.tab_bdense + (size_t)i * tab_row_words(T)); });
+        s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
+        if (full) static_for<1, T>([&](auto i) { s[i] = fe_sbox<ALPHA>(fe_add_lazy(s[i], fe_const(rk + i * kFeStride)), c.alpha, one, f); });
+        if (sparse_layer) {
+            sparse_layer_tab<T>(s, tb.tab_sparse + (size_t)(r + 1 - first_partial) * sparse_tab_words(T), f);
+        } else {
+            const uint32_t *mat = full ? tb.tab_full + (size_t)full_ordinal(r, c) * T * tab_row_words(T) : tb.tab_bdense;
+            Fe z[T];
+            static_for<0, T>([&](auto i) { z[i] = s[i]; });
+            if (r + 1 == c.total_rounds) static_for<0, T>([&](auto i) { s[i] = row_tab<T, false>(z, mat + (size_t)i * tab_row_words(T), f); });
+            else static_for<0, T>([&](auto i) { s[i] = row_tab<T, true>(z, mat + (size_t)i * tab_row_words(T), f); });
         }
     }
     if (PMX_OPT_TAB_TOUCH && guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1)
@@ -252,29 +263,46 @@ PMX_FN Fe matrix_row_add(const Fe *s, const uint32_t *row, const Fe &addend, con
 #define PMX_HYBRID_WIDE_LANES_TAB 1
 #endif
 
-template <int T, class Scratch>
+// The t rows of one dense layer with the element loop rolled (dynamic indexing through the scratch): NORM rows are
+// s_0 + sum_{j>=1} c_j s_j - the same code for every row, which is why the normalised entry is column 0 and not the
+// diagonal - the last round's rows are t-term dot products.
+template <int T, bool NORM, class Scratch>
 PMX_FN void matrix_rows_rolled_tab(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    auto row = [&](uint32_t i) {
+        const uint32_t *tab = mat + (size_t)i * tab_row_words(T);
 #if PMX_HYBRID_TAB_AUTO
-    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, tab_dot<T, false>(s, mat + (size_t)i * tab_row_words(T), s[0], f));
-    const Fe last = tab_dot<T, false>(s, mat + (size_t)(T - 1) * tab_row_words(T), s[0], f);
+        if constexpr (NORM) return tab_dot<T - 1, true>(&s[1], tab, s[0], f);
+        else return tab_dot<T, false>(s, tab, s[0], f);
 #else
-    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, tab_dot_stream<T>(s, mat + (size_t)i * tab_row_words(T), f));
-    const Fe last = tab_dot_stream<T>(s, mat + (size_t)(T - 1) * tab_row_words(T), f);
+        if constexpr (NORM) return tab_dot<T - 1, true>(&s[1], tab, s[0], f);
+        else return tab_dot_stream<T>(s, tab, f);
 #endif
-    static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
-    s[T - 1] = last;
-}
-
-template <int T, class Scratch>
-PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
+    };
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, matrix_row<T>(s, mat + (size_t)i * T * kFeStride, f));
-    const Fe last = matrix_row<T>(s, mat + (size_t)(T - 1) * T * kFeStride, f);
+    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, row(i));
+    const Fe last = row(T - 1);
     static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
     s[T - 1] = last;
 }
 
+template <int T, bool NORM, class Scratch>
+PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
+    auto row = [&](uint32_t i) {
+        const uint32_t *rc = mat + (size_t)i * T * kFeStride;
+        if constexpr (NORM) return matrix_row_add<T - 1>(&s[1], rc + kFeStride, s[0], f);
+        else return matrix_row<T>(s, rc, f);
+    };
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, row(i));
+    const Fe last = row(T - 1);
+    static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
+    s[T - 1] = last;
+}
+
+// One loop over the rounds, each a non-linear stage (all lanes through the rolled S-box loop, or lane 0 alone) followed by
+// a linear stage chosen by the round - sparse layer, normalised dense layer, the last round's dense layer - so that every
+// block of code exists once (the sparse layer is used by the entrance round and by the partial rounds alike; two inlined
+// copies would not fit the instruction cache at t = 9).
 template <int T, int ALPHA, class Scratch>
 PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
                            const FieldRt &f) {
@@ -282,73 +310,78 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
     uint32_t guard = 0;   // keeps table_touch's loads alive (see the end of the function)
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
-        if (r < first_partial || r > last_partial) {            // full round
+        const bool full = r < first_partial || r > last_partial;
+        const bool sparse_layer = r + 1 >= first_partial && r < last_partial;   // entrance round and all partial rounds but the last
+        const uint32_t layer = r + 1 - first_partial;                            // index into `sparse` when sparse_layer
+        if (full) {            // S-box on every lane
             static_for<0, T - 1>([&](auto i) { sc.set(i, s[i]); });
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i)
                 sc.set(i, fe_sbox<ALPHA>(fe_add_lazy(sc.get(i), fe_const(rk + i * kFeStride)), c.alpha, one, f));
             s[T - 1] = fe_sbox<ALPHA>(fe_add_lazy(s[T - 1], fe_const(rk + (T - 1) * kFeStride)), c.alpha, one, f);
             static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
-            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) matrix_rows_rolled_tab<T>(s, sc, tb.tab_mds, f);
-            else matrix_rows_rolled<T>(s, sc, tb.mds, f);
-            continue;
-        }
-        // partial round: lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom); lane 0 is re-derived
-        // every round
-        if constexpr (PMX_HYBRID_TOUCH) {
-            if (r < last_partial) {
-                const uint32_t *rt = tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T);
-                if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB) guard ^= table_touch<tab_row_words(T - 1)>(rt);
-                if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB) guard ^= table_touch<(T - 1) * kTabOneWords>(rt + tab_row_words(T - 1));
-                if constexpr (T > PMX_HYBRID_TAB_MAX_T && PMX_HYBRID_TOUCH_ROW0)   // the element-form row 0 of the wide engines
-                    guard ^= table_touch<T * kFeStride>(tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride);
+        } else {               // partial round: S-box on lane 0; lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom)
+            if constexpr (PMX_HYBRID_TOUCH) {
+                if (sparse_layer) {
+                    const uint32_t *rt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
+                    if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB) guard ^= table_touch<tab_row_words(T - 1)>(rt);
+                    if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB) guard ^= table_touch<(T - 1) * kTabOneWords>(rt + tab_row_words(T - 1));
+                    if constexpr (T > PMX_HYBRID_TAB_MAX_T && PMX_HYBRID_TOUCH_ROW0)   // the element-form row 0 of the wide engines
+                        guard ^= table_touch<T * kFeStride>(tb.sparse + (size_t)layer * (2 * T - 1) * kFeStride);
+                }
             }
+            s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         }
-        s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
-        if (r < last_partial && T <= PMX_HYBRID_TAB_MAX_T) {
-            const uint32_t *sp = tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T);
+        if (sparse_layer) {
+            const uint32_t *spt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
             const Fe z0 = s[0];
-            PMX_SCHED_FENCE();
-            s[0] = tab_dot<T - 1, true>(&s[1], sp, z0, f);   // z_0 + v . (s_1 ..)
-            PMX_TRACK(0, s[0], f);
+            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
+                PMX_SCHED_FENCE();
+                s[0] = tab_dot<T - 1, true>(&s[1], spt, z0, f);   // z_0 + v . u
+                PMX_TRACK(0, s[0], f);
 #if PMX_HYBRID_TAB_AUTO
-            static_for<1, T>([&](auto i) {
-                PMX_SCHED_FENCE();
-                s[i] = tab_dot<1, true>(&z0, sp + tab_row_words(T - 1) + (i - 1) * kTabOneWords, s[i], f);
-            });
-            PMX_SCHED_FENCE();
-#else
-            tab_lanes_stream<T - 1>(z0, sp + tab_row_words(T - 1), &s[1], f);
-#endif
-            static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
-        } else if (r < last_partial) {
-            const uint32_t *sp = tb.sparse + (size_t)(r - first_partial) * (2 * T - 1) * kFeStride;
-            const Fe z0 = s[0];
-            if constexpr (PMX_HYBRID_WIDE_ROW0_TAB && T - 1 <= 6) {
-                PMX_SCHED_FENCE();
-                s[0] = tab_dot<T - 1, true>(&s[1], tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T), z0, f);
-                PMX_SCHED_FENCE();
-            } else {
-                s[0] = matrix_row_add<T - 1>(&s[1], sp + kFeStride, z0, f);   // z_0 + v . (s_1 ..)
-            }
-            PMX_TRACK(0, s[0], f);
-            if constexpr (PMX_HYBRID_WIDE_LANES_TAB) {
-                // wide states: only the identity lanes take tables - that is where they pay (108 instead of 171 multiplies
-                // each); a 9-term row saves 63 of 810 and would double the constant stream
-                PMX_SCHED_FENCE();
-                tab_lanes_stream<T - 1>(z0, tb.tab_sparse + (size_t)(r - first_partial) * sparse_tab_words(T) + tab_row_words(T - 1), &s[1], f);
-            } else {
                 static_for<1, T>([&](auto i) {
                     PMX_SCHED_FENCE();
-                    s[i] = mont_mul_add(z0, fe_const(sp + (T + i - 1) * kFeStride), s[i], f);
+                    s[i] = tab_dot<1, true>(&z0, spt + tab_row_words(T - 1) + (i - 1) * kTabOneWords, s[i], f);
                 });
                 PMX_SCHED_FENCE();
+#else
+                tab_lanes_stream<T - 1>(z0, spt + tab_row_words(T - 1), &s[1], f);
+#endif
+            } else {
+                const uint32_t *sp = tb.sparse + (size_t)layer * (2 * T - 1) * kFeStride;
+                if constexpr (PMX_HYBRID_WIDE_ROW0_TAB && T - 1 <= 6) {
+                    PMX_SCHED_FENCE();
+                    s[0] = tab_dot<T - 1, true>(&s[1], spt, z0, f);
+                    PMX_SCHED_FENCE();
+                } else {
+                    s[0] = matrix_row_add<T - 1>(&s[1], sp + kFeStride, z0, f);   // z_0 + v . u
+                }
+                PMX_TRACK(0, s[0], f);
+                if constexpr (PMX_HYBRID_WIDE_LANES_TAB) {
+                    // wide states: only the identity lanes take tables - that is where they pay (108 instead of 171 multiplies
+                    // each); a 9-term row saves 63 of 810 and would double the constant stream
+                    PMX_SCHED_FENCE();
+                    tab_lanes_stream<T - 1>(z0, spt + tab_row_words(T - 1), &s[1], f);
+                } else {
+                    static_for<1, T>([&](auto i) {
+                        PMX_SCHED_FENCE();
+                        s[i] = mont_mul_add(z0, fe_const(sp + (T + i - 1) * kFeStride), s[i], f);
+                    });
+                    PMX_SCHED_FENCE();
+                }
             }
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
-        } else {
-            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) matrix_rows_rolled_tab<T>(s, sc, tb.tab_bdense, f);
+        } else if (r + 1 == c.total_rounds) {      // last round: fully dense, its output is the permutation's
+            const uint32_t o = full_ordinal(r, c);
+            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) matrix_rows_rolled_tab<T, false>(s, sc, tb.tab_full + (size_t)o * T * tab_row_words(T), f);
+            else matrix_rows_rolled<T, false>(s, sc, tb.full + (size_t)o * T * T * kFeStride, f);
+        } else {                                   // normalised dense layer: a full round's own matrix, or B after the last partial round
+            const uint32_t o = full ? full_ordinal(r, c) : 0;
+            if constexpr (T <= PMX_HYBRID_TAB_MAX_T)
+                matrix_rows_rolled_tab<T, true>(s, sc, full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense, f);
             else
-                matrix_rows_rolled<T>(s, sc, tb.bdense, f);         // last partial round: dense matrix B
+                matrix_rows_rolled<T, true>(s, sc, full ? tb.full + (size_t)o * T * T * kFeStride : tb.bdense, f);
         }
     }
     if (PMX_HYBRID_TOUCH && guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1): the compiler cannot know
@@ -383,6 +416,18 @@ PMX_FN Fe coop_post(const Fe (&z)[3], const uint32_t *entry, const FieldRt &f) {
     Fe row[3];
     static_for<0, 3>([&](auto j) { row[j] = fe_const(entry + (1 + j) * kFeStride); });
     return mont_dot<3>(z, row, f);
+}
+// the same for a normalised dense layer (every lane's row has ONE in column 0): z_0 + c_1 z_1 + c_2 z_2
+PMX_FN Fe coop_post_norm(const Fe (&z)[3], const uint32_t *entry, const FieldRt &f) {
+    Fe row[3];
+    static_for<1, 3>([&](auto j) { row[j] = fe_const(entry + (1 + j) * kFeStride); });
+    return mont_dot_add<2>(&z[1], &row[1], z[0], f);
+}
+// normalised dense layers of the optimised schedule: every full round's but the entrance round's (sparse) and the last
+// round's (dense), and the one after the last partial round
+PMX_FN bool coop_layer_is_norm(uint32_t r, const Rounds &c) {
+    const uint32_t last_partial = c.half_full + c.partial_rounds - 1;
+    return r == last_partial || (is_full_round(r, c) && r + 1 != c.half_full && r + 1 != c.total_rounds);
 }
 
 // ---- folded sparse rounds (S-box exponents with alpha - 1 a power of two: 5 and 17) ---------------------------------

@@ -38,21 +38,23 @@ struct Prepared {
     //   [mds_offset, opt_offset)   mds      [t][t]
     //   -- only when has_opt (see pmx_permute.hpp: OptTables) --
     //   opt_offset                 ark'     [rounds][t]
-    //   opt_sparse_offset          sparse   [RP-1][2t-1]
-    //   opt_bdense_offset          bdense   [t][t]
+    //   opt_full_offset            full     [RF-1][t][t]     one matrix per full round except the entrance round
+    //   opt_sparse_offset          sparse   [RP][2t-1]       layer 0 follows the entrance round, layer j partial round j-1
+    //   opt_bdense_offset          bdense   [t][t]           layer after the last partial round
     std::vector<uint32_t> consts;
     size_t mds_offset;
     bool has_opt;
-    size_t opt_offset, opt_sparse_offset, opt_bdense_offset;
+    size_t opt_offset, opt_full_offset, opt_sparse_offset, opt_bdense_offset;
     //   -- only when has_opt and t == 3 (pmx_permute.hpp: cooperative schedule) --
     //   coop_offset                coop     [rounds][3][4]
     size_t coop_offset;
     //   -- only when has_opt: shifted tables (pmx_field.hpp: tab_dot); R = tab_row_words(t) --
-    //   tab_mds_offset             mds      [t] rows of R words
-    //   tab_sparse_offset          sparse   [RP-1] x (row 0 over its t-1 constants v: tab_row_words(t-1) words, then t-1 single
+    //   tab_full_offset            full     [RF-1][t] rows of R words (normalised rows: their t-1 constants c_1.. in the
+    //                                       tab_row_words(t-1) layout at the start of the row; last matrix: all t)
+    //   tab_sparse_offset          sparse   [RP] x (row 0 over its t-1 constants v: tab_row_words(t-1) words, then t-1 single
     //                                       constants w of kTabOneWords)
-    //   tab_bdense_offset          bdense   [t] rows of R words
-    size_t tab_mds_offset, tab_sparse_offset, tab_bdense_offset;
+    //   tab_bdense_offset          bdense   [t] rows of R words (normalised)
+    size_t tab_full_offset, tab_sparse_offset, tab_bdense_offset;
     size_t io_offset;   // kIoWords words behind FieldRt::io
 };
 
@@ -128,25 +130,22 @@ inline bool mat_inverse(const HostField &f, HostMat a, HostMat &inv) {
 }
 
 // The optimised schedule updates its identity lanes without a magnitude cap (pmx_permute.hpp: mont_mul_add).
-// With Q = 2^261 / p (>= 64) and every lane below Q p (nine normalised limbs), row 0 of a partial round returns at
-// most ((t-1) Q + B_z) / Q + 1 <= 9.2 p for t <= 9, so the S-box input x = row0 + constant is below 10.2 p and the
-// S-box output z_0 below B_z p with
-//     alpha >= 4: the chain ends in a product with x of a value < 1.05 p  ->  B_z < 1.05 * 10.2 / 64 + 1 < 1.2
-//     alpha = 3: x^2 * x, x^2 < 2.7 p -> B_z < 1.5;   alpha = 2: B_z < 2.7;   alpha = 1: z_0 = x, B_z < 10.2;
+// With Q = 2^261 / p (>= 64) and every lane below Q p (nine normalised limbs), row 0 of a sparse layer returns at most
+// (t-1) + B_z + 1 <= 10.3 p for t <= 9, so the S-box input x = row0 + constant is below 11.3 p and the S-box output z_0
+// below B_z p with
+//     alpha >= 4: the chain ends in a product with x of a value < 1.05 p  ->  B_z < 1.05 * 11.3 / 64 + 1 < 1.2
+//     alpha = 3: x^2 * x, x^2 < 3 p -> B_z < 1.6;   alpha = 2: B_z < 3;   alpha = 1: z_0 = x, B_z < 11.3;
 //     alpha = 0: z_0 = 1.
-// A lane then grows by at most (B_z / Q + 1) p per round from < 2.2 p at the start of the partial section; the
-// dense round after the last sparse one adds its own + p.  The schedule is used when all of that stays below Q.
+// A lane starts as an S-box output of the entrance round (< 1.3 p), takes its first update there and one more per sparse
+// partial round, growing by at most (B_z / Q + 1) p each time; the dense layer after the last partial round adds its own
+// + p.  The schedule is used when all of that stays below Q.
 inline bool opt_schedule_lane_headroom(long double two_261_over_p, uint32_t partial_rounds, uint64_t alpha) {
-    const long double bz = alpha == 0 ? 1.0L : alpha == 1 ? 10.2L : alpha == 2 ? 2.7L : alpha == 3 ? 1.5L : 1.3L;
+    const long double bz = alpha == 0 ? 1.0L : alpha == 1 ? 11.3L : alpha == 2 ? 3.0L : alpha == 3 ? 1.6L : 1.3L;
     const long double growth = 1.0L + bz / two_261_over_p;
-    const long double worst = 2.2L + growth * (long double)(partial_rounds > 0 ? partial_rounds - 1 : 0) + 1.5L;
+    const long double worst = 1.4L + growth * (long double)partial_rounds + 1.5L;
     return worst < two_261_over_p;
 }
 
-// Derives the tables of the optimised schedule from (ark, mds).  Notation of pmx_permute.hpp / DESIGN.md:
-// basis change N_k = diag(1, Nh_k) on lanes 1..t-1, Nh_0 = I;  B_k = M N_k;  for k < RP-1: Nh_{k+1} = lower-right
-// block of B_k, sparse_k = N_{k+1}^-1 B_k = [[b00, bv],[Bh^-1 bw, I]].  Round constants of lanes 1.. are deferred
-// (vector D) and re-enter through lane 0 (e_k) and through the first full round after the partial section.
 inline U256 host_pow(const HostField &f, const U256 &x, uint64_t e) {   // x^e in the Montgomery domain
     U256 acc = f.r;
     for (int bit = 63; bit >= 0; --bit) {
@@ -156,85 +155,122 @@ inline U256 host_pow(const HostField &f, const U256 &x, uint64_t e) {   // x^e i
     return acc;
 }
 
+// index of a full round's matrix in the `full` table: every full round but the entrance round (the last one of the first
+// half, whose linear layer is sparse[0]) has its own, in round order
+inline size_t full_matrix_ordinal(uint32_t r, uint32_t half_full, uint32_t rp) { return r < half_full ? r : r - rp - 1; }
+
+// Derives the tables of the optimised schedule from (ark, mds).  Two exact rewrites of the same permutation:
+//
+// (1) Basis change on lanes 1..t-1 (Poseidon paper, appendix B).  The partial rounds apply no S-box to those lanes, so they
+//     may be carried in any basis N_j = diag(1, Nh_j).  With B_j = M N_j the layer after S-box layer j becomes
+//     sparse_j = N_{j+1}^-1 B_j = [[b00, bv], [Bh^-1 bw, I]]  for Nh_{j+1} = Bh_j (lower-right block of B_j): 2t-1 products
+//     instead of t^2.  Layer j = 0 is the one after the LAST FULL ROUND OF THE FIRST HALF (the "entrance" round: the state
+//     it produces is only ever used in the new basis), j = 1..RP-1 follow the partial rounds, and the layer after the last
+//     partial round is dense (B_RP: the full rounds need every lane back).  Round constants of lanes 1.. are deferred
+//     (vector D) and re-enter through lane 0 (e_j) and through the first full round after the partial section.
+//
+// (2) Diagonal scalings.  x -> x^alpha commutes with a diagonal matrix up to its alpha-th power, S(D x) = D^alpha S(x), so
+//     the state between two rounds may be carried as D_r s_r for any invertible diagonal D_r (D = 1 at both ends): every
+//     constant is rescaled on the host, nothing else changes.  One free scalar per lane and round boundary makes one matrix
+//     entry per row equal to ONE: column 0 of every dense layer that feeds a full S-box layer, the coefficient of the
+//     S-box output in row 0 of every sparse layer (the lanes keep their unit coefficients).  A normalised row is
+//     z_0 + sum_{j >= 1} c_j z_j: t-1 products and an addend.  Only the last round's matrix stays fully dense (its
+//     output is the permutation's, unscaled).
+//
+// Products by constants per permutation: (RF-2) t (t-1) + t^2 + RP (2t-2) + t (t-1), e.g. t = 3, 8 + 31: 175 (dense
+// schedule 351); t = 9, 8 + 57: 1497 (5265).
 inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full, uint32_t rp, uint32_t rounds, uint64_t alpha,
                               const std::vector<U256> &ark, const HostMat &M, std::vector<U256> &ark_opt,
-                              std::vector<U256> &sparse, std::vector<U256> &bdense) {
+                              std::vector<U256> &fullmat, std::vector<U256> &sparse, std::vector<U256> &bdense) {
     if (rp == 0 || half_full == 0 || t < 2 || half_full + rp >= rounds) return false;
-    const size_t n = t - 1;
+    const size_t n = t - 1, per = 2 * (size_t)t - 1;
+    const uint32_t rf_total = rounds - rp, entrance = half_full - 1, last_partial = half_full + rp - 1;
     const U256 zero = {{0, 0, 0, 0}};
+    // ---- (1) basis change ----------------------------------------------------------------------------------------
     ark_opt = ark;
-    sparse.assign((size_t)(rp - 1) * (2 * t - 1), zero);
+    sparse.assign((size_t)rp * per, zero);
     HostMat Nh = mat_identity(f, n);
     HostMat B;
-    // D_0 = c_0[1:], e_0 = c_0[0]
-    std::vector<U256> D(n);
-    {
-        const size_t r0 = (size_t)half_full * t;
-        for (size_t i = 0; i < n; ++i) { D[i] = ark[r0 + 1 + i]; ark_opt[r0 + 1 + i] = zero; }
-    }
-    for (uint32_t k = 0; k < rp; ++k) {
+    std::vector<U256> D(n, zero);   // deferred constants of lanes 1.., in the current basis
+    for (uint32_t j = 0; j <= rp; ++j) {
         // B = M * diag(1, Nh)
         B.assign(t, std::vector<U256>(t, zero));
         for (size_t i = 0; i < t; ++i) {
             B[i][0] = M[i][0];
-            for (size_t j = 0; j < n; ++j)
-                for (size_t l = 0; l < n; ++l) B[i][1 + j] = f.add(B[i][1 + j], f.mul(M[i][1 + l], Nh[l][j]));
+            for (size_t c = 0; c < n; ++c)
+                for (size_t l = 0; l < n; ++l) B[i][1 + c] = f.add(B[i][1 + c], f.mul(M[i][1 + l], Nh[l][c]));
         }
-        if (k + 1 == rp) break;
+        if (j == rp) break;
         HostMat Bh(n, std::vector<U256>(n)), Bh_inv;
         for (size_t i = 0; i < n; ++i)
-            for (size_t j = 0; j < n; ++j) Bh[i][j] = B[1 + i][1 + j];
+            for (size_t c = 0; c < n; ++c) Bh[i][c] = B[1 + i][1 + c];
         if (!mat_inverse(f, Bh, Bh_inv)) return false;
-        U256 *sp = &sparse[(size_t)k * (2 * t - 1)];
-        for (size_t j = 0; j < t; ++j) sp[j] = B[0][j];                  // row0 = (b00, bv)
+        U256 *sp = &sparse[(size_t)j * per];
+        for (size_t c = 0; c < t; ++c) sp[c] = B[0][c];                  // row0 = (b00, bv)
         std::vector<U256> bw(n);
         for (size_t i = 0; i < n; ++i) bw[i] = B[1 + i][0];
         const std::vector<U256> w = mat_vec(f, Bh_inv, bw);              // Bh^-1 bw
         for (size_t i = 0; i < n; ++i) sp[t + i] = w[i];
-        // constants of the next partial round in the new basis
-        const size_t rn = (size_t)(half_full + k + 1) * t;
+        // constants of the round that follows (partial round j) in the new basis
+        const size_t rn = (size_t)(half_full + j) * t;
         std::vector<U256> c1(n);
         for (size_t i = 0; i < n; ++i) c1[i] = ark[rn + 1 + i];
         const std::vector<U256> ct = mat_vec(f, Bh_inv, c1);
         U256 e = ark[rn];
-        for (size_t j = 0; j < n; ++j) e = f.add(e, f.mul(B[0][1 + j], D[j]));   // + bv . D_k
+        for (size_t c = 0; c < n; ++c) e = f.add(e, f.mul(B[0][1 + c], D[c]));   // + bv . D
         ark_opt[rn] = e;
         for (size_t i = 0; i < n; ++i) { ark_opt[rn + 1 + i] = zero; D[i] = f.add(D[i], ct[i]); }
         Nh = Bh;
     }
     bdense.assign((size_t)t * t, zero);
     for (size_t i = 0; i < t; ++i)
-        for (size_t j = 0; j < t; ++j) bdense[i * t + j] = B[i][j];
-    // Scaled S-box inputs (exact): the partial rounds run on  x~_k = mu_k x_k  instead of x_k, with mu_0 = 1 and
-    // mu_{k+1} = mu_k^alpha / m00_k.  Then z~_k = x~_k^alpha = mu_k^alpha z_k and
-    //     x~_{k+1} = mu_{k+1} (m00_k z_k + v_k . u + e_{k+1}) = z~_k + (mu_{k+1} v_k) . u + mu_{k+1} e_{k+1}:
-    // the coefficient of the S-box output in row 0 is exactly ONE, so that product disappears from every sparse round
-    // (row 0 is a (t-1)-term dot product plus an addend).  The identity lanes take  u += (w_k / mu_k^alpha) z~_k,  and the
-    // dense matrix of the last partial round absorbs 1 / mu^alpha in its column 0.  Only constants change.
-    {
-        U256 mu_alpha = f.r;                                    // mu_k^alpha, mu_0 = 1
-        for (uint32_t k = 0; k + 1 < rp; ++k) {
-            U256 *sp = &sparse[(size_t)k * (2 * t - 1)];
-            if (u256_is_zero(sp[0]) || u256_is_zero(mu_alpha)) return false;
-            const U256 inv_mu_alpha = f.inverse(mu_alpha);
-            for (size_t i = 0; i < n; ++i) sp[t + i] = f.mul(sp[t + i], inv_mu_alpha);   // w~_k
-            const U256 mu_next = f.mul(mu_alpha, f.inverse(sp[0]));                       // mu_{k+1}
-            for (size_t j = 1; j < t; ++j) sp[j] = f.mul(sp[j], mu_next);                 // v~_k
-            sp[0] = f.r;                                                                  // the coefficient of z~_k: one
-            const size_t rn = (size_t)(half_full + k + 1) * t;
-            ark_opt[rn] = f.mul(ark_opt[rn], mu_next);                                    // e~_{k+1}
-            mu_alpha = host_pow(f, mu_next, alpha);
-        }
-        if (u256_is_zero(mu_alpha)) return false;
-        const U256 inv_mu_alpha = f.inverse(mu_alpha);
-        for (size_t i = 0; i < t; ++i) bdense[i * t] = f.mul(bdense[i * t], inv_mu_alpha);
-    }
+        for (size_t c = 0; c < t; ++c) bdense[i * t + c] = B[i][c];
     // E = B [0; D] joins the constants of the first full round after the partial section
     const size_t rf = (size_t)(half_full + rp) * t;
     for (size_t i = 0; i < t; ++i) {
         U256 e = zero;
-        for (size_t j = 0; j < n; ++j) e = f.add(e, f.mul(B[i][1 + j], D[j]));
+        for (size_t c = 0; c < n; ++c) e = f.add(e, f.mul(B[i][1 + c], D[c]));
         ark_opt[rf + i] = f.add(ark[rf + i], e);
+    }
+    fullmat.assign((size_t)(rf_total - 1) * t * t, zero);
+    for (size_t o = 0; o + 1 < rf_total; ++o)
+        for (size_t i = 0; i < t; ++i)
+            for (size_t c = 0; c < t; ++c) fullmat[(o * t + i) * t + c] = M[i][c];
+    // ---- (2) diagonal scalings -------------------------------------------------------------------------------------
+    std::vector<U256> d(t, f.r), dn(t), e(t), inv_e(t);
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const bool full = r < half_full || r > last_partial;
+        for (size_t i = 0; i < t; ++i) ark_opt[(size_t)r * t + i] = f.mul(ark_opt[(size_t)r * t + i], d[i]);   // D_r c_r
+        for (size_t i = 0; i < t; ++i) {                // scaling of what enters the linear layer
+            e[i] = (full || i == 0) ? host_pow(f, d[i], alpha) : d[i];
+            if (u256_is_zero(e[i])) return false;
+            inv_e[i] = f.inverse(e[i]);
+        }
+        if (r == entrance || (!full && r < last_partial)) {            // sparse layer
+            U256 *sp = &sparse[(size_t)(r - entrance) * per];
+            if (u256_is_zero(sp[0])) return false;
+            dn[0] = f.mul(e[0], f.inverse(sp[0]));
+            for (size_t c = 1; c < t; ++c) sp[c] = f.mul(f.mul(sp[c], dn[0]), inv_e[c]);
+            sp[0] = f.r;                                               // the coefficient of the S-box output: one
+            for (size_t i = 1; i < t; ++i) {
+                dn[i] = e[i];                                          // the lanes keep their unit coefficients
+                sp[t + i - 1] = f.mul(f.mul(sp[t + i - 1], dn[i]), inv_e[0]);
+            }
+        } else {
+            const bool last = r + 1 == rounds;
+            U256 *L = full ? &fullmat[full_matrix_ordinal(r, half_full, rp) * t * t] : bdense.data();
+            for (size_t i = 0; i < t; ++i) {
+                if (last) {
+                    dn[i] = f.r;
+                } else {
+                    if (u256_is_zero(L[i * t])) return false;
+                    dn[i] = f.mul(e[0], f.inverse(L[i * t]));          // column 0 becomes one
+                }
+                for (size_t c = 0; c < t; ++c) L[i * t + c] = f.mul(f.mul(L[i * t + c], dn[i]), inv_e[c]);
+                if (!last) L[i * t] = f.r;
+            }
+        }
+        d = dn;
     }
     return true;
 }
@@ -267,9 +303,11 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         to_limbs29(times_pow2(hf, v, 5), &out.consts[k * kFeStride]);   // x*2^256 -> x*2^261
     }
     // optimised schedule
-    std::vector<U256> tab_src_mds, tab_src_sparse, tab_src_bdense;
+    std::vector<U256> src_full, src_sparse, src_bdense;
+    const uint32_t half = cfg->full_rounds / 2, rp = cfg->partial_rounds;
+    const size_t n_full = cfg->full_rounds ? (size_t)cfg->full_rounds - 1 : 0;   // matrices in `full`
     {
-        std::vector<U256> ark(n_ark), ark_opt, sparse, bdense;
+        std::vector<U256> ark(n_ark), ark_opt;
         for (size_t k = 0; k < n_ark; ++k) std::memcpy(ark[k].l, cfg->ark + 4 * k, 32);
         HostMat M(t, std::vector<U256>(t));
         for (size_t i = 0; i < t; ++i)
@@ -278,86 +316,83 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         for (int i = 3; i >= 0; --i) pv = pv * 18446744073709551616.0L + (long double)hf.p.l[i];
         long double two_261 = 1;
         for (int i = 0; i < 261; ++i) two_261 *= 2;
-        out.has_opt = opt_schedule_lane_headroom(two_261 / pv, cfg->partial_rounds, cfg->alpha) &&
-                      derive_opt_tables(hf, t, cfg->full_rounds / 2, cfg->partial_rounds, (uint32_t)rounds, cfg->alpha, ark, M,
-                                        ark_opt, sparse, bdense);
+        out.has_opt = opt_schedule_lane_headroom(two_261 / pv, rp, cfg->alpha) &&
+                      derive_opt_tables(hf, t, half, rp, (uint32_t)rounds, cfg->alpha, ark, M, ark_opt, src_full, src_sparse, src_bdense);
         out.opt_offset = out.consts.size();
-        out.opt_sparse_offset = out.opt_bdense_offset = out.opt_offset;
+        out.opt_full_offset = out.opt_sparse_offset = out.opt_bdense_offset = out.opt_offset;
         if (out.has_opt) {
-            for (size_t i = 0; i < t; ++i)
-                for (size_t j = 0; j < t; ++j) tab_src_mds.push_back(M[i][j]);
-            tab_src_sparse = sparse;
-            tab_src_bdense = bdense;
-            out.opt_sparse_offset = out.opt_offset + n_ark * kFeStride;
-            out.opt_bdense_offset = out.opt_sparse_offset + sparse.size() * kFeStride;
-            out.consts.resize(out.opt_bdense_offset + bdense.size() * kFeStride, 0u);
+            out.opt_full_offset = out.opt_offset + n_ark * kFeStride;
+            out.opt_sparse_offset = out.opt_full_offset + src_full.size() * kFeStride;
+            out.opt_bdense_offset = out.opt_sparse_offset + src_sparse.size() * kFeStride;
+            out.consts.resize(out.opt_bdense_offset + src_bdense.size() * kFeStride, 0u);
             size_t k = out.opt_offset / kFeStride;
-            for (const auto *vec : {&ark_opt, &sparse, &bdense})
+            for (const auto *vec : {&ark_opt, &src_full, &src_sparse, &src_bdense})
                 for (const U256 &v : *vec) to_limbs29(times_pow2(hf, v, 5), &out.consts[(k++) * kFeStride]);
         }
     }
     // cooperative t = 3 table: per (round, lane): ark' element, then the lane's matrix row of that round
     out.coop_offset = out.consts.size();
     if (out.has_opt && t == 3) {
-        const uint32_t half = cfg->full_rounds / 2, rp = cfg->partial_rounds;
+        out.consts.resize(out.coop_offset + (size_t)rounds * 3 * kCoopElems * kFeStride, 0u);
         const uint32_t *ark_o = &out.consts[out.opt_offset];
-        const uint32_t *mds_i = &out.consts[out.mds_offset];
+        const uint32_t *full_i = &out.consts[out.opt_full_offset];
         const uint32_t *sparse_i = &out.consts[out.opt_sparse_offset];
         const uint32_t *bdense_i = &out.consts[out.opt_bdense_offset];
         uint32_t one29[kN];
         to_limbs29(times_pow2(hf, hf.r, 5), one29);
-        out.consts.resize(out.coop_offset + (size_t)rounds * 3 * kCoopElems * kFeStride, 0u);
-        // (the resize may move the buffer: re-take the pointers)
-        ark_o = &out.consts[out.opt_offset];
-        mds_i = &out.consts[out.mds_offset];
-        sparse_i = &out.consts[out.opt_sparse_offset];
-        bdense_i = &out.consts[out.opt_bdense_offset];
         auto put = [&](size_t r, size_t q, size_t slot, const uint32_t *src) {
             std::memcpy(&out.consts[out.coop_offset + ((r * 3 + q) * kCoopElems + slot) * kFeStride], src, kN * 4);
         };
+        const bool folded = cfg->alpha == 5 || cfg->alpha == 17;   // folded sparse rounds (pmx_permute.hpp: coop_fold_*)
         for (size_t r = 0; r < rounds; ++r) {
+            const bool partial = r >= half && r < (size_t)half + rp;
             for (size_t q = 0; q < 3; ++q) {
                 put(r, q, 0, ark_o + (r * 3 + q) * kFeStride);
-                const bool partial = r >= half && r < half + rp;
-                if (!partial) {
-                    for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, mds_i + (q * 3 + j) * kFeStride);
-                } else if (r + 1 == half + rp) {
-                    for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, bdense_i + (q * 3 + j) * kFeStride);
-                } else {
-                    const uint32_t *sp = sparse_i + (r - half) * 5 * kFeStride;   // row0[3] = (m00, v_1, v_2), w[2]
-                    if (cfg->alpha == 5 || cfg->alpha == 17) {   // folded sparse rounds (pmx_permute.hpp: coop_fold_*)
+                if (r + 1 == half || (partial && r + 1 < (size_t)half + rp)) {       // sparse layer: row0[3] = (ONE, v_1, v_2), w[2]
+                    const uint32_t *sp = sparse_i + (r + 1 - half) * 5 * kFeStride;
+                    if (partial && folded) {
                         if (q == 0) {
-                            put(r, q, 1, sp);                             // stage A: x * m00
+                            put(r, q, 1, sp);                             // stage A: x * ONE
                         } else {
                             put(r, q, 1, sp + (3 + q - 1) * kFeStride);   // stage A: x * w_q
                             put(r, q, 2, sp + q * kFeStride);             // stage B: s_q * v_q
                         }
-                    } else if (q == 0) {
+                    } else if (q == 0) {                                  // uniform rounds (the entrance round is one: full S-box layer)
                         for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, sp + j * kFeStride);
                     } else {
-                        put(r, q, 1, sp + (3 + q - 1) * kFeStride);   // w_q * z_0
-                        put(r, q, 1 + q, one29);                      // + ONE * z_q   (other slot stays 0)
+                        put(r, q, 1, sp + (3 + q - 1) * kFeStride);       // w_q * z_0
+                        put(r, q, 1 + q, one29);                          // + ONE * z_q   (other slot stays 0)
                     }
+                } else {
+                    const uint32_t *mat = partial ? bdense_i : full_i + full_matrix_ordinal((uint32_t)r, half, rp) * 9 * kFeStride;
+                    for (size_t j = 0; j < 3; ++j) put(r, q, 1 + j, mat + (q * 3 + j) * kFeStride);
                 }
             }
         }
     }
-    // shifted tables of every constant the optimised schedule multiplies by: every matrix row is one t-term dot
-    // product; a sparse round is its row 0 (t terms) followed by t-1 single products
-    out.tab_mds_offset = out.tab_sparse_offset = out.tab_bdense_offset = out.consts.size();
+    // shifted tables of every constant the optimised schedule multiplies by.  A normalised row (column 0 = ONE) is an
+    // addend plus a (t-1)-term dot product over c_1.., the last round's rows are t-term dot products; a sparse layer is its
+    // row 0 (t-1 terms) followed by t-1 single products.
+    out.tab_full_offset = out.tab_sparse_offset = out.tab_bdense_offset = out.consts.size();
     if (out.has_opt) {
         const size_t row = (size_t)tab_row_words((int)t), row0 = (size_t)tab_row_words((int)t - 1), per_round = (size_t)sparse_tab_words((int)t),
                      src_per_round = 2 * t - 1;
-        const size_t n_sparse = tab_src_sparse.size() / src_per_round;
-        out.tab_sparse_offset = out.tab_mds_offset + t * row;
+        const size_t n_sparse = src_sparse.size() / src_per_round;
+        out.tab_sparse_offset = out.tab_full_offset + n_full * t * row;
         out.tab_bdense_offset = out.tab_sparse_offset + n_sparse * per_round;
         out.consts.resize(out.tab_bdense_offset + t * row, 0u);
-        for (size_t i = 0; i < t; ++i) put_shifted_row(hf, &tab_src_mds[i * t], t, &out.consts[out.tab_mds_offset + i * row]);
-        for (size_t i = 0; i < t; ++i) put_shifted_row(hf, &tab_src_bdense[i * t], t, &out.consts[out.tab_bdense_offset + i * row]);
+        for (size_t o = 0; o < n_full; ++o) {
+            for (size_t i = 0; i < t; ++i) {
+                uint32_t *dst = &out.consts[out.tab_full_offset + (o * t + i) * row];
+                if (o + 1 == n_full) put_shifted_row(hf, &src_full[(o * t + i) * t], t, dst);             // last round: dense
+                else put_shifted_row(hf, &src_full[(o * t + i) * t + 1], t - 1, dst);                  // normalised: c_1 ..
+            }
+        }
+        for (size_t i = 0; i < t; ++i) put_shifted_row(hf, &src_bdense[i * t + 1], t - 1, &out.consts[out.tab_bdense_offset + i * row]);
         for (size_t r = 0; r < n_sparse; ++r) {
             uint32_t *dst = &out.consts[out.tab_sparse_offset + r * per_round];
-            put_shifted_row(hf, &tab_src_sparse[r * src_per_round + 1], t - 1, dst);   // row 0 without its first entry (ONE: the addend)
-            for (size_t l = 0; l + 1 < t; ++l) put_shifted_row(hf, &tab_src_sparse[r * src_per_round + t + l], 1, dst + row0 + l * kTabOneWords);
+            put_shifted_row(hf, &src_sparse[r * src_per_round + 1], t - 1, dst);   // row 0 without its first entry (ONE: the addend)
+            for (size_t l = 0; l + 1 < t; ++l) put_shifted_row(hf, &src_sparse[r * src_per_round + t + l], 1, dst + row0 + l * kTabOneWords);
         }
     }
     FieldRt &f = out.f;
@@ -374,7 +409,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     to_limbs29(times_pow2(hf, hf.r, 5), out.one.l);     // 2^261 mod p
     out.c.rate = cfg->rate;
     out.c.capacity = cfg->capacity;
-    out.c.half_full = cfg->full_rounds / 2;   // odd RF: RF/2 full rounds before the partial section, RF - RF/2 after (mod.rs:96-116)
+    out.c.half_full = half;   // odd RF: RF/2 full rounds before the partial section, RF - RF/2 after (mod.rs:96-116)
     out.c.partial_rounds = cfg->partial_rounds;
     out.c.total_rounds = (uint32_t)rounds;
     out.c.alpha = cfg->alpha;

@@ -46,9 +46,10 @@ static void permute_opt_t(const Prepared &pp, uint64_t *states, size_t n) {
     OptTables tb;
     tb.ark = pp.consts.data() + pp.opt_offset;
     tb.mds = pp.consts.data() + pp.mds_offset;
+    tb.full = pp.consts.data() + pp.opt_full_offset;
     tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
     tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
-    tb.tab_mds = pp.consts.data() + pp.tab_mds_offset;
+    tb.tab_full = pp.consts.data() + pp.tab_full_offset;
     tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
     tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     for (size_t k = 0; k < n; ++k) {
@@ -87,7 +88,7 @@ static void coop_permute_one(Fe (&s)[4], const uint32_t *coop, const Prepared &p
         }
         Fe z[3], nxt[4];
         for (int q = 0; q < 3; ++q) z[q] = coop_pre<ALPHA>(s[q], entry(q), is_full_round(r, pp.c) || q == 0, pp.c, pp.one, pp.f);
-        for (int q = 0; q < 4; ++q) nxt[q] = coop_post(z, entry(q), pp.f);
+        for (int q = 0; q < 4; ++q) nxt[q] = coop_layer_is_norm(r, pp.c) ? coop_post_norm(z, entry(q), pp.f) : coop_post(z, entry(q), pp.f);
         for (int q = 0; q < 4; ++q) s[q] = nxt[q];
     }
 }
@@ -123,9 +124,10 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
     OptTables tb;
     tb.ark = pp.consts.data() + pp.opt_offset;
     tb.mds = pp.consts.data() + pp.mds_offset;
+    tb.full = pp.consts.data() + pp.opt_full_offset;
     tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
     tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
-    tb.tab_mds = pp.consts.data() + pp.tab_mds_offset;
+    tb.tab_full = pp.consts.data() + pp.tab_full_offset;
     tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
     tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     for (size_t k = 0; k < n; ++k) {
