@@ -287,10 +287,10 @@ struct HybridEngine {
             region[q] = v;
         }
         __syncthreads();
-        Abi a[T];
-        static_for<0, T>([&](auto i) { a[i] = abi_from_u4(region[lane * kChunks + 2 * i], region[lane * kChunks + 2 * i + 1]); });
+        // element by element (one ABI element live at a time: reading all T first held 8 T more registers at the kernel's
+        // widest point)
+        static_for<0, T>([&](auto i) { s[i] = fe_from_abi(abi_from_u4(region[lane * kChunks + 2 * i], region[lane * kChunks + 2 * i + 1]), f); });
         __syncthreads();   // the staging area is the scratch array: finish reading before anyone writes slots
-        static_for<0, T>([&](auto i) { s[i] = fe_from_abi(a[i], f); });
     }
 
     __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {

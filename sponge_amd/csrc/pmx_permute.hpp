@@ -259,6 +259,10 @@ PMX_FN Fe matrix_row_add(const Fe *s, const uint32_t *row, const Fe &addend, con
 #ifndef PMX_HYBRID_TAB_AUTO
 #define PMX_HYBRID_TAB_AUTO 1   // t <= PMX_HYBRID_TAB_MAX_T: 1 = compiler-scheduled tab_dot (t = 4 +1 %, t = 5 +6 % over 0 = the streamed forms)
 #endif
+#ifndef PMX_HYBRID_WIDE_NORM
+#define PMX_HYBRID_WIDE_NORM 1   // t >= 6: 1 = normalised dense layers skip the product by ONE (a second rolled row block in the kernel),
+                                 // 0 = they run the last round's t-term row code on the same table
+#endif
 #ifndef PMX_HYBRID_WIDE_LANES_TAB
 #define PMX_HYBRID_WIDE_LANES_TAB 1
 #endif
@@ -372,16 +376,24 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                 }
             }
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
-        } else if (r + 1 == c.total_rounds) {      // last round: fully dense, its output is the permutation's
-            const uint32_t o = full_ordinal(r, c);
-            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) matrix_rows_rolled_tab<T, false>(s, sc, tb.tab_full + (size_t)o * T * tab_row_words(T), f);
-            else matrix_rows_rolled<T, false>(s, sc, tb.full + (size_t)o * T * T * kFeStride, f);
-        } else {                                   // normalised dense layer: a full round's own matrix, or B after the last partial round
+        } else {
+            // dense layer: a full round's own matrix or B after the last partial round - normalised (z_0 + sum_{j>=1} c_j z_j),
+            // except the last round's, whose output is the permutation's
+            const bool last = r + 1 == c.total_rounds;
             const uint32_t o = full ? full_ordinal(r, c) : 0;
-            if constexpr (T <= PMX_HYBRID_TAB_MAX_T)
-                matrix_rows_rolled_tab<T, true>(s, sc, full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense, f);
-            else
-                matrix_rows_rolled<T, true>(s, sc, full ? tb.full + (size_t)o * T * T * kFeStride : tb.bdense, f);
+            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
+                const uint32_t *mat = full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense;
+                if (last) matrix_rows_rolled_tab<T, false>(s, sc, mat, f);
+                else matrix_rows_rolled_tab<T, true>(s, sc, mat, f);
+            } else {
+                const uint32_t *mat = full ? tb.full + (size_t)o * T * T * kFeStride : tb.bdense;
+                if constexpr (PMX_HYBRID_WIDE_NORM) {
+                    if (last) matrix_rows_rolled<T, false>(s, sc, mat, f);
+                    else matrix_rows_rolled<T, true>(s, sc, mat, f);
+                } else {   // one block of row code: the element table keeps ONE in column 0, the t-term rows serve every dense layer
+                    matrix_rows_rolled<T, false>(s, sc, mat, f);
+                }
+            }
         }
     }
     if (PMX_HYBRID_TOUCH && guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1): the compiler cannot know
