@@ -190,9 +190,10 @@ struct RegEngine {
         }
     }
 
-    __device__ __forceinline__ void permute() {
-        if constexpr (TAB) permute_opt_tab<T, ALPHA>(s, tb, c, one, f);
-        else if constexpr (OPT) permute_opt<T, ALPHA>(s, tb, c, one, f);
+    // lanes [want_lo, want_hi) of the result are all the caller will read (see permute_opt); default: the whole state
+    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T) {
+        if constexpr (TAB) permute_opt_tab<T, ALPHA>(s, tb, c, one, f, want_lo, want_hi);
+        else if constexpr (OPT) permute_opt<T, ALPHA>(s, tb, c, one, f, want_lo, want_hi);
         else permute_dense<T, ALPHA>(s, tb.ark, tb.mds, c, one, f);
     }
 };
@@ -328,7 +329,7 @@ struct HybridEngine {
         });
     }
 
-    __device__ __forceinline__ void permute() { permute_hybrid<T, ALPHA>(s, sc, tb, c, one, f); }
+    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T) { permute_hybrid<T, ALPHA>(s, sc, tb, c, one, f, want_lo, want_hi); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -431,7 +432,7 @@ struct LdsEngine {
         __syncthreads();
     }
 
-    __device__ __forceinline__ void permute() {
+    __device__ __forceinline__ void permute(uint32_t /*want_lo*/ = 0, uint32_t /*want_hi*/ = PMX_MAX_WIDTH) {
         uint32_t *const home = cur;
         permute_dense_rt<ALPHA>(*this, t, ark, mds, c, one, f);
         // Lanes may permute a different number of times (per-sponge modes) while load/store_states use the
@@ -541,9 +542,13 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     size_t k_in = 0, rem = out_len, pos = 0;
     uint32_t idx = 0;
     bool squeezing = false, need = false;
+    // The sponge is dropped when the row is done, so the LAST permutation only has to produce the lanes the last squeeze
+    // copies out: [capacity, capacity + rem) once rem <= rate elements are left (want_hi; otherwise the whole state).
+    const uint32_t t_all = c.rate + c.capacity;
+    uint32_t want_hi = t_all;
     for (;;) {
         if (need) {
-            e.permute();
+            e.permute(want_hi < t_all ? c.capacity : 0, want_hi);
             need = false;
         }
         if (k_in < in_len) {                                   // absorb_internal, mod.rs:121-150
@@ -564,6 +569,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
             squeezing = true;
             need = true;
             idx = 0;
+            if (rem <= c.rate) want_hi = c.capacity + (uint32_t)rem;
             continue;
         }
         const bool last = idx + rem <= c.rate;                 // squeeze_internal, mod.rs:153-182
@@ -577,6 +583,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
         rem -= take;
         pos += take;
         idx = 0;
+        if (need && rem <= c.rate) want_hi = c.capacity + (uint32_t)rem;
     }
 }
 
@@ -595,7 +602,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     e.zero();
     e.set(e.c.capacity, fe_from_abi(abi_load(pair), e.f));
     e.set(e.c.capacity + 1, fe_from_abi(abi_load(pair + 8), e.f));
-    e.permute();
+    e.permute(e.c.capacity, e.c.capacity + 1);   // only the digest lane of the result is read
     const Abi digest = fe_to_abi(e.get(e.c.capacity), e.f);
     if (active) abi_store(reinterpret_cast<uint32_t *>(out + gid * 4), digest);
 }

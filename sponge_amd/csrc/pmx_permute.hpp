@@ -100,8 +100,11 @@ PMX_FN void sparse_layer_elem(Fe (&s)[T], const uint32_t *sp, const FieldRt &f) 
 
 // One loop over the rounds: a non-linear stage (every lane, or lane 0 alone) followed by the round's linear layer - sparse,
 // normalised dense, or the last round's dense one - so that each block of code exists once in a kernel.
+// want_lo / want_hi: lanes [want_lo, want_hi) of the RESULT the caller will read (a fixed-shape hash squeezing its last
+// elements, a 2-to-1 compression): the other rows of the last round's matrix are skipped and those lanes hold garbage.
 template <int T, int ALPHA>
-PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
+PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f, uint32_t want_lo = 0,
+                        uint32_t want_hi = T) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
@@ -115,8 +118,13 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
             const uint32_t *mat = full ? tb.full + (size_t)full_ordinal(r, c) * T * T * kFeStride : tb.bdense;
             Fe z[T];
             static_for<0, T>([&](auto i) { z[i] = s[i]; });
-            if (r + 1 == c.total_rounds) static_for<0, T>([&](auto i) { s[i] = row_elem<T, false>(z, mat + (size_t)i * T * kFeStride, f); });
-            else static_for<0, T>([&](auto i) { s[i] = row_elem<T, true>(z, mat + (size_t)i * T * kFeStride, f); });
+            if (r + 1 == c.total_rounds) {
+                static_for<0, T>([&](auto i) {
+                    if ((uint32_t)i >= want_lo && (uint32_t)i < want_hi) s[i] = row_elem<T, false>(z, mat + (size_t)i * T * kFeStride, f);
+                });
+            } else {
+                static_for<0, T>([&](auto i) { s[i] = row_elem<T, true>(z, mat + (size_t)i * T * kFeStride, f); });
+            }
         }
     }
 }
@@ -178,7 +186,8 @@ PMX_FN void sparse_layer_tab(Fe (&s)[T], const uint32_t *sp, const FieldRt &f) {
 }
 
 template <int T, int ALPHA>
-PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f) {
+PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f, uint32_t want_lo = 0,
+                            uint32_t want_hi = T) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
     uint32_t guard = 0;   // keeps table_touch's loads alive
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
@@ -196,8 +205,13 @@ PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, co
             const uint32_t *mat = full ? tb.tab_full + (size_t)full_ordinal(r, c) * T * tab_row_words(T) : tb.tab_bdense;
             Fe z[T];
             static_for<0, T>([&](auto i) { z[i] = s[i]; });
-            if (r + 1 == c.total_rounds) static_for<0, T>([&](auto i) { s[i] = row_tab<T, false>(z, mat + (size_t)i * tab_row_words(T), f); });
-            else static_for<0, T>([&](auto i) { s[i] = row_tab<T, true>(z, mat + (size_t)i * tab_row_words(T), f); });
+            if (r + 1 == c.total_rounds) {
+                static_for<0, T>([&](auto i) {
+                    if ((uint32_t)i >= want_lo && (uint32_t)i < want_hi) s[i] = row_tab<T, false>(z, mat + (size_t)i * tab_row_words(T), f);
+                });
+            } else {
+                static_for<0, T>([&](auto i) { s[i] = row_tab<T, true>(z, mat + (size_t)i * tab_row_words(T), f); });
+            }
         }
     }
     if (PMX_OPT_TAB_TOUCH && guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1)
@@ -270,8 +284,10 @@ PMX_FN Fe matrix_row_add(const Fe *s, const uint32_t *row, const Fe &addend, con
 // The t rows of one dense layer with the element loop rolled (dynamic indexing through the scratch): NORM rows are
 // s_0 + sum_{j>=1} c_j s_j - the same code for every row, which is why the normalised entry is column 0 and not the
 // diagonal - the last round's rows are t-term dot products.
+// Rows [lo, hi) only (the rest of s is left as it was / unspecified): the last round of a permutation whose caller reads
+// only those lanes.
 template <int T, bool NORM, class Scratch>
-PMX_FN void matrix_rows_rolled_tab(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
+PMX_FN void matrix_rows_rolled_tab(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f, uint32_t lo = 0, uint32_t hi = T) {
     auto row = [&](uint32_t i) {
         const uint32_t *tab = mat + (size_t)i * tab_row_words(T);
 #if PMX_HYBRID_TAB_AUTO
@@ -282,23 +298,27 @@ PMX_FN void matrix_rows_rolled_tab(Fe (&s)[T], Scratch &sc, const uint32_t *mat,
         else return tab_dot_stream<T>(s, tab, f);
 #endif
     };
+    const uint32_t end = hi < (uint32_t)T ? hi : (uint32_t)T - 1;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, row(i));
-    const Fe last = row(T - 1);
+    for (uint32_t i = lo; i < end; ++i) sc.set(i, row(i));
+    Fe last = s[T - 1];
+    if (hi == (uint32_t)T) last = row(T - 1);
     static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
     s[T - 1] = last;
 }
 
 template <int T, bool NORM, class Scratch>
-PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f) {
+PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f, uint32_t lo = 0, uint32_t hi = T) {
     auto row = [&](uint32_t i) {
         const uint32_t *rc = mat + (size_t)i * T * kFeStride;
         if constexpr (NORM) return matrix_row_add<T - 1>(&s[1], rc + kFeStride, s[0], f);
         else return matrix_row<T>(s, rc, f);
     };
+    const uint32_t end = hi < (uint32_t)T ? hi : (uint32_t)T - 1;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (uint32_t i = 0; i + 1 < (uint32_t)T; ++i) sc.set(i, row(i));
-    const Fe last = row(T - 1);
+    for (uint32_t i = lo; i < end; ++i) sc.set(i, row(i));
+    Fe last = s[T - 1];
+    if (hi == (uint32_t)T) last = row(T - 1);
     static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
     s[T - 1] = last;
 }
@@ -309,7 +329,7 @@ PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, con
 // copies would not fit the instruction cache at t = 9).
 template <int T, int ALPHA, class Scratch>
 PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
-                           const FieldRt &f) {
+                           const FieldRt &f, uint32_t want_lo = 0, uint32_t want_hi = T) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
     uint32_t guard = 0;   // keeps table_touch's loads alive (see the end of the function)
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
@@ -383,15 +403,16 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             const uint32_t o = full ? full_ordinal(r, c) : 0;
             if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
                 const uint32_t *mat = full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense;
-                if (last) matrix_rows_rolled_tab<T, false>(s, sc, mat, f);
+                if (last) matrix_rows_rolled_tab<T, false>(s, sc, mat, f, want_lo, want_hi);
                 else matrix_rows_rolled_tab<T, true>(s, sc, mat, f);
             } else {
                 const uint32_t *mat = full ? tb.full + (size_t)o * T * T * kFeStride : tb.bdense;
                 if constexpr (PMX_HYBRID_WIDE_NORM) {
-                    if (last) matrix_rows_rolled<T, false>(s, sc, mat, f);
+                    if (last) matrix_rows_rolled<T, false>(s, sc, mat, f, want_lo, want_hi);
                     else matrix_rows_rolled<T, true>(s, sc, mat, f);
                 } else {   // one block of row code: the element table keeps ONE in column 0, the t-term rows serve every dense layer
-                    matrix_rows_rolled<T, false>(s, sc, mat, f);
+                    if (last) matrix_rows_rolled<T, false>(s, sc, mat, f, want_lo, want_hi);
+                    else matrix_rows_rolled<T, false>(s, sc, mat, f);
                 }
             }
         }
