@@ -379,16 +379,16 @@ def main():
         algo_bytes = bytes_per_unit * per_gpu_units
         achieved = algo_bytes / kernel_s / 1e9
         # engines as dispatched (pmx_device.hip): t = 3..9 run the optimised schedule, with every matrix as shifted tables up
-        # to t = 5 and the identity lanes only above
-        mads = mads_per_permutation(t, alpha, rf, rp, optimised=3 <= t <= 9, row_tables=3 <= t <= 5, lane_tables=3 <= t <= 9) \
-            + (3 if merkle else 2 * t) * 162   # + ABI conversions
+        # to t = 5 and the identity lanes only above.  ABI <-> internal conversions cost no multiplies there (the schedule's
+        # own scaling makes the ABI residue the internal form, pmx_field.hpp: fe_from_abi_scaled).
+        mads = mads_per_permutation(t, alpha, rf, rp, optimised=3 <= t <= 9, row_tables=3 <= t <= 5, lane_tables=3 <= t <= 9)
         # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
         # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
         last_row = 81 * t + (18 if 3 <= t <= 5 else 81)
         if merkle:
             mads -= (t - 1) * last_row
         elif hashing:
-            mads -= (t - out_len) * last_row / perms_per_row + (2 * t - in_len / perms_per_row - out_len / perms_per_row) * 162   # (and only in_len + out_len conversions per row)
+            mads -= (t - out_len) * last_row / perms_per_row
         mad_rate = mads * per_gpu_units / kernel_s
         traffic, traffic_src = load_traffic(args.workload, per_gpu_units)
         out = {

@@ -130,6 +130,17 @@ struct RegEngine {
         for (int i = 0; i < T; ++i) s[i] = fe_zero();
     }
 
+    // ABI <-> internal: the optimised schedule works in coordinates in which the ABI residue is the internal form (no
+    // multiplication, pmx_field.hpp: fe_from_abi_scaled); the dense schedule converts exactly
+    __device__ __forceinline__ Fe from_abi(const Abi &x) const {
+        if constexpr (OPT) return fe_from_abi_scaled(x);
+        else return fe_from_abi(x, f);
+    }
+    __device__ __forceinline__ Abi to_abi(const Fe &x) const {
+        if constexpr (OPT) return fe_to_abi_scaled(x, f);
+        else return fe_to_abi(x, f);
+    }
+
     // The block's kThreads states are contiguous in global memory: copy them as one linear stream.
     __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
         const size_t first = (size_t)blockIdx.x * kThreads;
@@ -146,7 +157,7 @@ struct RegEngine {
         if (threadIdx.x < valid) {
 #pragma unroll
             for (int i = 0; i < T; ++i)
-                s[i] = fe_from_abi(abi_from_u4(stage[threadIdx.x * kChunks + 2 * i], stage[threadIdx.x * kChunks + 2 * i + 1]), f);
+                s[i] = from_abi(abi_from_u4(stage[threadIdx.x * kChunks + 2 * i], stage[threadIdx.x * kChunks + 2 * i + 1]));
         } else {
             zero();
         }
@@ -160,7 +171,7 @@ struct RegEngine {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-            const Abi a = fe_to_abi(s[i], f);
+            const Abi a = to_abi(s[i]);
             stage[threadIdx.x * kChunks + 2 * i] = abi_lo(a);
             stage[threadIdx.x * kChunks + 2 * i + 1] = abi_hi(a);
         }
@@ -272,6 +283,8 @@ struct HybridEngine {
     __device__ __forceinline__ void zero() {
         static_for<0, T>([&](auto i) { s[i] = fe_zero(); });
     }
+    __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi_scaled(x); }      // optimised schedule: see RegEngine
+    __device__ __forceinline__ Abi to_abi(const Fe &x) const { return fe_to_abi_scaled(x, f); }
 
     // every wave stages its own 64 contiguous states through its own region
     __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
@@ -290,7 +303,7 @@ struct HybridEngine {
         __syncthreads();
         // element by element (one ABI element live at a time: reading all T first held 8 T more registers at the kernel's
         // widest point)
-        static_for<0, T>([&](auto i) { s[i] = fe_from_abi(abi_from_u4(region[lane * kChunks + 2 * i], region[lane * kChunks + 2 * i + 1]), f); });
+        static_for<0, T>([&](auto i) { s[i] = from_abi(abi_from_u4(region[lane * kChunks + 2 * i], region[lane * kChunks + 2 * i + 1])); });
         __syncthreads();   // the staging area is the scratch array: finish reading before anyone writes slots
     }
 
@@ -301,7 +314,7 @@ struct HybridEngine {
         const uint32_t n_chunks = (uint32_t)valid * kChunks;
         __syncthreads();
         static_for<0, T>([&](auto i) {
-            const Abi a = fe_to_abi(s[i], f);
+            const Abi a = to_abi(s[i]);
             region[lane * kChunks + 2 * i] = abi_lo(a);
             region[lane * kChunks + 2 * i + 1] = abi_hi(a);
         });
@@ -389,6 +402,8 @@ struct LdsEngine {
     __device__ __forceinline__ void zero() {
         for (uint32_t i = 0; i < t; ++i) set(i, fe_zero());
     }
+    __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi(x, f); }            // dense schedule: exact conversions
+    __device__ __forceinline__ Abi to_abi(const Fe &x) const { return fe_to_abi(x, f); }
 
     // wave-level: 64 contiguous ABI states = 64*2t contiguous 16-B chunks in global memory, staged through
     // the `nxt` buffer (chunk q of the wave at uint4 index q), then converted element by element
@@ -407,7 +422,7 @@ struct LdsEngine {
             st[q] = v;
         }
         __syncthreads();
-        for (uint32_t i = 0; i < t; ++i) set(i, fe_from_abi(abi_from_u4(st[lane * chunks + 2 * i], st[lane * chunks + 2 * i + 1]), f));
+        for (uint32_t i = 0; i < t; ++i) set(i, from_abi(abi_from_u4(st[lane * chunks + 2 * i], st[lane * chunks + 2 * i + 1])));
         __syncthreads();
     }
 
@@ -420,7 +435,7 @@ struct LdsEngine {
         uint4 *st = reinterpret_cast<uint4 *>(nxt);
         __syncthreads();
         for (uint32_t i = 0; i < t; ++i) {
-            const Abi a = fe_to_abi(get(i), f);
+            const Abi a = to_abi(get(i));
             st[lane * chunks + 2 * i] = abi_lo(a);
             st[lane * chunks + 2 * i + 1] = abi_hi(a);
         }
@@ -471,7 +486,7 @@ __device__ __forceinline__ uint32_t absorb_elements(Engine &e, const uint64_t *r
     while (__builtin_amdgcn_ballot_w64(k < in_len)) {
         for (uint32_t j = 0; j < c.rate; ++j) {   // wave-uniform trip count; lanes drop out as they fill up or run dry
             if (k < in_len && idx < c.rate) {
-                const Fe x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)), e.f);
+                const Fe x = e.from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)));
                 const uint32_t pos = c.capacity + idx;
                 // state[capacity + idx] += element (mod.rs:128,143); normalised so the permutation's own lazy
                 // round-constant add stays within the limb bounds
@@ -510,7 +525,7 @@ __device__ __forceinline__ uint32_t squeeze_elements(Engine &e, uint64_t *row, s
             const bool last = idx + rem <= c.rate;
             const uint32_t take = last ? (uint32_t)rem : c.rate - idx;
             for (uint32_t k = 0; k < take; ++k)
-                abi_store(reinterpret_cast<uint32_t *>(row + 4 * (pos + k)), fe_to_abi(e.get(c.capacity + idx + k), e.f));
+                abi_store(reinterpret_cast<uint32_t *>(row + 4 * (pos + k)), e.to_abi(e.get(c.capacity + idx + k)));
             if (last) {
                 idx += take;
                 done = true;
@@ -558,7 +573,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
                 continue;
             }
             Fe x = fe_zero();
-            if (active) x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row_in + 4 * k_in)), e.f);
+            if (active) x = e.from_abi(abi_load(reinterpret_cast<const uint32_t *>(row_in + 4 * k_in)));
             const uint32_t at = c.capacity + idx;
             e.set(at, fe_normalize(fe_add_lazy(e.get(at), x)));
             ++idx;
@@ -575,7 +590,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
         const bool last = idx + rem <= c.rate;                 // squeeze_internal, mod.rs:153-182
         const uint32_t take = last ? (uint32_t)rem : c.rate - idx;
         for (uint32_t k = 0; k < take; ++k) {
-            const Abi v = fe_to_abi(e.get(c.capacity + idx + k), e.f);
+            const Abi v = e.to_abi(e.get(c.capacity + idx + k));
             if (active) abi_store(reinterpret_cast<uint32_t *>(row_out + 4 * (pos + k)), v);
         }
         if (last) break;
@@ -600,10 +615,10 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     const bool active = gid < n;
     const uint32_t *pair = reinterpret_cast<const uint32_t *>(in + (active ? gid : 0) * 8);
     e.zero();
-    e.set(e.c.capacity, fe_from_abi(abi_load(pair), e.f));
-    e.set(e.c.capacity + 1, fe_from_abi(abi_load(pair + 8), e.f));
+    e.set(e.c.capacity, e.from_abi(abi_load(pair)));
+    e.set(e.c.capacity + 1, e.from_abi(abi_load(pair + 8)));
     e.permute(e.c.capacity, e.c.capacity + 1);   // only the digest lane of the result is read
-    const Abi digest = fe_to_abi(e.get(e.c.capacity), e.f);
+    const Abi digest = e.to_abi(e.get(e.c.capacity));
     if (active) abi_store(reinterpret_cast<uint32_t *>(out + gid * 4), digest);
 }
 
@@ -636,6 +651,9 @@ struct QuadEngine {
         role = q < 3 ? q : 2;   // lane 3 reads lane 2's entries; in the uniform rounds it shadows lane 2 (its result is never read)
         s = fe_zero();
     }
+
+    __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi_scaled(x); }      // optimised schedule: see RegEngine
+    __device__ __forceinline__ Abi to_abi(const Fe &x) const { return fe_to_abi_scaled(x, f); }
 
     // element held by lane `lane` of this quad, in every lane
     template <int LANE>
@@ -683,9 +701,9 @@ __global__ void __launch_bounds__(256, 2)
     QuadEngine<ALPHA> e(d, consts);
     const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     const bool active = g < n;
-    if (active && (e.q == 1 || e.q == 2)) e.s = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(in + (g * 2 + (e.q - 1)) * 4)), e.f);
+    if (active && (e.q == 1 || e.q == 2)) e.s = e.from_abi(abi_load(reinterpret_cast<const uint32_t *>(in + (g * 2 + (e.q - 1)) * 4)));
     e.permute();
-    const Abi digest = fe_to_abi(e.s, e.f);
+    const Abi digest = e.to_abi(e.s);
     if (active && e.q == 1) abi_store(reinterpret_cast<uint32_t *>(out + g * 4), digest);   // state[capacity]
 }
 
@@ -697,9 +715,9 @@ __global__ void __launch_bounds__(256, 2)
     const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     const bool active = g < n;
     uint32_t *mine = reinterpret_cast<uint32_t *>(states + ((active ? g : 0) * 3 + e.role) * 4);
-    if (active && e.q < 3) e.s = fe_from_abi(abi_load(mine), e.f);
+    if (active && e.q < 3) e.s = e.from_abi(abi_load(mine));
     e.permute();
-    const Abi v = fe_to_abi(e.s, e.f);
+    const Abi v = e.to_abi(e.s);
     if (active && e.q < 3) abi_store(mine, v);
 }
 
@@ -729,7 +747,7 @@ __global__ void __launch_bounds__(256, 2)
                 continue;
             }
             Fe x = fe_zero();
-            if (active) x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row_in + 4 * k_in)), e.f);
+            if (active) x = e.from_abi(abi_load(reinterpret_cast<const uint32_t *>(row_in + 4 * k_in)));
             if (e.q == c.capacity + idx) e.s = fe_normalize(fe_add_lazy(e.s, x));
             ++idx;
             ++k_in;
@@ -743,7 +761,7 @@ __global__ void __launch_bounds__(256, 2)
         }
         const bool last = idx + rem <= c.rate;                 // squeeze_internal, mod.rs:153-182
         const uint32_t take = last ? (uint32_t)rem : c.rate - idx;
-        const Abi v = fe_to_abi(e.s, e.f);
+        const Abi v = e.to_abi(e.s);
         for (uint32_t k = 0; k < take; ++k)
             if (active && e.q == c.capacity + idx + k) abi_store(reinterpret_cast<uint32_t *>(row_out + 4 * (pos + k)), v);
         if (last) break;
@@ -766,7 +784,7 @@ __global__ void __launch_bounds__(256, 2)
     const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     const bool active = g < n;
     uint32_t *mine = reinterpret_cast<uint32_t *>(states + ((active ? g : 0) * 3 + e.role) * 4);
-    if (active && e.q < 3) e.s = fe_from_abi(abi_load(mine), e.f);
+    if (active && e.q < 3) e.s = e.from_abi(abi_load(mine));
     uint32_t idx = 0;
     if (active) idx = (mode_tag[g] == PMX_MODE_ABSORBING) ? mode_index[g] : e.c.rate;
     if (idx > e.c.rate) idx = e.c.rate;                        // device-resident mode words are not validated by the host
@@ -775,7 +793,7 @@ __global__ void __launch_bounds__(256, 2)
     while (__builtin_amdgcn_ballot_w64(k < in_len)) {
         for (uint32_t j = 0; j < e.c.rate; ++j) {
             if (k < in_len && idx < e.c.rate) {
-                const Fe x = fe_from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)), e.f);
+                const Fe x = e.from_abi(abi_load(reinterpret_cast<const uint32_t *>(row + 4 * k)));
                 if (e.q == e.c.capacity + idx) e.s = fe_normalize(fe_add_lazy(e.s, x));   // state[capacity + idx] += element (mod.rs:128,143)
                 idx += 1;
                 k += 1;
@@ -789,7 +807,7 @@ __global__ void __launch_bounds__(256, 2)
             }
         }
     }
-    const Abi v = fe_to_abi(e.s, e.f);
+    const Abi v = e.to_abi(e.s);
     if (active && e.q < 3) abi_store(mine, v);
     if (active && e.q == 0) {
         mode_tag[g] = PMX_MODE_ABSORBING;                      // mod.rs:130-132
@@ -806,7 +824,7 @@ __global__ void __launch_bounds__(256, 2)
     const size_t g = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     const bool active = g < n;
     uint32_t *mine = reinterpret_cast<uint32_t *>(states + ((active ? g : 0) * 3 + e.role) * 4);
-    if (active && e.q < 3) e.s = fe_from_abi(abi_load(mine), e.f);
+    if (active && e.q < 3) e.s = e.from_abi(abi_load(mine));
     uint32_t idx = 0;
     bool need = true;                                          // Absorbing -> permute, start at 0 (mod.rs:324-328)
     if (active && mode_tag[g] == PMX_MODE_SQUEEZING) {         // mod.rs:330-336
@@ -826,7 +844,7 @@ __global__ void __launch_bounds__(256, 2)
         if (!done) {
             const bool last = idx + rem <= e.c.rate;
             const uint32_t take = last ? (uint32_t)rem : e.c.rate - idx;
-            const Abi v = fe_to_abi(e.s, e.f);                 // every lane converts its own element; the matching one stores
+            const Abi v = e.to_abi(e.s);                 // every lane converts its own element; the matching one stores
             for (uint32_t k = 0; k < take; ++k)
                 if (e.q == e.c.capacity + idx + k) abi_store(reinterpret_cast<uint32_t *>(row + 4 * (pos + k)), v);
             if (last) {
@@ -840,7 +858,7 @@ __global__ void __launch_bounds__(256, 2)
             }
         }
     }
-    const Abi v = fe_to_abi(e.s, e.f);
+    const Abi v = e.to_abi(e.s);
     if (active && e.q < 3) abi_store(mine, v);
     if (active && e.q == 0) {
         mode_tag[g] = PMX_MODE_SQUEEZING;                      // mod.rs:162-164

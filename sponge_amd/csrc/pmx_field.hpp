@@ -623,6 +623,32 @@ PMX_FN Abi fe_to_abi(const Fe &x, const FieldRt &f) {
     return r;
 }
 
+// ---- ABI <-> internal without a multiplication (optimised schedule) ---------------------------------------------------------
+// The optimised schedule carries its state scaled lane by lane anyway (pmx_prepare.hpp: derive_opt_tables); with the scaling
+// 2^-5 at both ends of the permutation the internal form of a state element x is (x / 32) * 2^261 = x * 2^256 - the ABI
+// residue itself.  Entering is bit-slicing 8 x 32 -> 9 x 29, leaving is the exact reduction to [0, p) and slicing back; the
+// elements a sponge absorbs (added to the state in the same scaled coordinates) and squeezes are converted the same way.
+PMX_FN Fe fe_from_abi_scaled(const Abi &x) { return limbs_32_to_29(x); }
+
+// x norm with value below 3 p (a state lane after a permutation is below 1.3 p, after absorbing one more element 2.3 p)
+PMX_FN Abi fe_to_abi_scaled(const Fe &x, const FieldRt &f) {
+    Fe t = x;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        Fe d;
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < kN; ++i) {
+            const uint32_t v = t.l[i] - f.p[i] - borrow;   // limbs below 2^29: bit 31 of the wrapped difference is the borrow
+            d.l[i] = v & kMask;
+            borrow = v >> 31;
+        }
+#pragma unroll
+        for (int i = 0; i < kN; ++i) t.l[i] = borrow ? t.l[i] : d.l[i];
+    }
+    return limbs_29_to_32(t);
+}
+
 #if defined(__HIPCC__)
 // 32-byte ABI element <-> two 16-byte vectors
 __device__ __forceinline__ Abi abi_from_u4(const uint4 &lo, const uint4 &hi) {

@@ -170,7 +170,7 @@ inline size_t full_matrix_ordinal(uint32_t r, uint32_t half_full, uint32_t rp) {
 //     (vector D) and re-enter through lane 0 (e_j) and through the first full round after the partial section.
 //
 // (2) Diagonal scalings.  x -> x^alpha commutes with a diagonal matrix up to its alpha-th power, S(D x) = D^alpha S(x), so
-//     the state between two rounds may be carried as D_r s_r for any invertible diagonal D_r (D = 1 at both ends): every
+//     the state between two rounds may be carried as D_r s_r for any invertible diagonal D_r (the same D at both ends): every
 //     constant is rescaled on the host, nothing else changes.  One free scalar per lane and round boundary makes one matrix
 //     entry per row equal to ONE: column 0 of every dense layer that feeds a full S-box layer, the coefficient of the
 //     S-box output in row 0 of every sparse layer (the lanes keep their unit coefficients).  A normalised row is
@@ -237,7 +237,13 @@ inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full
         for (size_t i = 0; i < t; ++i)
             for (size_t c = 0; c < t; ++c) fullmat[(o * t + i) * t + c] = M[i][c];
     // ---- (2) diagonal scalings -------------------------------------------------------------------------------------
-    std::vector<U256> d(t, f.r), dn(t), e(t), inv_e(t);
+    // D at both ends of the permutation is 2^-5, not 1: the internal form of x / 32 is (x / 32) 2^261 = x 2^256, the ABI
+    // residue itself, so states, absorbed and squeezed elements enter and leave the kernels without a multiplication
+    // (pmx_field.hpp: fe_from_abi_scaled / fe_to_abi_scaled).  Between two permutations of a sponge the state stays in
+    // these coordinates.
+    const U256 thirty_two = {{32, 0, 0, 0}};
+    const U256 io_scale = f.inverse(f.to_mont(thirty_two));
+    std::vector<U256> d(t, io_scale), dn(t), e(t), inv_e(t);
     for (uint32_t r = 0; r < rounds; ++r) {
         const bool full = r < half_full || r > last_partial;
         for (size_t i = 0; i < t; ++i) ark_opt[(size_t)r * t + i] = f.mul(ark_opt[(size_t)r * t + i], d[i]);   // D_r c_r
@@ -261,7 +267,7 @@ inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full
             U256 *L = full ? &fullmat[full_matrix_ordinal(r, half_full, rp) * t * t] : bdense.data();
             for (size_t i = 0; i < t; ++i) {
                 if (last) {
-                    dn[i] = f.r;
+                    dn[i] = io_scale;
                 } else {
                     if (u256_is_zero(L[i * t])) return false;
                     dn[i] = f.mul(e[0], f.inverse(L[i * t]));          // column 0 becomes one

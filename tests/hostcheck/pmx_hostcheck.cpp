@@ -54,7 +54,7 @@ static void permute_opt_t(const Prepared &pp, uint64_t *states, size_t n) {
     tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
-        for (int i = 0; i < T; ++i) s[i] = fe_from_abi(load_abi(states + (k * T + i) * 4), pp.f);
+        for (int i = 0; i < T; ++i) s[i] = fe_from_abi_scaled(load_abi(states + (k * T + i) * 4));
         if constexpr (TAB) {
             if (pp.c.alpha == 5) permute_opt_tab<T, 5>(s, tb, pp.c, pp.one, pp.f);
             else if (pp.c.alpha == 17) permute_opt_tab<T, 17>(s, tb, pp.c, pp.one, pp.f);
@@ -64,7 +64,7 @@ static void permute_opt_t(const Prepared &pp, uint64_t *states, size_t n) {
             else if (pp.c.alpha == 17) permute_opt<T, 17>(s, tb, pp.c, pp.one, pp.f);
             else permute_opt<T, 0>(s, tb, pp.c, pp.one, pp.f);
         }
-        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi(s[i], pp.f));
+        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
     }
 }
 
@@ -102,12 +102,12 @@ extern "C" int hc_permute_coop(const pmx_config *cfg, uint64_t *states, size_t n
     const uint32_t *coop = pp.consts.data() + pp.coop_offset;
     for (size_t k = 0; k < n; ++k) {
         Fe s[4];
-        for (int i = 0; i < 3; ++i) s[i] = fe_from_abi(load_abi(states + (k * 3 + i) * 4), pp.f);
+        for (int i = 0; i < 3; ++i) s[i] = fe_from_abi_scaled(load_abi(states + (k * 3 + i) * 4));
         s[3] = fe_zero();
         if (pp.c.alpha == 5) coop_permute_one<5>(s, coop, pp);
         else if (pp.c.alpha == 17) coop_permute_one<17>(s, coop, pp);
         else coop_permute_one<0>(s, coop, pp);
-        for (int i = 0; i < 3; ++i) store_abi(states + (k * 3 + i) * 4, fe_to_abi(s[i], pp.f));
+        for (int i = 0; i < 3; ++i) store_abi(states + (k * 3 + i) * 4, fe_to_abi_scaled(s[i], pp.f));
     }
     return PMX_OK;
 }
@@ -133,11 +133,11 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
         HostScratch<T> sc;
-        for (int i = 0; i < T; ++i) s[i] = fe_from_abi(load_abi(states + (k * T + i) * 4), pp.f);
+        for (int i = 0; i < T; ++i) s[i] = fe_from_abi_scaled(load_abi(states + (k * T + i) * 4));
         if (pp.c.alpha == 5) permute_hybrid<T, 5>(s, sc, tb, pp.c, pp.one, pp.f);
         else if (pp.c.alpha == 17) permute_hybrid<T, 17>(s, sc, tb, pp.c, pp.one, pp.f);
         else permute_hybrid<T, 0>(s, sc, tb, pp.c, pp.one, pp.f);
-        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi(s[i], pp.f));
+        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
     }
 }
 
