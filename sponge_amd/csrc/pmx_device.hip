@@ -286,6 +286,33 @@ struct HybridEngine {
     __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi_scaled(x); }      // optimised schedule: see RegEngine
     __device__ __forceinline__ Abi to_abi(const Fe &x) const { return fe_to_abi_scaled(x, f); }
 
+#ifndef PMX_HYB_DIRECT_IO
+#define PMX_HYB_DIRECT_IO 1
+#endif
+#if PMX_HYB_DIRECT_IO
+    // Every lane reads and writes its own 32 T contiguous bytes with 16-byte accesses.  Across the lanes of a wave these are
+    // strided, but every cache line is used in full within the 2 T accesses of the lane that owns it, and a wide permutation
+    // moves 64 T bytes in ~2 ms of arithmetic: nothing to gain from staging the wave's span through LDS, and without the
+    // staging code (two barriers, the T-element gather) the register allocation of the permute kernel comes out like that of
+    // the hash kernel (no spills inside the rounds).
+    __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
+        const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
+        const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + (gid < n ? gid : 0) * kChunks;
+        static_for<0, T>([&](auto i) { s[i] = from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])); });
+    }
+
+    __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {
+        const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
+        if (gid < n) {
+            uint4 *g = reinterpret_cast<uint4 *>(g_states) + gid * kChunks;
+            static_for<0, T>([&](auto i) {
+                const Abi a = to_abi(s[i]);
+                g[2 * i] = abi_lo(a);
+                g[2 * i + 1] = abi_hi(a);
+            });
+        }
+    }
+#else
     // every wave stages its own 64 contiguous states through its own region
     __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
         const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
@@ -303,7 +330,10 @@ struct HybridEngine {
         __syncthreads();
         // element by element (one ABI element live at a time: reading all T first held 8 T more registers at the kernel's
         // widest point)
-        static_for<0, T>([&](auto i) { s[i] = from_abi(abi_from_u4(region[lane * kChunks + 2 * i], region[lane * kChunks + 2 * i + 1])); });
+        static_for<0, T>([&](auto i) {
+            s[i] = from_abi(abi_from_u4(region[lane * kChunks + 2 * i], region[lane * kChunks + 2 * i + 1]));
+            PMX_SCHED_FENCE();
+        });
         __syncthreads();   // the staging area is the scratch array: finish reading before anyone writes slots
     }
 
@@ -317,6 +347,7 @@ struct HybridEngine {
             const Abi a = to_abi(s[i]);
             region[lane * kChunks + 2 * i] = abi_lo(a);
             region[lane * kChunks + 2 * i + 1] = abi_hi(a);
+            PMX_SCHED_FENCE();   // one element at a time: interleaved, the T conversions are the widest point of the kernel
         });
         __syncthreads();
 #pragma unroll
@@ -326,6 +357,8 @@ struct HybridEngine {
         }
         __syncthreads();
     }
+
+#endif
 
     __device__ __forceinline__ Fe get(uint32_t i) const {
         Fe r = s[0];
@@ -466,7 +499,10 @@ template <class Engine>
 __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves) permute_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states, size_t n) {
     Engine e(d, consts);
     e.load_states(states, n);
-    e.permute();
+    // (all lanes of the result are wanted; the width is passed as the run-time value it also is in the other kernels: with the
+    // compile-time constant the wide engines' last round is specialised and the register allocation of the whole kernel
+    // comes out worse - 132 instead of 0..20 bytes of scratch per lane at t = 9, spills inside the sparse rounds)
+    e.permute(0, e.c.rate + e.c.capacity);
     e.store_states(states, n);
 }
 

@@ -407,8 +407,8 @@ PMX_FN Fe tab_dot(const Fe *z, const uint32_t *tab, const Fe &s, const FieldRt &
 #define PMX_TAB_PREFETCH 1
 #endif
 
-template <int N>
-PMX_FN Fe tab_dot_stream(const Fe *z, const uint32_t *tab, const FieldRt &f) {
+template <int N, bool ADD = false>
+PMX_FN Fe tab_dot_stream(const Fe *z, const uint32_t *tab, const FieldRt &f, const Fe *addend = nullptr) {
     constexpr int NG = (N + kTabChunk - 1) / kTabChunk;   // term groups per column
     constexpr int G = N <= 6 ? 1 : 2;                     // groups 0, 1 -> acc[0] (<= 54 + 2 products), the rest -> acc[1]
     static_assert(N <= 9, "two accumulators");
@@ -436,12 +436,12 @@ PMX_FN Fe tab_dot_stream(const Fe *z, const uint32_t *tab, const FieldRt &f) {
 #pragma unroll
             for (int j = 0; j < kN; ++j) acc[(G == 2 && g >= 2) ? 1 : 0] += (uint64_t)z[kTabChunk * g + i].l[j] * buf[c & 1][i * kN + j];
         }
-        if constexpr (g == NG - 1) tab_col_end<G, false>(k, acc, m, out, out, f);
+        if constexpr (g == NG - 1) tab_col_end<G, ADD>(k, acc, m, out, ADD ? *addend : out, f);
         if constexpr (G == 2) PMX_STREAM_FENCE(acc[1]);
         PMX_STREAM_FENCE(acc[0]);
     });
 #pragma unroll
-    for (int k = kN; k < kN + kTabSteps; ++k) tab_col_end<G, false>(k, acc, m, out, out, f);
+    for (int k = kN; k < kN + kTabSteps; ++k) tab_col_end<G, ADD>(k, acc, m, out, ADD ? *addend : out, f);
     return out;
 }
 
@@ -498,6 +498,22 @@ PMX_FN void cols_mul_acc(Cols &t, const Fe &a, const Fe &b) {
 #pragma unroll
         for (int j = 0; j < kN; ++j) t.c[i + j] += (uint64_t)a.l[i] * b.l[j];
     }
+}
+
+// the first term of a row: every column is WRITTEN by its first product instead of being zeroed and added to (the
+// zero-initialised accumulators were being hoisted above the preceding S-box and spilled: eight scratch accesses per
+// sparse round of the t = 9 permute kernel)
+PMX_FN void cols_mul_init(Cols &t, const Fe &a, const Fe &b) {
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+#pragma unroll
+        for (int j = 0; j < kN; ++j) {
+            const int k = i + j;
+            if (i == (k > kN - 1 ? k - (kN - 1) : 0)) t.c[k] = (uint64_t)a.l[i] * b.l[j];
+            else t.c[k] += (uint64_t)a.l[i] * b.l[j];
+        }
+    }
+    t.c[2 * kN - 1] = 0;
 }
 
 // push every column's bits above 29 into the next column

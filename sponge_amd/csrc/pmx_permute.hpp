@@ -238,9 +238,9 @@ template <int T>
 PMX_FN Fe matrix_row(const Fe (&s)[T], const uint32_t *row, const FieldRt &f) {
     static_assert(T <= 9, "one mid-row compression covers up to 9 terms");
     Cols acc;
-    cols_zero(acc);
     static_for<0, T>([&](auto j) {
-        cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
+        if constexpr (j == 0) cols_mul_init(acc, s[j], fe_const(row + j * kFeStride));
+        else cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
         if constexpr (T > kRowFreeTerms && j == kRowMidTerm - 1) cols_compress_range<kRowMidLo, kRowMidHi>(acc);
     });
     return cols_redc(acc, f);
@@ -252,9 +252,9 @@ template <int N>
 PMX_FN Fe matrix_row_add(const Fe *s, const uint32_t *row, const Fe &addend, const FieldRt &f) {
     static_assert(N <= 9, "one mid-row compression covers up to 9 terms");
     Cols acc;
-    cols_zero(acc);
     static_for<0, N>([&](auto j) {
-        cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
+        if constexpr (j == 0) cols_mul_init(acc, s[j], fe_const(row + j * kFeStride));
+        else cols_mul_acc(acc, s[j], fe_const(row + j * kFeStride));
         if constexpr (N > kRowFreeTerms && j == kRowMidTerm - 1) cols_compress_range<kRowMidLo, kRowMidHi>(acc);
     });
     return cols_redc<true>(acc, f, &addend);
@@ -271,7 +271,10 @@ PMX_FN Fe matrix_row_add(const Fe *s, const uint32_t *row, const Fe &addend, con
 #define PMX_HYBRID_TAB_MAX_T 5
 #endif
 #ifndef PMX_HYBRID_TAB_AUTO
-#define PMX_HYBRID_TAB_AUTO 1   // t <= PMX_HYBRID_TAB_MAX_T: 1 = compiler-scheduled tab_dot (t = 4 +1 %, t = 5 +6 % over 0 = the streamed forms)
+#define PMX_HYBRID_TAB_AUTO 0   // t <= PMX_HYBRID_TAB_MAX_T: 0 = the hand-pipelined stream forms, 1 = compiler-scheduled tab_dot.  The
+                                // compiler's own placement of the scalar loads was 1 % (t = 4) and 6 % (t = 5) faster in round 2 and
+                                // collapsed in round 3 (538 SGPR spills in the t = 5 sparse layer - 967 lane moves per 783 multiplies -
+                                // after an unrelated change: 2.6 -> 1.9e8 /s); the streams are 3.5 and 2.6e8 /s whatever else changes
 #endif
 #ifndef PMX_HYBRID_WIDE_NORM
 #define PMX_HYBRID_WIDE_NORM 1   // t >= 6: 1 = normalised dense layers skip the product by ONE (a second rolled row block in the kernel),
@@ -294,7 +297,7 @@ PMX_FN void matrix_rows_rolled_tab(Fe (&s)[T], Scratch &sc, const uint32_t *mat,
         if constexpr (NORM) return tab_dot<T - 1, true>(&s[1], tab, s[0], f);
         else return tab_dot<T, false>(s, tab, s[0], f);
 #else
-        if constexpr (NORM) return tab_dot<T - 1, true>(&s[1], tab, s[0], f);
+        if constexpr (NORM) return tab_dot_stream<T - 1, true>(&s[1], tab, f, &s[0]);
         else return tab_dot_stream<T>(s, tab, f);
 #endif
     };
@@ -361,7 +364,11 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             const Fe z0 = s[0];
             if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
                 PMX_SCHED_FENCE();
+#if PMX_HYBRID_TAB_AUTO
                 s[0] = tab_dot<T - 1, true>(&s[1], spt, z0, f);   // z_0 + v . u
+#else
+                s[0] = tab_dot_stream<T - 1, true>(&s[1], spt, f, &z0);
+#endif
                 PMX_TRACK(0, s[0], f);
 #if PMX_HYBRID_TAB_AUTO
                 static_for<1, T>([&](auto i) {
