@@ -167,15 +167,24 @@ PMX_FN constexpr int sparse_tab_words(int t) { return tab_row_words(t - 1) + (t 
 // one row of a dense layer as a shifted table; NORM: z_0 + sum_{j>=1} z_j c_j (the table holds c_1 ..)
 template <int T, bool NORM>
 PMX_FN Fe row_tab(const Fe (&z)[T], const uint32_t *tab, const FieldRt &f) {
+#if PMX_OPT_TAB_STREAM
+    if constexpr (NORM && T > 1) return tab_dot_stream<T - 1, true>(&z[1], tab, f, &z[0]);
+    else return tab_dot_stream<T>(z, tab, f);
+#else
     if constexpr (NORM && T > 1) return tab_dot<T - 1, true>(&z[1], tab, z[0], f);
     else return tab_dot<T, false>(z, tab, z[0], f);
+#endif
 }
 
 // a sparse layer on shifted tables: s = (z_0, u) in, the next state out
 template <int T>
 PMX_FN void sparse_layer_tab(Fe (&s)[T], const uint32_t *sp, const FieldRt &f) {
     const Fe z0 = s[0];
+#if PMX_OPT_TAB_STREAM
+    if constexpr (T > 1) s[0] = tab_dot_stream<T - 1, true>(&s[1], sp, f, &z0);
+#else
     if constexpr (T > 1) s[0] = tab_dot<T - 1, true>(&s[1], sp, z0, f);   // z_0 + v . u
+#endif
     PMX_TRACK(0, s[0], f);
 #if PMX_OPT_TAB_STREAM
     tab_lanes_stream<T - 1>(z0, sp + tab_row_words(T - 1), &s[1], f);
