@@ -59,7 +59,8 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 #define PMX_REG_TAB_MIN_WAVES 4
 #endif
 #ifndef PMX_REG_DRIVER_MIN_WAVES
-#define PMX_REG_DRIVER_MIN_WAVES 1   // absorb / squeeze kernels of the t = 3 engine: left alone they take 135 / 149 VGPRs (3 waves per SIMD)
+#define PMX_REG_DRIVER_MIN_WAVES 4   // absorb / squeeze kernels of the t = 3 engine: left alone they take 140 / 160 VGPRs (3 waves per SIMD);
+                                     // held to 128: absorb +4 %, squeeze +10 % (round 3, second A/B; the first, on the old schedule, was a wash)
 #endif
 template <int T, int ALPHA, bool OPT, bool TAB = false>
 struct RegEngine {
@@ -289,6 +290,12 @@ struct HybridEngine {
 #ifndef PMX_HYB_DIRECT_IO
 #define PMX_HYB_DIRECT_IO 1
 #endif
+#ifndef PMX_HYB_ROLLED_LOAD_MIN_T
+#define PMX_HYB_ROLLED_LOAD_MIN_T 9
+#endif
+#ifndef PMX_HYB_STAGED_STORE
+#define PMX_HYB_STAGED_STORE 1
+#endif
 #ifndef PMX_HYB_ROLLED_IO
 #define PMX_HYB_ROLLED_IO 0   // rolled element loops for the state I/O of the wide engines (no spill left inside the rounds at t = 9): C3 -0.8 %, t = 6 +1.5 %, t = 7, 8 -1 %
 #endif
@@ -301,15 +308,39 @@ struct HybridEngine {
     __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
         const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
         const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + (gid < n ? gid : 0) * kChunks;
-#if PMX_HYB_ROLLED_IO
-        zero();
+        if constexpr (T >= PMX_HYB_ROLLED_LOAD_MIN_T) {
+            zero();
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        for (uint32_t i = 0; i < (uint32_t)T; ++i) set(i, from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])));
-#else
-        static_for<0, T>([&](auto i) { s[i] = from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])); });
-#endif
+            for (uint32_t i = 0; i < (uint32_t)T; ++i) set(i, from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])));
+        } else {
+            static_for<0, T>([&](auto i) { s[i] = from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])); });
+        }
     }
 
+#if PMX_HYB_STAGED_STORE
+    // the store goes through the wave's LDS region so that every 16-byte write instruction covers 1 KiB of contiguous memory:
+    // written lane by lane (stride 32 T bytes) the partial lines are not all merged before they leave the L2 - 1.57 x the
+    // bytes at t = 9 (WRITE_SIZE, profiles/r03)
+    __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {
+        const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
+        const size_t valid = n > first ? (n - first < (size_t)64 ? n - first : (size_t)64) : 0;
+        uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * kChunks;
+        const uint32_t n_chunks = (uint32_t)valid * kChunks;
+        __syncthreads();
+        static_for<0, T>([&](auto i) {
+            const Abi a = to_abi(s[i]);
+            region[lane * kChunks + 2 * i] = abi_lo(a);
+            region[lane * kChunks + 2 * i + 1] = abi_hi(a);
+        });
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            const uint32_t q = lane + k * 64;
+            if (q < n_chunks) g[q] = region[q];
+        }
+        __syncthreads();
+    }
+#else
     __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {
         const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
         if (gid < n) {
@@ -330,6 +361,7 @@ struct HybridEngine {
 #endif
         }
     }
+#endif
 #else
     // every wave stages its own 64 contiguous states through its own region
     __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
