@@ -9,7 +9,9 @@
  * Element representation (everywhere in this ABI): a field element is 4 little-endian uint64_t limbs
  * holding the fully reduced Montgomery residue  x * 2^256 mod p  -- byte-identical to ark-ff's
  * Fp<MontBackend<_,4>,4>, so a Rust &[Fr] / Vec<Fr> is passed as-is (src/poseidon/mod.rs:57 `state`).
- * "Bit-exact" means limb-for-limb equality of these residues.
+ * "Bit-exact" means limb-for-limb equality of these residues.  Inputs must be fully reduced, as ark-ff keeps them
+ * (an unreduced state or message element is still processed modulo p, but an output that depends on it may come back
+ * unreduced; config constants are checked, batch data is not).
  *
  * State order inside one sponge state is the reference's: capacity elements first, then the rate
  * elements (src/poseidon/mod.rs:128,143,159).
