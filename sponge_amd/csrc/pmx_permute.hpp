@@ -390,9 +390,9 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
 #endif
             } else {
                 const uint32_t *sp = tb.sparse + (size_t)layer * (2 * T - 1) * kFeStride;
-                if constexpr (PMX_HYBRID_WIDE_ROW0_TAB && T - 1 <= 6) {
+                if constexpr (PMX_HYBRID_WIDE_ROW0_TAB) {
                     PMX_SCHED_FENCE();
-                    s[0] = tab_dot<T - 1, true>(&s[1], spt, z0, f);
+                    s[0] = tab_dot_stream<T - 1, true>(&s[1], spt, f, &z0);
                     PMX_SCHED_FENCE();
                 } else {
                     s[0] = matrix_row_add<T - 1>(&s[1], sp + kFeStride, z0, f);   // z_0 + v . u
