@@ -86,8 +86,8 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a third of a second of kernel time at C2)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--total-log2", type=int, default=None, help="log2 of the units (states / leaves / rows) over ALL ranks")
     ap.add_argument("--total-units", type=int, default=None, help="units over ALL ranks, any number (ragged shards)")
