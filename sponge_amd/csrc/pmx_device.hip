@@ -290,8 +290,9 @@ struct HybridEngine {
 #ifndef PMX_HYB_DIRECT_IO
 #define PMX_HYB_DIRECT_IO 1
 #endif
-#ifndef PMX_HYB_ROLLED_LOAD_MIN_T
-#define PMX_HYB_ROLLED_LOAD_MIN_T 9
+#ifndef PMX_HYB_ROLLED_LOAD
+#define PMX_HYB_ROLLED_LOAD(T) ((T) == 6 || (T) >= 9)   // widths whose permute kernel otherwise keeps spills inside the rounds (t = 6 at three
+                                                        // waves per SIMD: 76 -> 12 bytes of scratch; t = 9: 76 -> 0); t = 7, 8 have none and lose 1 %
 #endif
 #ifndef PMX_HYB_STAGED_STORE
 #define PMX_HYB_STAGED_STORE 1
@@ -308,7 +309,7 @@ struct HybridEngine {
     __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
         const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
         const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + (gid < n ? gid : 0) * kChunks;
-        if constexpr (T >= PMX_HYB_ROLLED_LOAD_MIN_T) {
+        if constexpr (PMX_HYB_ROLLED_LOAD(T)) {
             zero();
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (uint32_t i = 0; i < (uint32_t)T; ++i) set(i, from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])));
@@ -331,6 +332,7 @@ struct HybridEngine {
             const Abi a = to_abi(s[i]);
             region[lane * kChunks + 2 * i] = abi_lo(a);
             region[lane * kChunks + 2 * i + 1] = abi_hi(a);
+            PMX_SCHED_FENCE();   // one conversion at a time: interleaved, the T exact reductions are the widest point of the kernel
         });
         __syncthreads();
 #pragma unroll
