@@ -391,6 +391,7 @@ def main():
             mads -= (t - out_len) * last_row / perms_per_row
         mad_rate = mads * per_gpu_units / kernel_s
         traffic, traffic_src = load_traffic(args.workload, per_gpu_units)
+        valu_issue = load_valu_issue(args.workload, per_gpu_units, kernel_s, peak.compute_units, mads)
         out = {
             "metric": "Poseidon permutations/sec (%s, t=%d)" % ({"bls12_381_fr": "BLS12-381 Fr", "bn254_fr": "BN254 Fr"}[field_name], t),
             "value": value, "unit": "permutations/s",
@@ -420,6 +421,7 @@ def main():
                          "peak_by_carry_destination": {"vcc": peak.lane_mads_per_s_vcc, "sgpr_pair": peak.lane_mads_per_s_sgpr}, "shader_clock_hz": peak.shader_clock_hz,
                          "theoretical_peak": peak.theoretical_lane_mads_per_s, "compute_units": peak.compute_units,
                          "frac_of_theoretical": mad_rate / peak.theoretical_lane_mads_per_s if peak.theoretical_lane_mads_per_s else None},
+            "valu_issue": valu_issue,
             "gather_ms": 1e3 * (dev_s - steps_s) if world > 1 else None,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -552,6 +554,32 @@ def load_traffic(workload, per_gpu_units):
         return rec["bytes_per_launch"], "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
     except Exception:
         return None, None
+
+
+def load_valu_issue(workload, per_gpu_units, kernel_s, compute_units, mads):
+    """The binding resource, one level below `int_valu`: a SIMD of this part takes ONE VALU instruction per ~4 shader clocks
+    from any stream that holds multiplies, whatever the instruction is and whichever wave it comes from
+    (tools/issue_model_microbench.hip -> profiles/r03/f_issue_model_microbench.txt), so a kernel's floor is its VALU
+    instruction count, not its multiply count.  The count per permutation comes from the committed SQ_INSTS_VALU pass of
+    this command (profiles/valu_instructions.json, tools/valu_slots.py); the time per instruction is this run's."""
+    path = os.path.join(ROOT, "profiles", "valu_instructions.json")
+    try:
+        rec = json.load(open(path))
+        w = rec[workload]
+        if abs(w["units_per_launch"] - per_gpu_units) > 1 or not compute_units:
+            return None
+        per_unit = w["valu_instructions_per_wave"]   # one state per lane: what every lane executes
+        simds = compute_units * 4
+        ns = kernel_s * 1e9 * simds / (per_unit * per_gpu_units / 64.0)
+        floor = rec["floor_ns_per_instruction"]
+        return {"bound": "VALU issue slots (one instruction per SIMD and ~4 clocks in a stream with multiplies)",
+                "valu_instructions_per_permutation": per_unit, "multiply_share": mads / per_unit,
+                "ns_per_instruction_and_simd": ns, "floor_ns_per_instruction_and_simd": floor,
+                "frac": floor[str(w["waves_per_simd"])] / ns, "waves_per_simd": w["waves_per_simd"],
+                "source": "profiles/valu_instructions.json (rocprofv3 --pmc SQ_INSTS_VALU pass of this command; floors: "
+                          "tools/issue_model_microbench.hip, the '12 mad, then 4 and' stream at that many waves per SIMD)"}
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_r03.sh <tag> [stages]
-# stages: any of  test smoke bench prof pmc sponge levels lone paths   (default: "test smoke bench")
+# stages: any of  test smoke bench prof pmc slots sponge levels lone paths   (default: "test smoke bench")
 TAG=${1:-r03a}
 STAGES=${2:-"test smoke bench"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -44,6 +44,13 @@ if has sponge; then
   timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sponge -- python3 $R/tools/sponge_rate.py > $OUT/pmc_sponge.log 2>&1
   timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sponge_mixed -- python3 $R/tools/sponge_rate.py --mixed > $OUT/pmc_sponge_mixed.log 2>&1
 fi
+if has slots; then
+  # VALU issue-slot accounting of the dominant kernels: instruction counts and SQ cycle shares, in two counter passes
+  for w in c2 c3; do
+    timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/slots_a_$w -- python3 $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/slots_a_$w.log 2>&1
+    timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/slots_b_$w -- python3 $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/slots_b_$w.log 2>&1
+  done
+fi
 if has pmc; then
   for w in c2 c3; do
     timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$w -- python3 $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_fetch_$w.log 2>&1
@@ -58,6 +65,11 @@ if has pmc; then
   python tools/extract_traffic.py $OUT/pmc_fetch_c3 $OUT/pmc_write_c3 permute_kernel c3 $OUT/hbm_traffic.json 1 262144 >> $OUT/traffic.log 2>&1
   python tools/extract_traffic.py $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 compress c5 $OUT/hbm_traffic.json 21 2097151 >> $OUT/traffic.log 2>&1
   cat $OUT/traffic.log
+fi
+if has slots; then
+  ( python tools/valu_slots.py $OUT/slots_a_c2 permute_kernel 1048576 1 40077; python tools/valu_slots.py $OUT/slots_b_c2 permute_kernel 1048576 1 40077
+    python tools/valu_slots.py $OUT/slots_a_c3 permute_kernel 262144 1 198504; python tools/valu_slots.py $OUT/slots_b_c3 permute_kernel 262144 1 198504 ) > $OUT/valu_slots.txt 2>&1
+  cat $OUT/valu_slots.txt
 fi
 if has sponge; then
   python tools/sponge_pmc_summary.py $OUT > $OUT/sponge_summary.txt 2>&1; cat $OUT/sponge_summary.txt
