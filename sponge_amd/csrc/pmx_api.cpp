@@ -124,6 +124,8 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.tab_full_offset = (uint32_t)pp.tab_full_offset;
     d.tab_sparse_offset = (uint32_t)pp.tab_sparse_offset;
     d.tab_bdense_offset = (uint32_t)pp.tab_bdense_offset;
+    d.mfma_offset = (uint32_t)pp.mfma_offset;
+    d.mfma_dense = pp.mfma_dense ? 1u : 0u;
     d.io_offset = (uint32_t)pp.io_offset;
     d.has_opt = pp.has_opt ? 1u : 0u;
     {

@@ -228,9 +228,12 @@ struct RegEngine {
 #ifndef PMX_HYB_4WAVE_MAX_T
 #define PMX_HYB_4WAVE_MAX_T 4   // t = 4 (133 VGPRs when left alone) held to 128: four waves per SIMD, +3.8 % (round 3 A/B)
 #endif
-template <int T, int ALPHA>
+// MFMA: the dense layers run on the matrix cores (pmx_mfma.hpp); eight waves per workgroup share one LDS tile of the layer's
+// table rows - the wave-uniform kernels only (permute, hash, compress: inside the per-lane loops of absorb / squeeze not every
+// lane is active, and the lane exchange of that path needs both lanes of a pair).
+template <int T, int ALPHA, bool MFMA = false>
 struct HybridEngine {
-    static constexpr int kWaves = PMX_HYB_WAVES;
+    static constexpr int kWaves = MFMA ? 8 : PMX_HYB_WAVES;
     static constexpr int kThreads = 64 * kWaves;
     // waves per SIMD the register allocation must allow (4: <= 128 VGPRs, 3: <= 168, 2: <= 256)
     static constexpr int kMinWaves = T <= PMX_HYB_4WAVE_MAX_T ? 4 : T <= PMX_HYB_3WAVE_MAX_T ? 3 : 2;
@@ -264,7 +267,8 @@ struct HybridEngine {
     uint4 *region;    // this wave's LDS region
     uint32_t lane;
 
-    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes; }
+    static constexpr size_t kTileBytes = MFMA ? (size_t)mfma_k_steps(T) * 1024 : 0;   // one output row's table, behind the waves' regions
+    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes + kTileBytes; }
 
     __device__ __forceinline__ HybridEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
         f.io = consts + d.io_offset;
@@ -276,6 +280,7 @@ struct HybridEngine {
         tb.tab_full = consts + d.tab_full_offset;
         tb.tab_sparse = consts + d.tab_sparse_offset;
         tb.tab_bdense = consts + d.tab_bdense_offset;
+        tb.mfma = consts + d.mfma_offset;
         lane = threadIdx.x & 63;
         region = pmx_lds + (threadIdx.x >> 6) * (kWaveBytes / 16);
         sc.base = reinterpret_cast<uint32_t *>(region) + lane;
@@ -427,7 +432,9 @@ struct HybridEngine {
         });
     }
 
-    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T) { permute_hybrid<T, ALPHA>(s, sc, tb, c, one, f, want_lo, want_hi); }
+    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T) {
+        permute_hybrid<T, ALPHA, Scratch, MFMA ? kThreads : 0>(s, sc, tb, c, one, f, want_lo, want_hi, pmx_lds + kWaves * (kWaveBytes / 16));
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1005,19 +1012,27 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
 template <class Engine>
 struct Launch {
     static int grid(size_t n) { return (int)((n + Engine::kThreads - 1) / Engine::kThreads); }
+    // more than 64 KiB of dynamic LDS has to be asked for per kernel (and device)
+    template <class K>
+    static void allow_lds(K kernel, size_t bytes) {
+        if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    }
 
     static hipError_t permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
+        allow_lds(permute_kernel<Engine>, Engine::lds_bytes(c, t));
         hipLaunchKernelGGL(permute_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
                            c.consts, states, n);
         return hipGetLastError();
     }
     static hipError_t hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out,
                            size_t out_len, size_t n, hipStream_t st) {
+        allow_lds(hash_kernel<Engine>, Engine::lds_bytes(c, t));
         hipLaunchKernelGGL(hash_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
                            c.consts, in, in_len, out, out_len, n);
         return hipGetLastError();
     }
     static hipError_t compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
+        allow_lds(compress_kernel<Engine>, Engine::lds_bytes(c, t));
         hipLaunchKernelGGL(compress_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
                            c.consts, in, out, n);
         return hipGetLastError();
@@ -1056,14 +1071,30 @@ struct Launch {
         default: return hipErrorInvalidValue;                              \
     }
 
+// the wave-uniform kernels of the widest state: dense layers on the matrix cores when the config has their tables
+#if PMX_TU == 1 && PMX_MFMA_MAX_T >= 9
+#define PMX_HYB_MFMA(CALL)                                                                              \
+    do {                                                                                                \
+        if (t == 9 && c.mfma_dense && lds_fits_engine<HybridEngine<9, PMX_HYB_ALPHA, true>>(c, t))      \
+            return Launch<HybridEngine<9, PMX_HYB_ALPHA, true>>::CALL;                                  \
+    } while (0)
+#else
+#define PMX_HYB_MFMA(CALL) do { } while (0)
+#endif
+template <class Engine>
+static bool lds_fits_engine(const DevConfig &c, uint32_t t) { return Engine::lds_bytes(c, t) <= (size_t)c.max_lds_bytes; }
+
 hipError_t PMX_HYB_NAME(permute)(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
+    PMX_HYB_MFMA(permute(c, t, states, n, st));
     PMX_HYB_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t PMX_HYB_NAME(hash)(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                               size_t n, hipStream_t st) {
+    PMX_HYB_MFMA(hash(c, t, in, in_len, out, out_len, n, st));
     PMX_HYB_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
 hipError_t PMX_HYB_NAME(compress)(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
+    PMX_HYB_MFMA(compress(c, t, in, out, n, st));
     PMX_HYB_DISPATCH(compress(c, t, in, out, n, st));
 }
 hipError_t PMX_HYB_NAME(absorb)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,

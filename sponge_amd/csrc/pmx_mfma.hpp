@@ -1,0 +1,160 @@
+// Dense layers of a wide state on the matrix cores (gfx950: v_mfma_i32_32x32x32_i8).
+//
+// A dense layer multiplies the state by a matrix of CONSTANTS: out_i = sum_j c_ij z_j.  On the VALU that is t rows of
+// 81 t + 81 limb products (pmx_permute.hpp: matrix_rows_rolled); here it is an int8 GEMM whose N dimension is the 64 states
+// of the wave (one per lane), whose K dimension is the bytes of the state and whose M dimension is the bytes of the result:
+//
+//   * every element z_j (nine 29-bit limbs, value < 2^261 < 2^264) is re-cut into 33 bytes u_{j,b}; an element takes 36
+//     bytes of K (9 words, the top three bytes zero), the state t * 36, in k-steps of 32;
+//   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 58) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
+//     (pmx_prepare.hpp: put_mfma_layer; the modulus' top byte must be <= 126 for 32 of them to do), laid out as the A
+//     operand: 16 bytes per lane and k-step, lane l = row e (l & 31) and half (l >> 5) of the k-step;
+//   * MFMA bytes are signed, state bytes are not: they enter as u - 128 (one v_xor per register) and the host adds the
+//     constant 128 * sum_k Y_k back (per output row, as eight 64-bit word sums);
+//   * lanes 32-63 of an MFMA feed the SECOND half of every k-step for the columns (states) of lanes 0-31, not states of
+//     their own.  So a k-step is two MFMAs - states 0-31 and states 32-63 of the wave - and before them each lane hands the
+//     half of its byte registers its partner lane (+-32) must feed to that partner (v_permlane32_swap, once per layer);
+//     afterwards the 32 sums of a state sit half on its own lane and half on the partner: sixteen more swaps per row;
+//   * the 32 sums S_e (|S_e| < 2^25) are the integer V = sum_e S_e 2^(8e) = sum u Y < 2^272: eight 64-bit word sums, a
+//     carry pass, a re-cut into ten 29-bit limbs and two Montgomery steps (division by 2^58, which the table carries)
+//     give the row as a norm element below (1 + 2^-40) p - 20 multiplies instead of 810.
+//
+// The 11 KiB of table one row of t = 9 needs are staged in LDS once per WORKGROUP (read per wave from L2 they are 101 KiB
+// per wave and layer and the L2 -> L1 path sets the time), which is why the engines that use this run eight waves per
+// workgroup.  tools/mfma_dense_proto.{py,hip} is the stand-alone form of the same code with its check against Python
+// integers; profiles/r03/g_mfma_dense_proto.txt its measurements.
+#pragma once
+
+#include "pmx_field.hpp"
+
+namespace pmx {
+
+// Widths whose dense layers go to the matrix cores.  Below 7 a row is cheaper on the VALU (81 t + 81 multiplies against ~250
+// instructions of re-cutting and carrying per row); 9 is the width that has an engine for it so far (pmx_device.hip).
+#ifndef PMX_MFMA_MIN_T
+#define PMX_MFMA_MIN_T 9
+#endif
+#ifndef PMX_MFMA_MAX_T
+#define PMX_MFMA_MAX_T 9
+#endif
+
+constexpr int kMfmaElemBytes = 36;   // K bytes per element (33 used)
+PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32; }
+PMX_FN constexpr int mfma_row_words(int t) { return mfma_k_steps(t) * 64 * 4; }             // A operand of one output row
+PMX_FN constexpr int mfma_layer_words(int t) { return t * mfma_row_words(t) + t * 16; }     // t rows, then t x 8 int64 corrections
+
+#if defined(__HIPCC__)   // (tests/hostcheck compiles the headers with g++: no matrix cores there)
+
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+
+// lanes 32-63 of x <-> lanes 0-31 of y
+__device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+
+// Rows [lo, hi) of the layer whose tables start at `layer` (global memory; mfma_layer_words(T) words); the other rows of s
+// come back unspecified, like matrix_rows_rolled.  s norm.  `tile`: mfma_k_steps(T) KiB of LDS shared by the workgroup's
+// THREADS threads, all of which must arrive here together (two barriers per row) with every lane active.
+template <int T, int THREADS, class Scratch>
+__device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f, uint32_t lo,
+                                                 uint32_t hi) {
+    constexpr int NQ = mfma_k_steps(T), NW = 8 * NQ;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t W[NW];
+    static_for<0, T>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+#pragma unroll
+        for (int w = 0; w < 9; ++w) {
+            const int bit = 32 * w, li = bit / kW, sh = bit % kW;
+            uint64_t v = (uint64_t)s[j].l[li] >> sh;
+            if (li + 1 < kN) v |= (uint64_t)s[j].l[li + 1] << (kW - sh);
+            if (li + 2 < kN && 2 * kW - sh < 32) v |= (uint64_t)s[j].l[li + 2] << (2 * kW - sh);
+            W[9 * j + w] = (uint32_t)v ^ 0x80808080u;
+        }
+    });
+#pragma unroll
+    for (int w = 9 * T; w < NW; ++w) W[w] = 0x80808080u;   // (their table bytes are zero)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lane32_swap(W[8 * q + u], W[8 * q + 4 + u]);
+    }
+    const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(T));
+    Fe last = s[T - 1];
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (uint32_t i = lo; i < hi; ++i) {
+        __syncthreads();   // the previous row's readers are done with the tile
+        {
+            const mfma_v4i *src = reinterpret_cast<const mfma_v4i *>(layer) + (size_t)i * NQ * 64;
+            for (uint32_t e = threadIdx.x; e < (uint32_t)NQ * 64; e += THREADS) tile[e] = src[e];
+        }
+        __syncthreads();
+        mfma_v16i d1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d2 = d1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const mfma_v4i a = tile[q * 64 + lane];
+            const mfma_v4i b1 = {(int)W[8 * q + 0], (int)W[8 * q + 1], (int)W[8 * q + 2], (int)W[8 * q + 3]};
+            const mfma_v4i b2 = {(int)W[8 * q + 4], (int)W[8 * q + 5], (int)W[8 * q + 6], (int)W[8 * q + 7]};
+            d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, d1, 0, 0, 0);   // states 0-31 of the wave
+            d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, d2, 0, 0, 0);   // states 32-63
+        }
+        // register v of d1 / d2 holds row 8 (v / 4) + 4 (lane / 32) + v % 4 of the column lane % 32: after the exchange
+        // D1[4g + r] is row 8g + r and D2[4g + r] row 8g + 4 + r of THIS lane's state
+        uint32_t D1[16], D2[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            D1[v] = (uint32_t)d1[v];
+            D2[v] = (uint32_t)d2[v];
+            lane32_swap(D1[v], D2[v]);
+        }
+        uint32_t wd[9];
+        long long c = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {   // word w = rows 4w .. 4w + 3
+            const uint32_t *d = (w & 1) ? D2 : D1;
+            const int b = 4 * (w >> 1);
+            const long long t = (long long)(int)d[b] + ((long long)(int)d[b + 1] << 8) + ((long long)(int)d[b + 2] << 16) +
+                                ((long long)(int)d[b + 3] << 24) + corr[i * 8 + w] + c;
+            wd[w] = (uint32_t)t;
+            c = t >> 32;
+        }
+        wd[8] = (uint32_t)c;   // V >= 0: the top carry is not negative
+        uint32_t L[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int bit = kW * k, wi = bit / 32, sh = bit % 32;
+            uint64_t pair = wd[wi];
+            if (wi + 1 < 9) pair |= (uint64_t)wd[wi + 1] << 32;
+            L[k] = (uint32_t)(pair >> sh) & kMask;
+        }
+        uint64_t acc = L[0];
+        const uint32_t m0 = ((uint32_t)acc * f.pinv) & kMask;
+        acc += (uint64_t)m0 * f.p[0];
+        acc >>= kW;
+        acc += L[1];
+        acc += (uint64_t)m0 * f.p[1];
+        const uint32_t m1 = ((uint32_t)acc * f.pinv) & kMask;
+        acc += (uint64_t)m1 * f.p[0];
+        acc >>= kW;
+        Fe row;
+#pragma unroll
+        for (int k = 2; k <= 10; ++k) {
+            if (k < 10) acc += L[k];
+            if (k <= 8) acc += (uint64_t)m0 * f.p[k];
+            if (k - 1 <= 8) acc += (uint64_t)m1 * f.p[k - 1];
+            row.l[k - 2] = k < 10 ? ((uint32_t)acc & kMask) : (uint32_t)acc;
+            acc >>= kW;
+        }
+        if (i + 1 < (uint32_t)T) sc.set(i, row);
+        else last = row;
+    }
+    static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
+    s[T - 1] = last;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace pmx

@@ -6,6 +6,7 @@
 // rounds [0, RF/2) and [RF/2+RP, RF+RP) full, the RP in between partial; MDS also after the last round.
 #pragma once
 #include "pmx_field.hpp"
+#include "pmx_mfma.hpp"
 
 namespace pmx {
 
@@ -65,6 +66,7 @@ PMX_FN void permute_dense(Fe (&s)[T], const uint32_t *ark, const uint32_t *mds, 
 struct OptTables {
     const uint32_t *ark, *mds, *full, *sparse, *bdense;   // elements (mds: the reference matrix, dense schedule only)
     const uint32_t *tab_full, *tab_sparse, *tab_bdense;   // shifted tables (pmx_prepare.hpp layout)
+    const uint32_t *mfma;                                 // int8 tables of the dense layers (pmx_mfma.hpp), or null
 };
 
 PMX_FN uint32_t full_ordinal(uint32_t r, const Rounds &c) { return r < c.half_full ? r : r - c.partial_rounds - 1; }
@@ -339,9 +341,11 @@ PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, con
 // a linear stage chosen by the round - sparse layer, normalised dense layer, the last round's dense layer - so that every
 // block of code exists once (the sparse layer is used by the entrance round and by the partial rounds alike; two inlined
 // copies would not fit the instruction cache at t = 9).
-template <int T, int ALPHA, class Scratch>
+// MFMA_THREADS > 0: the dense layers run on the matrix cores (pmx_mfma.hpp) - the workgroup has that many threads, all of them
+// here together, and `tile` is its shared LDS tile.
+template <int T, int ALPHA, class Scratch, int MFMA_THREADS = 0>
 PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
-                           const FieldRt &f, uint32_t want_lo = 0, uint32_t want_hi = T) {
+                           const FieldRt &f, uint32_t want_lo = 0, uint32_t want_hi = T, void *tile = nullptr) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
     uint32_t guard = 0;   // keeps table_touch's loads alive (see the end of the function)
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
@@ -417,6 +421,13 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             // except the last round's, whose output is the permutation's
             const bool last = r + 1 == c.total_rounds;
             const uint32_t o = full ? full_ordinal(r, c) : 0;
+#if defined(__HIPCC__)
+            if constexpr (MFMA_THREADS > 0) {
+                const uint32_t n_full = c.total_rounds - c.partial_rounds - 1;   // the layer after the last partial round follows the full rounds' own
+                const uint32_t *lay = tb.mfma + (size_t)(full ? o : n_full) * mfma_layer_words(T);
+                matrix_rows_mfma<T, MFMA_THREADS>(s, sc, lay, static_cast<mfma_v4i *>(tile), f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
+            } else
+#endif
             if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
                 const uint32_t *mat = full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense;
                 if (last) matrix_rows_rolled_tab<T, false>(s, sc, mat, f, want_lo, want_hi);

@@ -55,8 +55,50 @@ struct Prepared {
     //                                       constants w of kTabOneWords)
     //   tab_bdense_offset          bdense   [t] rows of R words (normalised)
     size_t tab_full_offset, tab_sparse_offset, tab_bdense_offset;
+    //   -- only when mfma_dense: the dense layers as int8 GEMM operands (pmx_mfma.hpp); RF - 1 layers of `full`, then bdense --
+    //   mfma_offset                [RF][mfma_layer_words(t)]
+    size_t mfma_offset;
+    bool mfma_dense;
     size_t io_offset;   // kIoWords words behind FieldRt::io
 };
+
+// One dense layer as the A operands of pmx_mfma.hpp: `rows` = t rows of t constants (ABI Montgomery residues, row-major).
+// Row i, k-step q, lane l: 16 bytes = bytes e = l & 31 of the residues  Y = c_ij * 2^(8 b + 58) mod p  for the 16 positions
+// k = 32 q + 16 (l >> 5) + 0..15 of the state's byte string (k = 36 j + b), as balanced signed bytes; then per row the eight
+// word sums of 128 * sum_k Y_k (the state's bytes enter as u - 128).
+inline void put_mfma_layer(const HostField &hf, const U256 *rows, size_t t, uint32_t *dst) {
+    const size_t nq = (size_t)mfma_k_steps((int)t), row_words = (size_t)mfma_row_words((int)t);
+    int8_t *bytes = reinterpret_cast<int8_t *>(dst);
+    long long *corr = reinterpret_cast<long long *>(dst + t * row_words);
+    for (size_t i = 0; i < t; ++i) {
+        long long colsum[32] = {0};
+        for (size_t j = 0; j < t; ++j) {
+            U256 y = times_pow2(hf, hf.from_mont(rows[i * t + j]), 58);
+            for (size_t b = 0; b < 33; ++b) {
+                // balanced bytes of y: digit e in [-128, 127], carry into the next
+                unsigned carry = 0;
+                const size_t k = j * kMfmaElemBytes + b, q = k / 32, r = k % 32, h = r / 16, byte = r % 16;
+                for (size_t e = 0; e < 32; ++e) {
+                    int dgt = (int)((y.l[e / 8] >> (8 * (e % 8))) & 0xff) + (int)carry;
+                    carry = 0;
+                    if (dgt >= 128) {
+                        dgt -= 256;
+                        carry = 1;
+                    }
+                    bytes[(((i * nq + q) * 64 + 32 * h + e) * 16) + byte] = (int8_t)dgt;
+                    colsum[e] += dgt;
+                }
+                // (carry out of byte 31 cannot happen: the caller admits only moduli whose top byte is <= 126)
+                y = times_pow2(hf, y, 8);
+            }
+        }
+        for (size_t w = 0; w < 8; ++w) {
+            long long v = 0;
+            for (size_t tt = 0; tt < 4; ++tt) v += (128 * colsum[4 * w + tt]) * (1ll << (8 * tt));
+            corr[i * 8 + w] = v;
+        }
+    }
+}
 
 // shifted table of a ROW of n constants (given as ABI Montgomery residues C_i * 2^256) in the chunked layout of
 // pmx_field.hpp (tab_index): limb k of C_i * 2^(29 j + 58) mod p; tab_row_words(n) words, padding left 0
@@ -400,6 +442,16 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
             put_shifted_row(hf, &src_sparse[r * src_per_round + 1], t - 1, dst);   // row 0 without its first entry (ONE: the addend)
             for (size_t l = 0; l + 1 < t; ++l) put_shifted_row(hf, &src_sparse[r * src_per_round + t + l], 1, dst + row0 + l * kTabOneWords);
         }
+    }
+    // dense layers of the widest states as int8 GEMM operands
+    while (out.consts.size() % 4) out.consts.push_back(0u);   // 16-byte operands
+    out.mfma_offset = out.consts.size();
+    out.mfma_dense = out.has_opt && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T && n_full >= 1 && (hf.p.l[3] >> 56) <= 126;
+    if (out.mfma_dense) {
+        const size_t lw = (size_t)mfma_layer_words((int)t);
+        out.consts.resize(out.mfma_offset + (n_full + 1) * lw, 0u);
+        for (size_t o = 0; o < n_full; ++o) put_mfma_layer(hf, &src_full[o * t * t], t, &out.consts[out.mfma_offset + o * lw]);
+        put_mfma_layer(hf, src_bdense.data(), t, &out.consts[out.mfma_offset + n_full * lw]);
     }
     FieldRt &f = out.f;
     f.unit = 1;
