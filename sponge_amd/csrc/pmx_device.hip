@@ -231,9 +231,18 @@ struct RegEngine {
 // MFMA: the dense layers run on the matrix cores (pmx_mfma.hpp); eight waves per workgroup share one LDS tile of the layer's
 // table rows - the wave-uniform kernels only (permute, hash, compress: inside the per-lane loops of absorb / squeeze not every
 // lane is active, and the lane exchange of that path needs both lanes of a pair).
+#ifndef PMX_MFMA_WAVES
+#define PMX_MFMA_WAVES 4        // waves per workgroup of the matrix-core engines, and
+#endif
+#ifndef PMX_MFMA_TILE_STEPS
+#define PMX_MFMA_TILE_STEPS 6   // k-steps (KiB) of a row's table in LDS at a time.  At t = 9 (8 x 18 KiB of scratch per CU) that
+                                // is two workgroups of four waves per CU with a 6 KiB tile each - their phases drift apart, so one's
+                                // MFMAs run under the other's carries - or one of eight waves with a whole row (11 KiB), whose waves
+                                // all multiply and all carry at the same time
+#endif
 template <int T, int ALPHA, bool MFMA = false>
 struct HybridEngine {
-    static constexpr int kWaves = MFMA ? 8 : PMX_HYB_WAVES;
+    static constexpr int kWaves = MFMA ? PMX_MFMA_WAVES : PMX_HYB_WAVES;
     static constexpr int kThreads = 64 * kWaves;
     // waves per SIMD the register allocation must allow (4: <= 128 VGPRs, 3: <= 168, 2: <= 256)
     static constexpr int kMinWaves = T <= PMX_HYB_4WAVE_MAX_T ? 4 : T <= PMX_HYB_3WAVE_MAX_T ? 3 : 2;
@@ -267,7 +276,9 @@ struct HybridEngine {
     uint4 *region;    // this wave's LDS region
     uint32_t lane;
 
-    static constexpr size_t kTileBytes = MFMA ? (size_t)mfma_k_steps(T) * 1024 : 0;   // one output row's table, behind the waves' regions
+    // the stage of a row's table the workgroup shares, behind the waves' regions
+    static constexpr int kTileSteps = mfma_k_steps(T) < PMX_MFMA_TILE_STEPS ? mfma_k_steps(T) : PMX_MFMA_TILE_STEPS;
+    static constexpr size_t kTileBytes = MFMA ? (size_t)kTileSteps * 1024 : 0;
     static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes + kTileBytes; }
 
     __device__ __forceinline__ HybridEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
@@ -433,7 +444,7 @@ struct HybridEngine {
     }
 
     __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T) {
-        permute_hybrid<T, ALPHA, Scratch, MFMA ? kThreads : 0>(s, sc, tb, c, one, f, want_lo, want_hi, pmx_lds + kWaves * (kWaveBytes / 16));
+        permute_hybrid<T, ALPHA, Scratch, MFMA ? kThreads : 0, kTileSteps>(s, sc, tb, c, one, f, want_lo, want_hi, pmx_lds + kWaves * (kWaveBytes / 16));
     }
 };
 

@@ -56,12 +56,13 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
 }
 
 // Rows [lo, hi) of the layer whose tables start at `layer` (global memory; mfma_layer_words(T) words); the other rows of s
-// come back unspecified, like matrix_rows_rolled.  s norm.  `tile`: mfma_k_steps(T) KiB of LDS shared by the workgroup's
-// THREADS threads, all of which must arrive here together (two barriers per row) with every lane active.
-template <int T, int THREADS, class Scratch>
+// come back unspecified, like matrix_rows_rolled.  s norm.  `tile`: TILE_STEPS KiB of LDS shared by the workgroup's THREADS
+// threads, all of which must arrive here together (two barriers per stage of a row) with every lane active.
+template <int T, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f, uint32_t lo,
                                                  uint32_t hi) {
     constexpr int NQ = mfma_k_steps(T), NW = 8 * NQ;
+    constexpr int NS = (NQ + TILE_STEPS - 1) / TILE_STEPS;   // the tile holds TILE_STEPS k-steps: a row passes through it in NS stages
     const uint32_t lane = threadIdx.x & 63;
     uint32_t W[NW];
     static_for<0, T>([&](auto jj) {
@@ -84,23 +85,45 @@ __device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const 
     }
     const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(T));
     Fe last = s[T - 1];
+    // this thread's share of a stage of the table: fetched from global memory one stage ahead, so that the fetch runs behind
+    // the multiplications of the stage before instead of between the two barriers
+    constexpr int kPer = (TILE_STEPS * 64 + THREADS - 1) / THREADS;
+    mfma_v4i pre[kPer];
+    auto fetch = [&](uint32_t row, int stage) {
+        const mfma_v4i *src = reinterpret_cast<const mfma_v4i *>(layer) + ((size_t)row * NQ + (size_t)stage * TILE_STEPS) * 64;
+        const uint32_t count = (uint32_t)((stage == NS - 1 ? NQ - stage * TILE_STEPS : TILE_STEPS) * 64);
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const uint32_t e = threadIdx.x + q * THREADS;
+            if (e < count) pre[q] = src[e];
+        }
+    };
+    if (lo < hi) fetch(lo, 0);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (uint32_t i = lo; i < hi; ++i) {
-        __syncthreads();   // the previous row's readers are done with the tile
-        {
-            const mfma_v4i *src = reinterpret_cast<const mfma_v4i *>(layer) + (size_t)i * NQ * 64;
-            for (uint32_t e = threadIdx.x; e < (uint32_t)NQ * 64; e += THREADS) tile[e] = src[e];
-        }
-        __syncthreads();
         mfma_v16i d1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d2 = d1;
+        static_for<0, NS>([&](auto st) {
+            constexpr int stage = decltype(st)::value, steps = stage == NS - 1 ? NQ - stage * TILE_STEPS : TILE_STEPS;
+            __syncthreads();   // the readers of the stage before are done with the tile
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const mfma_v4i a = tile[q * 64 + lane];
-            const mfma_v4i b1 = {(int)W[8 * q + 0], (int)W[8 * q + 1], (int)W[8 * q + 2], (int)W[8 * q + 3]};
-            const mfma_v4i b2 = {(int)W[8 * q + 4], (int)W[8 * q + 5], (int)W[8 * q + 6], (int)W[8 * q + 7]};
-            d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, d1, 0, 0, 0);   // states 0-31 of the wave
-            d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, d2, 0, 0, 0);   // states 32-63
-        }
+            for (int q = 0; q < kPer; ++q) {
+                const uint32_t e = threadIdx.x + q * THREADS;
+                if (e < (uint32_t)steps * 64) tile[e] = pre[q];
+            }
+            __syncthreads();
+            if constexpr (stage + 1 < NS) fetch(i, stage + 1);
+            else if (i + 1 < hi) fetch(i + 1, 0);
+#pragma unroll
+            for (int qq = 0; qq < steps; ++qq) {
+                constexpr int q0 = stage * TILE_STEPS;
+                const int q = q0 + qq;
+                const mfma_v4i a = tile[qq * 64 + lane];
+                const mfma_v4i b1 = {(int)W[8 * q + 0], (int)W[8 * q + 1], (int)W[8 * q + 2], (int)W[8 * q + 3]};
+                const mfma_v4i b2 = {(int)W[8 * q + 4], (int)W[8 * q + 5], (int)W[8 * q + 6], (int)W[8 * q + 7]};
+                d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, d1, 0, 0, 0);   // states 0-31 of the wave
+                d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, d2, 0, 0, 0);   // states 32-63
+            }
+        });
         // register v of d1 / d2 holds row 8 (v / 4) + 4 (lane / 32) + v % 4 of the column lane % 32: after the exchange
         // D1[4g + r] is row 8g + r and D2[4g + r] row 8g + 4 + r of THIS lane's state
         uint32_t D1[16], D2[16];

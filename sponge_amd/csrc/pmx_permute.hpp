@@ -343,7 +343,7 @@ PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, con
 // copies would not fit the instruction cache at t = 9).
 // MFMA_THREADS > 0: the dense layers run on the matrix cores (pmx_mfma.hpp) - the workgroup has that many threads, all of them
 // here together, and `tile` is its shared LDS tile.
-template <int T, int ALPHA, class Scratch, int MFMA_THREADS = 0>
+template <int T, int ALPHA, class Scratch, int MFMA_THREADS = 0, int MFMA_TILE_STEPS = 0>
 PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
                            const FieldRt &f, uint32_t want_lo = 0, uint32_t want_hi = T, void *tile = nullptr) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
@@ -425,7 +425,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             if constexpr (MFMA_THREADS > 0) {
                 const uint32_t n_full = c.total_rounds - c.partial_rounds - 1;   // the layer after the last partial round follows the full rounds' own
                 const uint32_t *lay = tb.mfma + (size_t)(full ? o : n_full) * mfma_layer_words(T);
-                matrix_rows_mfma<T, MFMA_THREADS>(s, sc, lay, static_cast<mfma_v4i *>(tile), f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
+                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, static_cast<mfma_v4i *>(tile), f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
             } else
 #endif
             if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
