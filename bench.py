@@ -59,12 +59,13 @@ BASELINE_CONFIG = {("c2", False): "BASELINE.json configs[1] (C2)", ("c2", True):
                    ("c5", True): "BASELINE.json configs[4] (C5)"}
 
 
-def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tables=False):
+def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tables=False, mfma_dense=False):
     """v_mad_u64_u32 count of one permutation as implemented (pmx_field.hpp): product 81, square 45, reduction 81 limb
     products; one reduction per S-box step and per matrix row.  With shifted tables (tab_dot) a row of N constants
     costs 81 N + 18 instead of 81 N + 81 (`row_tables`) and an identity-lane update 81 + 18 + 9 instead of 162 + 9
     (`lane_tables`).  The optimised schedule carries the state scaled lane by lane so that one entry per row of every
-    matrix but the last round's is exactly one (pmx_prepare.hpp: derive_opt_tables)."""
+    matrix but the last round's is exactly one (pmx_prepare.hpp: derive_opt_tables).  `mfma_dense`: the rows of the DENSE
+    layers come from the matrix cores (pmx_mfma.hpp) - 20 multiplies each, the two Montgomery steps of the row's finish."""
     sqr, mul = 45 + 81, 81 + 81
     chain = {5: 2 * sqr + mul, 17: 4 * sqr + mul}.get(alpha)
     if chain is None:
@@ -75,11 +76,15 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     norm = 81 * (t - 1) + red + 9                           # a normalised row: t - 1 terms + 9 multiply-by-one injections of the addend
     lane = (81 + 18 + 9) if lane_tables else (mul + 9)
     sparse = norm + (t - 1) * lane                          # a sparse layer: row 0 and the identity lanes
+    if mfma_dense:
+        dot = norm_dense = 20
+    else:
+        norm_dense = norm
     if optimised:
         # S-box layers: RF full, RP partial.  Linear layers: RF - 2 normalised dense (every full round but the entrance and the
         # last one) + 1 dense (last round) + RP sparse (after the entrance round and after every partial round but the last)
         # + 1 normalised dense (after the last partial round)
-        return rf * t * chain + rp * chain + (rf - 2) * t * norm + t * dot + rp * sparse + t * norm
+        return rf * t * chain + rp * chain + (rf - 2) * t * norm_dense + t * dot + rp * sparse + t * norm_dense
     return (rf * t + rp) * chain + (rf + rp) * t * dot
 
 
@@ -381,10 +386,13 @@ def main():
         # engines as dispatched (pmx_device.hip): t = 3..9 run the optimised schedule, with every matrix as shifted tables up
         # to t = 5 and the identity lanes only above.  ABI <-> internal conversions cost no multiplies there (the schedule's
         # own scaling makes the ABI residue the internal form, pmx_field.hpp: fe_from_abi_scaled).
-        mads = mads_per_permutation(t, alpha, rf, rp, optimised=3 <= t <= 9, row_tables=3 <= t <= 5, lane_tables=3 <= t <= 9)
+        # t = 9, alpha = 5, permutation / hash / compression kernels: dense layers on the matrix cores when the modulus' top byte
+        # allows (pmx_prepare.hpp: mfma_dense; both benchmarked fields do)
+        mfma_dense = t == 9 and alpha == 5 and (field.modulus >> 248) <= 126
+        mads = mads_per_permutation(t, alpha, rf, rp, optimised=3 <= t <= 9, row_tables=3 <= t <= 5, lane_tables=3 <= t <= 9, mfma_dense=mfma_dense)
         # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
         # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
-        last_row = 81 * t + (18 if 3 <= t <= 5 else 81)
+        last_row = 20 if mfma_dense else 81 * t + (18 if 3 <= t <= 5 else 81)
         if merkle:
             mads -= (t - 1) * last_row
         elif hashing:
@@ -416,6 +424,7 @@ def main():
                          "note": "integer-VALU bound, not HBM bound (DESIGN.md): see int_valu"},
             "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": peak.lane_mads_per_s,
                          "unit": "lane-instr/s", "frac": mad_rate / peak.lane_mads_per_s, "mads_per_permutation": mads,
+                         "dense_layers": "v_mfma_i32_32x32x32_i8 (pmx_mfma.hpp): not counted as multiplies" if mfma_dense else "VALU",
                          "peak_source": "pmx_diag_int_valu_peak on this device just before the warm-up (%d launches of a dense v_mad_u64_u32 loop, two forms, median of the later half of each)" % peak.launches,
                          "peak_best_launch": peak.best_lane_mads_per_s,
                          "peak_by_carry_destination": {"vcc": peak.lane_mads_per_s_vcc, "sgpr_pair": peak.lane_mads_per_s_sgpr}, "shader_clock_hz": peak.shader_clock_hz,

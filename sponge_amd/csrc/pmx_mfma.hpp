@@ -43,6 +43,95 @@ PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32
 PMX_FN constexpr int mfma_row_words(int t) { return mfma_k_steps(t) * 64 * 4; }             // A operand of one output row
 PMX_FN constexpr int mfma_layer_words(int t) { return t * mfma_row_words(t) + t * 16; }     // t rows, then t x 8 int64 corrections
 
+// the state's K bytes: nine 32-bit words per element (u - 128 in every byte), padded with zero digits to whole k-steps
+template <int T>
+PMX_FN void mfma_state_words(const Fe (&s)[T], uint32_t (&W)[8 * mfma_k_steps(T)]) {
+    static_for<0, T>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+#pragma unroll
+        for (int w = 0; w < 9; ++w) {
+            const int bit = 32 * w, li = bit / kW, sh = bit % kW;
+            uint64_t v = (uint64_t)s[j].l[li] >> sh;
+            if (li + 1 < kN) v |= (uint64_t)s[j].l[li + 1] << (kW - sh);
+            if (li + 2 < kN && 2 * kW - sh < 32) v |= (uint64_t)s[j].l[li + 2] << (2 * kW - sh);
+            W[9 * j + w] = (uint32_t)v ^ 0x80808080u;
+        }
+    });
+#pragma unroll
+    for (int w = 9 * T; w < 8 * mfma_k_steps(T); ++w) W[w] = 0x80808080u;   // (their table bytes are zero)
+}
+
+// One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's
+// correction, as eight 64-bit word sums with carries, re-cut into ten 29-bit limbs, two Montgomery steps: V 2^-58 mod p, norm.
+PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
+    uint32_t wd[9];
+    long long c = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const long long t = (long long)R[w][0] + (long long)R[w][1] * 256 + (long long)R[w][2] * 65536 + (long long)R[w][3] * 16777216 + corr[w] + c;
+        wd[w] = (uint32_t)t;
+        c = t >> 32;
+    }
+    wd[8] = (uint32_t)c;   // V >= 0: the top carry is not negative
+    uint32_t L[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const int bit = kW * k, wi = bit / 32, sh = bit % 32;
+        uint64_t pair = wd[wi];
+        if (wi + 1 < 9) pair |= (uint64_t)wd[wi + 1] << 32;
+        L[k] = (uint32_t)(pair >> sh) & kMask;
+    }
+    uint64_t acc = L[0];
+    const uint32_t m0 = ((uint32_t)acc * f.pinv) & kMask;
+    acc += (uint64_t)m0 * f.p[0];
+    acc >>= kW;
+    acc += L[1];
+    acc += (uint64_t)m0 * f.p[1];
+    const uint32_t m1 = ((uint32_t)acc * f.pinv) & kMask;
+    acc += (uint64_t)m1 * f.p[0];
+    acc >>= kW;
+    Fe row;
+#pragma unroll
+    for (int k = 2; k <= 10; ++k) {
+        if (k < 10) acc += L[k];
+        if (k <= 8) acc += (uint64_t)m0 * f.p[k];
+        if (k - 1 <= 8) acc += (uint64_t)m1 * f.p[k - 1];
+        row.l[k - 2] = k < 10 ? ((uint32_t)acc & kMask) : (uint32_t)acc;
+        acc >>= kW;
+    }
+    return row;
+}
+
+#if !defined(__HIPCC__)
+// Host form for tests/hostcheck (g++, no matrix cores): the same tables, bytes and finish, the GEMM as plain integer sums.
+template <int T, int THREADS, int TILE_STEPS, class Scratch>
+inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, void * /*tile*/, const FieldRt &f, uint32_t lo, uint32_t hi) {
+    constexpr int NQ = mfma_k_steps(T);
+    uint32_t W[8 * NQ];
+    mfma_state_words<T>(s, W);
+    const int8_t *bytes = reinterpret_cast<const int8_t *>(layer);
+    const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(T));
+    Fe last = s[T - 1];
+    for (uint32_t i = lo; i < hi; ++i) {
+        int32_t R[8][4];
+        for (int e = 0; e < 32; ++e) {
+            long long sum = 0;
+            for (int k = 0; k < 32 * NQ; ++k) {
+                const int u = (int)(int8_t)((W[k / 4] >> (8 * (k % 4))) & 0xff);
+                const int q = k / 32, h = (k % 32) / 16, byte = k % 16;
+                sum += (long long)u * bytes[(((size_t)i * NQ + q) * 64 + 32 * h + e) * 16 + byte];
+            }
+            R[e / 4][e % 4] = (int32_t)sum;
+        }
+        const Fe row = mfma_row_finish(R, corr + (size_t)i * 8, f);
+        if (i + 1 < (uint32_t)T) sc.set(i, row);
+        else last = row;
+    }
+    static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
+    s[T - 1] = last;
+}
+#endif
+
 #if defined(__HIPCC__)   // (tests/hostcheck compiles the headers with g++: no matrix cores there)
 
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
@@ -65,19 +154,7 @@ __device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const 
     constexpr int NS = (NQ + TILE_STEPS - 1) / TILE_STEPS;   // the tile holds TILE_STEPS k-steps: a row passes through it in NS stages
     const uint32_t lane = threadIdx.x & 63;
     uint32_t W[NW];
-    static_for<0, T>([&](auto jj) {
-        constexpr int j = decltype(jj)::value;
-#pragma unroll
-        for (int w = 0; w < 9; ++w) {
-            const int bit = 32 * w, li = bit / kW, sh = bit % kW;
-            uint64_t v = (uint64_t)s[j].l[li] >> sh;
-            if (li + 1 < kN) v |= (uint64_t)s[j].l[li + 1] << (kW - sh);
-            if (li + 2 < kN && 2 * kW - sh < 32) v |= (uint64_t)s[j].l[li + 2] << (2 * kW - sh);
-            W[9 * j + w] = (uint32_t)v ^ 0x80808080u;
-        }
-    });
-#pragma unroll
-    for (int w = 9 * T; w < NW; ++w) W[w] = 0x80808080u;   // (their table bytes are zero)
+    mfma_state_words<T>(s, W);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -125,52 +202,16 @@ __device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const 
             }
         });
         // register v of d1 / d2 holds row 8 (v / 4) + 4 (lane / 32) + v % 4 of the column lane % 32: after the exchange
-        // D1[4g + r] is row 8g + r and D2[4g + r] row 8g + 4 + r of THIS lane's state
-        uint32_t D1[16], D2[16];
+        // d1[4g + r] is row 8g + r and d2[4g + r] row 8g + 4 + r of THIS lane's state, i.e. word 2g of the row is d1[4g ..], word 2g + 1 d2[4g ..]
+        int32_t R[8][4];
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            D1[v] = (uint32_t)d1[v];
-            D2[v] = (uint32_t)d2[v];
-            lane32_swap(D1[v], D2[v]);
+            uint32_t x = (uint32_t)d1[v], y = (uint32_t)d2[v];
+            lane32_swap(x, y);
+            R[2 * (v / 4)][v % 4] = (int32_t)x;
+            R[2 * (v / 4) + 1][v % 4] = (int32_t)y;
         }
-        uint32_t wd[9];
-        long long c = 0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {   // word w = rows 4w .. 4w + 3
-            const uint32_t *d = (w & 1) ? D2 : D1;
-            const int b = 4 * (w >> 1);
-            const long long t = (long long)(int)d[b] + ((long long)(int)d[b + 1] << 8) + ((long long)(int)d[b + 2] << 16) +
-                                ((long long)(int)d[b + 3] << 24) + corr[i * 8 + w] + c;
-            wd[w] = (uint32_t)t;
-            c = t >> 32;
-        }
-        wd[8] = (uint32_t)c;   // V >= 0: the top carry is not negative
-        uint32_t L[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            const int bit = kW * k, wi = bit / 32, sh = bit % 32;
-            uint64_t pair = wd[wi];
-            if (wi + 1 < 9) pair |= (uint64_t)wd[wi + 1] << 32;
-            L[k] = (uint32_t)(pair >> sh) & kMask;
-        }
-        uint64_t acc = L[0];
-        const uint32_t m0 = ((uint32_t)acc * f.pinv) & kMask;
-        acc += (uint64_t)m0 * f.p[0];
-        acc >>= kW;
-        acc += L[1];
-        acc += (uint64_t)m0 * f.p[1];
-        const uint32_t m1 = ((uint32_t)acc * f.pinv) & kMask;
-        acc += (uint64_t)m1 * f.p[0];
-        acc >>= kW;
-        Fe row;
-#pragma unroll
-        for (int k = 2; k <= 10; ++k) {
-            if (k < 10) acc += L[k];
-            if (k <= 8) acc += (uint64_t)m0 * f.p[k];
-            if (k - 1 <= 8) acc += (uint64_t)m1 * f.p[k - 1];
-            row.l[k - 2] = k < 10 ? ((uint32_t)acc & kMask) : (uint32_t)acc;
-            acc >>= kW;
-        }
+        const Fe row = mfma_row_finish(R, corr + (size_t)i * 8, f);
         if (i + 1 < (uint32_t)T) sc.set(i, row);
         else last = row;
     }

@@ -421,14 +421,15 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             // except the last round's, whose output is the permutation's
             const bool last = r + 1 == c.total_rounds;
             const uint32_t o = full ? full_ordinal(r, c) : 0;
-#if defined(__HIPCC__)
             if constexpr (MFMA_THREADS > 0) {
                 const uint32_t n_full = c.total_rounds - c.partial_rounds - 1;   // the layer after the last partial round follows the full rounds' own
                 const uint32_t *lay = tb.mfma + (size_t)(full ? o : n_full) * mfma_layer_words(T);
+#if defined(__HIPCC__)
                 matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, static_cast<mfma_v4i *>(tile), f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
-            } else
+#else
+                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, tile, f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
 #endif
-            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
+            } else if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
                 const uint32_t *mat = full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense;
                 if (last) matrix_rows_rolled_tab<T, false>(s, sc, mat, f, want_lo, want_hi);
                 else matrix_rows_rolled_tab<T, true>(s, sc, mat, f);

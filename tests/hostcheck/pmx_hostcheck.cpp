@@ -130,6 +130,7 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
     tb.tab_full = pp.consts.data() + pp.tab_full_offset;
     tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
     tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
+    tb.mfma = nullptr;
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
         HostScratch<T> sc;
@@ -139,6 +140,36 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
         else permute_hybrid<T, 0>(s, sc, tb, pp.c, pp.one, pp.f);
         for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
     }
+}
+
+// The matrix-core form of the widest hybrid (HybridEngine<9, 5, true>): the same round loop with its dense layers through
+// pmx_mfma.hpp's tables, byte strings and row finish - the GEMM itself as plain integer sums (no matrix cores on the host).
+extern "C" int hc_permute_hybrid_mfma(const pmx_config *cfg, uint64_t *states, size_t n) {
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);
+    if (rc) return rc;
+    if (!pp.has_opt || !pp.mfma_dense || pp.t != 9) return PMX_ERR_UNSUPPORTED;
+    constexpr int T = 9;
+    OptTables tb;
+    tb.ark = pp.consts.data() + pp.opt_offset;
+    tb.mds = pp.consts.data() + pp.mds_offset;
+    tb.full = pp.consts.data() + pp.opt_full_offset;
+    tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
+    tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
+    tb.tab_full = pp.consts.data() + pp.tab_full_offset;
+    tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
+    tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
+    tb.mfma = pp.consts.data() + pp.mfma_offset;
+    for (size_t k = 0; k < n; ++k) {
+        Fe s[T];
+        HostScratch<T> sc;
+        for (int i = 0; i < T; ++i) s[i] = fe_from_abi_scaled(load_abi(states + (k * T + i) * 4));
+        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, 256, 6>(s, sc, tb, pp.c, pp.one, pp.f);
+        else permute_hybrid<T, 0, HostScratch<T>, 256, 6>(s, sc, tb, pp.c, pp.one, pp.f);
+        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
+    }
+    return PMX_OK;
 }
 
 // register + scratch hybrid on the optimised schedule (what HybridEngine runs)

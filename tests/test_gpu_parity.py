@@ -274,6 +274,35 @@ def test_odd_full_rounds_vs_c_oracle(rate, rf, rp):
     assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
 
 
+@pytest.mark.parametrize("field_name,modulus", [("pallas_fp", 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001),
+                                                ("p25519", (1 << 255) - 19)])
+def test_t9_dense_layers_on_and_off_the_matrix_cores(field_name, modulus):
+    """The wave-uniform t = 9 kernels run their dense layers on the matrix cores when the modulus' residues fit 32 balanced bytes
+    (top byte <= 126: pmx_prepare.hpp, pmx_mfma.hpp) and on the element-form rows otherwise.  A third field on each side of that
+    rule - neither is a benchmarked one - through permutation (sizes that leave a workgroup, a wave and a lane pair l / l + 32
+    partly empty), hash driver and compression, against the C port."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.Field(field_name, modulus)
+    cfg = S.poseidon_config_from_lfsr(f, 8, 5, 8, 57)
+    cr = cref.CRef(O.make_config(modulus, 255, 8, 5, 8, 57))
+    for n in (1, 33, 70, 255, 257, 1000):
+        states = synth.random_elements(f, n * 9, seed=900 + n).reshape(n, 9, 4)
+        assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0)), (field_name, n)
+    edge = f.from_ints([v for e in (0, 1, modulus - 1, modulus - 2) for v in [e] * 9]).reshape(4, 9, 4)
+    assert np.array_equal(cfg.context().permute_batch(edge), cr.permute_batch(edge, threads=0))
+    msgs = synth.random_elements(f, 70 * 19, seed=5).reshape(70, 19, 4)
+    assert np.array_equal(cfg.context().hash_batch(msgs, 19, 10), cr.hash_batch(msgs, 19, 10, threads=0))
+    leaves = synth.random_elements(f, 512, seed=6)
+    nodes, _ = cfg.context().merkle_2to1(leaves)
+    assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
+    # the per-lane drivers (absorb / squeeze) stay on the element-form rows at every modulus: new; absorb(11); squeeze(9) = a hash row
+    msgs = synth.random_elements(f, 130 * 11, seed=7).reshape(130, 11, 4)
+    b = S.BatchPoseidonSponge.new(cfg, 130)
+    b.absorb(msgs)
+    assert np.array_equal(b.squeeze_native_field_elements(9), cr.hash_batch(msgs, 11, 9, threads=0))
+
+
 def test_merkle_tree_paths():
     """Tree container + batch path verification (2-to-1 compression mode) against the oracle's tree."""
     from oracle import poseidon_oracle as O

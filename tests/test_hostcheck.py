@@ -29,6 +29,7 @@ def hc():
     lib.hc_permute_opt_tab.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_hybrid.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_coop.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    lib.hc_permute_hybrid_mfma.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_field_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_sqr_column.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
@@ -142,7 +143,7 @@ def test_table_column_accumulators_cannot_overflow(hc):
         assert (int(hi[0]) == 0) == ok, (terms, zmax, int(hi[0]))
 
 
-def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False, tab=False):
+def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False, tab=False, mfma=False):
     cfg = oracle_config(name)
     p = cfg.p
     ark = mont_limbs([v for row in cfg.ark for v in row], p)
@@ -155,7 +156,7 @@ def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False,
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
     out = np.ascontiguousarray(states, dtype=np.uint64).copy()
     n = out.size // (cfg.t * 4)
-    fn = hc.hc_permute_opt_tab if tab else hc.hc_permute_coop if coop else hc.hc_permute_hybrid if hybrid else (
+    fn = hc.hc_permute_hybrid_mfma if mfma else hc.hc_permute_opt_tab if tab else hc.hc_permute_coop if coop else hc.hc_permute_hybrid if hybrid else (
         hc.hc_permute_opt if opt else (hc.hc_permute_rt if rt else hc.hc_permute))
     assert fn(ctypes.byref(c), out.ctypes.data, n) == 0
     return out
@@ -181,6 +182,9 @@ def test_permutation_templates_match_golden(hc, name):
     if cfg.t == 3:
         out = run_permute(hc, name, states, coop=True)  # three-lanes-per-state schedule (small Merkle levels)
         assert cref.limbs_to_elems(out, cfg.p) == want, "coop"
+    if cfg.t == 9:
+        out = run_permute(hc, name, states, mfma=True)  # dense layers as the matrix-core engine computes them (pmx_mfma.hpp)
+        assert cref.limbs_to_elems(out, cfg.p) == want, "hybrid, dense layers on the int8 tables"
 
 
 def test_permutation_templates_match_c_oracle_on_random_batch(hc):
@@ -198,6 +202,13 @@ def test_permutation_templates_match_c_oracle_on_random_batch(hc):
     states = sy.random_elements(S.BN254_FR, 64 * 9, seed=78).reshape(64, 9, 4)
     want = cref.CRef(oracle_config("bn254_t9_a5_8_57")).permute_batch(states, threads=0)
     assert np.array_equal(run_permute(hc, "bn254_t9_a5_8_57", states, hybrid=True), want)
+    assert np.array_equal(run_permute(hc, "bn254_t9_a5_8_57", states, mfma=True), want)
+    # edge states: every element 0, 1 (Montgomery), p - 1
+    from oracle import poseidon_oracle as Oo
+    p = Oo.BN254_FR
+    edge = mont_limbs([v for e in (0, 1, p - 1, p - 2, (1 << 253) + 12345) for v in [e] * 9], p).reshape(5, 9, 4)
+    want = cref.CRef(oracle_config("bn254_t9_a5_8_57")).permute_batch(edge, threads=0)
+    assert np.array_equal(run_permute(hc, "bn254_t9_a5_8_57", edge, mfma=True), want)
 
 
 def test_identity_lane_magnitudes_stay_inside_their_bounds(hc):
@@ -289,6 +300,7 @@ def test_long_partial_sections_leave_the_optimised_schedule(hc):
 
 
 PALLAS_FP = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001      # 255 bits, not a reference field
+P25519 = (1 << 255) - 19   # top byte 0x7f
 SMALL_P = (1 << 230) + 0x1D                                                         # pseudo-modulus near the lower limit
 
 
@@ -317,6 +329,33 @@ def test_other_255_bit_prime(hc, p):
         out = limbs.copy()
         assert fn(ctypes.byref(c), out.ctypes.data, len(states)) == 0
         assert cref.limbs_to_elems(out, p) == want, fn.__name__
+
+
+def test_matrix_core_tables_only_for_moduli_whose_residues_fit_32_balanced_bytes(hc):
+    """pmx_mfma.hpp stores residues in 32 balanced signed bytes, which needs the modulus' top byte <= 126; 2^255 - 19 (0x7f) does
+    not qualify: prepare() then builds no such tables, the matrix-core form refuses and the element-form rows (what the product
+    dispatches to in that case) still agree with the big-integer oracle at t = 9.  Pallas (top byte 0x40) qualifies."""
+    for p, ok in ((P25519, False), (PALLAS_FP, True)):
+        cfg = O.make_config(p, 255, 8, 5, 8, 57)
+        rng = random.Random(4242)
+        states = [[rng.randrange(p) for _ in range(9)] for _ in range(3)] + [[p - 1] * 9]
+        want = [x for st in states for x in O.permute(cfg, st)]
+        limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), 9, 4)
+        ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+        mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+        c = PmxConfig()
+        c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = 8, 57, 5, 8, 1
+        for i, l in enumerate(O.to_limbs(p)):
+            c.modulus[i] = l
+        c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+        out = limbs.copy()
+        assert hc.hc_permute_hybrid(ctypes.byref(c), out.ctypes.data, len(states)) == 0
+        assert cref.limbs_to_elems(out, p) == want
+        out = limbs.copy()
+        rc = hc.hc_permute_hybrid_mfma(ctypes.byref(c), out.ctypes.data, len(states))
+        assert rc == (0 if ok else -4), (hex(p >> 248), rc)
+        if ok:
+            assert cref.limbs_to_elems(out, p) == want
 
 
 @pytest.mark.parametrize("rate", [2, 4])

@@ -68,7 +68,7 @@ if has pmc; then
 fi
 if has slots; then
   ( python tools/valu_slots.py $OUT/slots_a_c2 permute_kernel 1048576 1 40077; python tools/valu_slots.py $OUT/slots_b_c2 permute_kernel 1048576 1 40077
-    python tools/valu_slots.py $OUT/slots_a_c3 permute_kernel 262144 1 198504; python tools/valu_slots.py $OUT/slots_b_c3 permute_kernel 262144 1 198504 ) > $OUT/valu_slots.txt 2>&1
+    python tools/valu_slots.py $OUT/slots_a_c3 permute_kernel 262144 1 146160; python tools/valu_slots.py $OUT/slots_b_c3 permute_kernel 262144 1 146160 ) > $OUT/valu_slots.txt 2>&1
   cat $OUT/valu_slots.txt
 fi
 if has sponge; then
