@@ -1082,19 +1082,20 @@ struct Launch {
         default: return hipErrorInvalidValue;                              \
     }
 
-// the wave-uniform kernels of the widest state: dense layers on the matrix cores when the config has their tables
-#if PMX_TU == 1 && PMX_MFMA_MAX_T >= 9
-#define PMX_HYB_MFMA(CALL)                                                                              \
-    do {                                                                                                \
-        if (t == 9 && c.mfma_dense && lds_fits_engine<HybridEngine<9, PMX_HYB_ALPHA, true>>(c, t))      \
-            return Launch<HybridEngine<9, PMX_HYB_ALPHA, true>>::CALL;                                  \
-    } while (0)
-#else
-#define PMX_HYB_MFMA(CALL) do { } while (0)
-#endif
 template <class Engine>
 static bool lds_fits_engine(const DevConfig &c, uint32_t t) { return Engine::lds_bytes(c, t) <= (size_t)c.max_lds_bytes; }
-
+// the wave-uniform kernels of the wide states: dense layers on the matrix cores when the config has their tables
+#define PMX_HYB_MFMA_CASE(W, CALL)                                                                      \
+    if (t == W && W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T && lds_fits_engine<HybridEngine<W, PMX_HYB_ALPHA, true>>(c, t)) \
+        return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::CALL;
+#define PMX_HYB_MFMA(CALL)               \
+    do {                                 \
+        if (c.mfma_dense) {              \
+            PMX_HYB_MFMA_CASE(7, CALL)   \
+            PMX_HYB_MFMA_CASE(8, CALL)   \
+            PMX_HYB_MFMA_CASE(9, CALL)   \
+        }                                \
+    } while (0)
 hipError_t PMX_HYB_NAME(permute)(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
     PMX_HYB_MFMA(permute(c, t, states, n, st));
     PMX_HYB_DISPATCH(permute(c, t, states, n, st));

@@ -29,15 +29,14 @@
 
 namespace pmx {
 
-// Widths whose dense layers go to the matrix cores.  Below 7 a row is cheaper on the VALU (81 t + 81 multiplies against ~250
-// instructions of re-cutting and carrying per row); 9 is the width that has an engine for it so far (pmx_device.hip).
+// Widths whose dense layers go to the matrix cores.  A row costs ~250 VALU instructions of finish plus its share of the state's
+// re-cut (26 per element) and 2 x ceil(36 t / 32) MFMA issue slots, against 81 t + 81 multiplies and their carries on the VALU.
 #ifndef PMX_MFMA_MIN_T
-#define PMX_MFMA_MIN_T 9
+#define PMX_MFMA_MIN_T 7
 #endif
 #ifndef PMX_MFMA_MAX_T
 #define PMX_MFMA_MAX_T 9
 #endif
-
 constexpr int kMfmaElemBytes = 36;   // K bytes per element (33 used)
 PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32; }
 PMX_FN constexpr int mfma_row_words(int t) { return mfma_k_steps(t) * 64 * 4; }             // A operand of one output row

@@ -303,6 +303,29 @@ def test_t9_dense_layers_on_and_off_the_matrix_cores(field_name, modulus):
     assert np.array_equal(b.squeeze_native_field_elements(9), cr.hash_batch(msgs, 11, 9, threads=0))
 
 
+@pytest.mark.parametrize("rate", [6, 7, 8])
+@pytest.mark.parametrize("alpha", [5, 17, 3])
+def test_widths_7_to_9_and_every_exponent_on_the_matrix_cores(rate, alpha):
+    """t = 7, 8, 9 x the dedicated chain (5), the other dedicated one (17: the generic-exponent build of the hybrid engines) and
+    a plain square-and-multiply exponent: permutation, hash driver (last permutation computes only the wanted rows) and
+    compression against the C port."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    cfg = S.poseidon_config_from_lfsr(f, rate, alpha, 8, 57)
+    cr = cref.CRef(O.make_config(O.BLS12_381_FR, 255, rate, alpha, 8, 57))
+    t = rate + 1
+    for n in (1, 95, 300):
+        states = synth.random_elements(f, n * t, seed=70 * rate + alpha + n).reshape(n, t, 4)
+        assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0)), (rate, alpha, n)
+    L = 2 * rate + 1
+    msgs = synth.random_elements(f, 70 * L, seed=alpha).reshape(70, L, 4)
+    assert np.array_equal(cfg.context().hash_batch(msgs, L, 3), cr.hash_batch(msgs, L, 3, threads=0))
+    leaves = synth.random_elements(f, 128, seed=rate)
+    nodes, _ = cfg.context().merkle_2to1(leaves)
+    assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
+
+
 def test_merkle_tree_paths():
     """Tree container + batch path verification (2-to-1 compression mode) against the oracle's tree."""
     from oracle import poseidon_oracle as O
