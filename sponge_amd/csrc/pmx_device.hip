@@ -228,8 +228,8 @@ struct RegEngine {
 #ifndef PMX_HYB_4WAVE_MAX_T
 #define PMX_HYB_4WAVE_MAX_T 4   // t = 4 (133 VGPRs when left alone) held to 128: four waves per SIMD, +3.8 % (round 3 A/B)
 #endif
-// MFMA: the dense layers run on the matrix cores (pmx_mfma.hpp); eight waves per workgroup share one LDS tile of the layer's
-// table rows - the wave-uniform kernels only (permute, hash, compress: inside the per-lane loops of absorb / squeeze not every
+// MFMA: the dense layers run on the matrix cores (pmx_mfma.hpp); the PMX_MFMA_WAVES waves of a workgroup share one LDS tile of the
+// layer's table rows - the wave-uniform kernels only (permute, hash, compress: inside the per-lane loops of absorb / squeeze not every
 // lane is active, and the lane exchange of that path needs both lanes of a pair).
 #ifndef PMX_MFMA_WAVES
 #define PMX_MFMA_WAVES 4        // waves per workgroup of the matrix-core engines, and

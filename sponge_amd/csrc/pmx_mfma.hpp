@@ -19,9 +19,9 @@
 //     carry pass, a re-cut into ten 29-bit limbs and two Montgomery steps (division by 2^58, which the table carries)
 //     give the row as a norm element below (1 + 2^-40) p - 20 multiplies instead of 810.
 //
-// The 11 KiB of table one row of t = 9 needs are staged in LDS once per WORKGROUP (read per wave from L2 they are 101 KiB
-// per wave and layer and the L2 -> L1 path sets the time), which is why the engines that use this run eight waves per
-// workgroup.  tools/mfma_dense_proto.{py,hip} is the stand-alone form of the same code with its check against Python
+// The 11 KiB of table one row of t = 9 needs pass through an LDS tile once per WORKGROUP, in stages (read per wave from L2 they
+// are 101 KiB per wave and layer and the L2 -> L1 path sets the time), which is why the engines that use this run several waves
+// per workgroup (pmx_device.hip: PMX_MFMA_WAVES, PMX_MFMA_TILE_STEPS).  tools/mfma_dense_proto.{py,hip} is the stand-alone form of the same code with its check against Python
 // integers; profiles/r03/g_mfma_dense_proto.txt its measurements.
 #pragma once
 
