@@ -67,7 +67,13 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
     long long c = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-        const long long t = (long long)R[w][0] + (long long)R[w][1] * 256 + (long long)R[w][2] * 65536 + (long long)R[w][3] * 16777216 + corr[w] + c;
+        // (the weights come from a register the compiler cannot see through - f.unit is 1 - so that each term is ONE v_mad_i64_i32
+        // instead of a sign extension, a 64-bit shift and a 64-bit add)
+        const int w8 = (int)(f.unit << 8), w16 = (int)(f.unit << 16), w24 = (int)(f.unit << 24);
+        long long t = corr[w] + c + (long long)R[w][0];
+        t += (long long)R[w][1] * w8;
+        t += (long long)R[w][2] * w16;
+        t += (long long)R[w][3] * w24;
         wd[w] = (uint32_t)t;
         c = t >> 32;
     }
