@@ -64,20 +64,22 @@ PMX_FN void mfma_state_words(const Fe (&s)[T], uint32_t (&W)[8 * mfma_k_steps(T)
 // correction, as eight 64-bit word sums with carries, re-cut into ten 29-bit limbs, two Montgomery steps: V 2^-58 mod p, norm.
 PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
     uint32_t wd[9];
-    long long c = 0;
+    // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from a
+    // register the compiler cannot see through - f.unit is 1 - or it would turn each into a sign extension, a 64-bit shift and a
+    // 64-bit add.  |t| < 2^50, so the carry into the next word (t >> 32) is the high register as it stands.
+    const int w1 = (int)f.unit, w8 = (int)(f.unit << 8), w16 = (int)(f.unit << 16), w24 = (int)(f.unit << 24);
+    int carry = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-        // (the weights come from a register the compiler cannot see through - f.unit is 1 - so that each term is ONE v_mad_i64_i32
-        // instead of a sign extension, a 64-bit shift and a 64-bit add)
-        const int w8 = (int)(f.unit << 8), w16 = (int)(f.unit << 16), w24 = (int)(f.unit << 24);
-        long long t = corr[w] + c + (long long)R[w][0];
+        long long t = corr[w] + (long long)carry * w1;
+        t += (long long)R[w][0] * w1;
         t += (long long)R[w][1] * w8;
         t += (long long)R[w][2] * w16;
         t += (long long)R[w][3] * w24;
         wd[w] = (uint32_t)t;
-        c = t >> 32;
+        carry = (int)(t >> 32);
     }
-    wd[8] = (uint32_t)c;   // V >= 0: the top carry is not negative
+    wd[8] = (uint32_t)carry;   // V >= 0: the top carry is not negative
     uint32_t L[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
