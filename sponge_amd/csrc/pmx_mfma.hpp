@@ -29,7 +29,7 @@
 
 namespace pmx {
 
-// Widths whose dense layers go to the matrix cores.  A row costs ~250 VALU instructions of finish plus its share of the state's
+// Widths whose dense layers go to the matrix cores.  A row costs ~155 VALU instructions of finish plus its share of the state's
 // re-cut (26 per element) and 2 x ceil(36 t / 32) MFMA issue slots, against 81 t + 81 multiplies and their carries on the VALU.
 #ifndef PMX_MFMA_MIN_T
 #define PMX_MFMA_MIN_T 7
