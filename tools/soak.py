@@ -26,6 +26,9 @@ cases.append((S.poseidon_config_from_lfsr(f, 2, 5, 7, 31), cref.CRef(O.make_conf
 cases.append((S.poseidon_config_from_lfsr(f, 4, 5, 8, 56), cref.CRef(O.make_config(O.BLS12_381_FR, 255, 4, 5, 8, 56)), 5, [1, 64, 65, 1000, 5000]))
 cases.append((S.poseidon_config_from_lfsr(S.BN254_FR, 8, 5, 8, 57), cref.CRef(O.make_config(O.BN254_FR, 254, 8, 5, 8, 57)), 9, [1, 64, 130, 3000]))
 cases.append((S.poseidon_config_from_lfsr(f, 11, 5, 8, 57), cref.CRef(O.make_config(O.BLS12_381_FR, 255, 11, 5, 8, 57)), 12, [1, 64, 130]))
+# t = 7, 8: the other widths of the matrix-core engine (table stages of 6 + 2 and 6 + 3 k-steps), alpha 5 and the generic-exponent build
+cases.append((S.poseidon_config_from_lfsr(f, 6, 5, 8, 57), cref.CRef(O.make_config(O.BLS12_381_FR, 255, 6, 5, 8, 57)), 7, [1, 33, 64, 257, 1000]))
+cases.append((S.poseidon_config_from_lfsr(f, 7, 17, 8, 57), cref.CRef(O.make_config(O.BLS12_381_FR, 255, 7, 17, 8, 57)), 8, [1, 65, 300, 2000]))
 t0, it, checked = time.time(), 0, 0
 while time.time() - t0 < budget:
     cfg, cr, t, sizes = cases[it % len(cases)]
