@@ -277,7 +277,9 @@ struct HybridEngine {
     uint32_t lane;
 
     // the stage of a row's table the workgroup shares, behind the waves' regions
-    static constexpr int kTileSteps = mfma_k_steps(T) < PMX_MFMA_TILE_STEPS ? mfma_k_steps(T) : PMX_MFMA_TILE_STEPS;
+    // (a whole row where two workgroups per CU still fit - t = 7: 8 KiB, t = 8: 9 KiB -, PMX_MFMA_TILE_STEPS at t = 9)
+    static constexpr int kTileFit = (int)((80 * 1024 - PMX_MFMA_WAVES * kWaveBytes) / 1024);
+    static constexpr int kTileSteps = mfma_k_steps(T) <= kTileFit ? mfma_k_steps(T) : PMX_MFMA_TILE_STEPS;
     static constexpr size_t kTileBytes = MFMA ? (size_t)kTileSteps * 1024 : 0;
     static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes + kTileBytes; }
 
