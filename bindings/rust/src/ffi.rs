@@ -109,7 +109,6 @@ extern "C" {
                                    row_elems: usize) -> c_int;
     pub fn pmx_mgpu_merkle_2to1_dev(g: *mut pmx_mgpu, d_nodes: *const *mut u64, d_top: *const *mut u64, n_leaves: usize) -> c_int;
     pub fn pmx_mgpu_merkle_2to1(g: *mut pmx_mgpu, leaves: *const u64, n_leaves: usize, root: *mut u64) -> c_int;
-    pub fn pmx_mgpu_test_fault(fail_local: c_int, no_threads: c_int) -> c_int;
     // diagnostics
     pub fn pmx_diag_int_valu_peak(device: c_int, seconds: f64, out: *mut pmx_valu_peak) -> c_int;
 }

@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define PMX_ABI_VERSION 2
+/* 3: PMX_ERR_HOST, pmx_merkle_verify_paths_dev, indices >= 2^depth fail verification, pmx_ctx_engine_info;
+ *    the test hooks left this header (poseidon_mi355x_testing.h). */
+#define PMX_ABI_VERSION 3
 #define PMX_LIMBS 4        /* uint64_t limbs per field element */
 #define PMX_MAX_WIDTH 16   /* largest rate+capacity accepted (reference default table uses 3..9) */
 
@@ -246,10 +248,9 @@ int pmx_mgpu_merkle_2to1_dev(pmx_mgpu *g, uint64_t *const *d_nodes, uint64_t *co
 /* Host leaves [n_leaves][4] -> root [4] (single-process groups). */
 int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t n_leaves, uint64_t *root);
 
-/* Test hook: the host fan-out of pmx_mgpu_permute_batch / _hash_batch fails on local device `fail_local` (-1: off) and,
- * with no_threads != 0, runs as if no worker thread could be started (the shards then go one after the other on the
- * calling thread).  Process-wide; for the library's own tests. */
-int pmx_mgpu_test_fault(int fail_local, int no_threads);
+/* (The library's own test hooks - fault injection in the host fan-out, device groups whose slots share one GPU - are
+ * declared in poseidon_mi355x_testing.h.  They are inert unless the process runs with PMX_TEST_HOOKS=1 and are not part
+ * of this ABI.) */
 
 /* ---- diagnostics ---------------------------------------------------------------------------------------
  * The binding roofline of these kernels is the issue rate of v_mad_u64_u32 (one per 32x32-bit limb product), not

@@ -19,7 +19,7 @@ PMX_ERR_UNSUPPORTED = -4
 PMX_ERR_RCCL = -5
 PMX_ERR_HOST = -6
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 UNIQUE_ID_BYTES = 128
 MAX_LOCAL_DEVICES = 16
 
@@ -121,9 +121,15 @@ SIGNATURES = {
     "pmx_mgpu_all_gather_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
     "pmx_mgpu_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz]),
     "pmx_mgpu_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p]),
-    "pmx_mgpu_test_fault": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     # diagnostics
     "pmx_diag_int_valu_peak": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.POINTER(PmxValuPeak)]),
+}
+
+# include/poseidon_mi355x_testing.h: inert unless the process runs with PMX_TEST_HOOKS=1 (the library's own tests)
+TEST_HOOK_SIGNATURES = {
+    "pmx_test_hooks_enabled": (ctypes.c_int, []),
+    "pmx_mgpu_test_fault": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "pmx_mgpu_test_shared_device": (ctypes.c_int, [ctypes.c_int]),
 }
 
 _lib = None
@@ -137,7 +143,7 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `make -C sponge_amd/csrc` "
                 "(or __graft_entry__.build()). There is no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in SIGNATURES.items():
+        for name, (restype, argtypes) in list(SIGNATURES.items()) + list(TEST_HOOK_SIGNATURES.items()):
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes

@@ -242,14 +242,19 @@ extern "C" int pmx_ctx_acquire(const pmx_config *cfg, int device, pmx_ctx **out)
         winner = cache_find(cc, key, blob);
         if (!winner) {
             fresh->cache_blob = std::move(blob);
-            cc.by_key[key].push_back(fresh);
+            try {
+                cc.by_key[key].push_back(fresh);
+            } catch (...) {
+                // still under the lock: the map belongs to every thread (a bucket the failed insert may have left empty)
+                auto it = cc.by_key.find(key);
+                if (it != cc.by_key.end() && it->second.empty()) cc.by_key.erase(it);
+                throw;
+            }
             fresh->cache_key = key;      // set last: from here on the context belongs to the cache
             fresh->cache_refs = 1;
         }
     } catch (...) {
-        auto it = cc.by_key.find(key);   // (a bucket the failed insert may have left empty)
-        if (it != cc.by_key.end() && it->second.empty()) cc.by_key.erase(it);
-        (void)ctx_free(fresh);
+        (void)ctx_free(fresh);           // the lock is released by now; `fresh` never reached the cache
         throw;
     }
     if (winner) {

@@ -13,7 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -160,6 +162,42 @@ static int group_contexts(pmx_mgpu *g, const pmx_config *cfg) {
     return PMX_OK;
 }
 
+// Test hooks (include/poseidon_mi355x_testing.h; not part of the product ABI, not in the Rust binding).  They only take
+// effect in a process started with PMX_TEST_HOOKS=1 - anywhere else the setters answer PMX_ERR_UNSUPPORTED and the
+// library behaves as if they did not exist.  Process-wide, read by the fan-out's worker threads: atomics.
+//   fault:          the host fan-out of the next calls fails on one local slot and / or behaves as if no worker thread
+//                   could be started (error carry-back and the serial path, on any box);
+//   shared device:  pmx_mgpu_create accepts the same device ordinal in several slots and more slots than visible devices,
+//                   so that every world > 1 branch below runs on a ONE-GPU box behind tests/fake_rccl (RCCL itself
+//                   refuses two ranks on one device).
+namespace {
+struct Hooks {
+    std::atomic<int> fail_local{-1};
+    std::atomic<bool> no_threads{false};
+    std::atomic<bool> shared_device{false};
+};
+Hooks g_hooks;
+bool hooks_armed() {
+    static const bool armed = [] {
+        const char *e = std::getenv("PMX_TEST_HOOKS");
+        return e && e[0] == '1' && e[1] == 0;
+    }();
+    return armed;
+}
+}  // namespace
+extern "C" int pmx_test_hooks_enabled(void) { return hooks_armed() ? 1 : 0; }
+extern "C" int pmx_mgpu_test_fault(int fail_local, int no_threads) {
+    if (!hooks_armed()) return set_error(PMX_ERR_UNSUPPORTED, "test hooks are off (start the process with PMX_TEST_HOOKS=1)");
+    g_hooks.fail_local.store(fail_local);
+    g_hooks.no_threads.store(no_threads != 0);
+    return PMX_OK;
+}
+extern "C" int pmx_mgpu_test_shared_device(int allow) {
+    if (!hooks_armed()) return set_error(PMX_ERR_UNSUPPORTED, "test hooks are off (start the process with PMX_TEST_HOOKS=1)");
+    g_hooks.shared_device.store(allow != 0);
+    return PMX_OK;
+}
+
 extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *devices, pmx_mgpu **out) {
     PMX_ABI_BEGIN("pmx_mgpu_create")
     if (!cfg || !out) return set_error(PMX_ERR_ARG, "pmx_mgpu_create: null pointer");
@@ -167,8 +205,10 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
     const int visible = pmx_device_count();
     if (visible == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
     if (int rc = rccl_ready()) return rc;
-    if (n_devices <= 0 || n_devices > visible || n_devices > PMX_MAX_LOCAL_DEVICES)
-        return set_error(PMX_ERR_ARG, "n_devices %d out of range [1,%d]", n_devices, visible < PMX_MAX_LOCAL_DEVICES ? visible : PMX_MAX_LOCAL_DEVICES);
+    const bool shared = g_hooks.shared_device.load();   // test hook: slots may share a device (never set in production)
+    const int max_slots = shared || visible > PMX_MAX_LOCAL_DEVICES ? PMX_MAX_LOCAL_DEVICES : visible;
+    if (n_devices <= 0 || n_devices > max_slots) return set_error(PMX_ERR_ARG, "n_devices %d out of range [1,%d]", n_devices, max_slots);
+    if (shared && !devices) return set_error(PMX_ERR_ARG, "shared-device groups (test hook) name their devices explicitly");
     GroupHolder hold{new (std::nothrow) pmx_mgpu()};
     pmx_mgpu *g = hold.g;
     if (!g) return set_error(PMX_ERR_HOST, "out of host memory");
@@ -181,7 +221,7 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
         const int d = devices ? devices[l] : l;
         g->device[l] = d;
         if (d < 0 || d >= visible) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", d, visible);
-        for (int k = 0; k < l; ++k)
+        for (int k = 0; k < l && !shared; ++k)
             if (g->device[k] == d) return set_error(PMX_ERR_ARG, "device %d listed twice", d);
     }
     int rc = group_contexts(g, cfg);
@@ -274,21 +314,6 @@ extern "C" int pmx_mgpu_synchronize(pmx_mgpu *g) {
     PMX_ABI_END
 }
 
-// Test hook (tests/test_gpu_mgpu.py): makes the host fan-out of the next calls fail on one local device and / or behave
-// as if no worker thread could be started, so that the error carry-back and the serial path run on a one-GPU box too.
-namespace {
-struct Fault {
-    int fail_local = -1;
-    bool no_threads = false;
-};
-Fault g_fault;
-}  // namespace
-extern "C" int pmx_mgpu_test_fault(int fail_local, int no_threads) {
-    g_fault.fail_local = fail_local;
-    g_fault.no_threads = no_threads != 0;
-    return PMX_OK;
-}
-
 static int local_span(const pmx_mgpu *g, size_t n_total, size_t l, size_t *start, size_t *count) {
     return pmx_shard_bounds(n_total, g->world, g->first_rank + (int)l, start, count);
 }
@@ -318,35 +343,47 @@ static int fan_out(pmx_mgpu *g, size_t n, const char *who, Work work) {
     const size_t L = g->ctx.size();
     std::vector<int> rcs(L, PMX_OK);
     std::vector<std::string> msgs(L);
-    auto run = [&](size_t l) {
-        size_t start = 0, count = 0;
-        int rc = local_span(g, n, l, &start, &count);
-        if (!rc && count) {
-            if (g_fault.fail_local == (int)l) rc = set_error(PMX_ERR_HIP, "injected failure (pmx_mgpu_test_fault)");
-            else rc = work(l, start, count);
+    // runs on worker threads: nothing may leave it by exception (an exception that escapes a thread function is
+    // std::terminate, and the caller's PMX_ABI_BEGIN guard is on another stack)
+    auto run = [&](size_t l) noexcept {
+        int rc = PMX_OK;
+        try {
+            size_t start = 0, count = 0;
+            rc = local_span(g, n, l, &start, &count);
+            if (!rc && count) {
+                if (g_hooks.fail_local.load() == (int)l) rc = set_error(PMX_ERR_HIP, "injected failure (pmx_mgpu_test_fault)");
+                else rc = work(l, start, count);
+            }
+            if (rc) msgs[l] = pmx_last_error();   // the error text is thread-local: carry it back to the caller's thread
+        } catch (...) {
+            rc = PMX_ERR_HOST;                    // (msgs[l] may be what could not be allocated: the code alone goes back)
         }
         rcs[l] = rc;
-        if (rc) msgs[l] = pmx_last_error();   // the error text is thread-local: carry it back to the caller's thread
     };
     // one host thread per further device; a thread that cannot be started (std::system_error) is not fatal: its shard
-    // runs on the calling thread instead, after the ones that did start
-    std::vector<std::thread> workers;
+    // runs on the calling thread instead, after the ones that did start.  The workers are joined on every way out of
+    // this frame (destroying a joinable std::thread is std::terminate).
+    struct Workers {
+        std::vector<std::thread> th;
+        void join() { for (auto &w : th) if (w.joinable()) w.join(); }
+        ~Workers() { join(); }
+    } workers;
     std::vector<size_t> serial;
-    workers.reserve(L);
+    workers.th.reserve(L);
     serial.reserve(L);
     for (size_t l = 1; l < L; ++l) {
         try {
-            if (g_fault.no_threads) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
-            workers.emplace_back(run, l);
+            if (g_hooks.no_threads.load()) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+            workers.th.emplace_back(run, l);
         } catch (const std::system_error &) {
             serial.push_back(l);
         }
     }
     run(0);
     for (size_t l : serial) run(l);
-    for (auto &w : workers) w.join();
+    workers.join();
     for (size_t l = 0; l < L; ++l)
-        if (rcs[l]) return set_error(rcs[l], "device %d: %s", g->device[l], msgs[l].c_str());
+        if (rcs[l]) return set_error(rcs[l], "device %d (slot %zu): %s", g->device[l], l, msgs[l].empty() ? "host failure on the worker thread" : msgs[l].c_str());
     return PMX_OK;
 }
 

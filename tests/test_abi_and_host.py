@@ -17,8 +17,8 @@ from helpers import golden, oracle_config
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "poseidon_mi355x.h")).read()
+def declared_functions(header="poseidon_mi355x.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pmx_[a-z0-9_]+)\s*\(", text)))
 
@@ -30,7 +30,34 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.pmx_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.pmx_abi_version() == _lib.ABI_VERSION == 3
+    # the library's own test hooks have their own header and are not part of the product ABI
+    hooks = declared_functions("poseidon_mi355x_testing.h")
+    assert sorted(_lib.TEST_HOOK_SIGNATURES) == hooks and not set(hooks) & set(names)
+    for name in hooks:
+        assert hasattr(lib, name), name
+
+
+def test_test_hooks_are_inert_without_the_environment_variable():
+    """include/poseidon_mi355x_testing.h: in a process that was not started with PMX_TEST_HOOKS=1 the setters refuse and
+    change nothing; the Rust binding does not declare them."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from sponge_amd import _lib
+lib = _lib.lib()
+assert lib.pmx_test_hooks_enabled() == 0
+assert lib.pmx_mgpu_test_fault(0, 1) == _lib.PMX_ERR_UNSUPPORTED
+assert lib.pmx_mgpu_test_shared_device(1) == _lib.PMX_ERR_UNSUPPORTED
+assert b"PMX_TEST_HOOKS" in lib.pmx_last_error()
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "PMX_TEST_HOOKS"}
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
+    ffi = open(os.path.join(ROOT, "bindings", "rust", "src", "ffi.rs")).read()
+    assert "pmx_mgpu_test" not in ffi and "pmx_test_hooks" not in ffi
 
 
 def test_rust_binding_source_declares_the_whole_header():

@@ -2,10 +2,13 @@
 sharded permutation of host and device-resident batches, the RCCL gather, the sharded Merkle reduction - all against
 the C restatement - and the live communicator's own account of its ranks."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 import torch
+
+os.environ.setdefault("PMX_TEST_HOOKS", "1")      # the fault hook below is inert otherwise (poseidon_mi355x_testing.h)
 
 import sponge_amd as S
 from sponge_amd import _lib, mgpu, synth
@@ -152,7 +155,7 @@ def test_fan_out_carries_a_device_failure_back_to_the_caller():
         _lib.check(lib.pmx_mgpu_test_fault(last, 0))
         with pytest.raises(S.PmxError) as ei:
             g.permute_batch(states)
-        assert ei.value.code == _lib.PMX_ERR_HIP and f"device {g.devices[last]}: injected failure" in str(ei.value)
+        assert ei.value.code == _lib.PMX_ERR_HIP and f"device {g.devices[last]} (slot {last}): injected failure" in str(ei.value)
         msgs = synth.random_elements(cfg.field, 100 * 4, seed=1).reshape(100, 4, 4)
         with pytest.raises(S.PmxError, match="injected failure"):
             g.hash_batch(msgs, 4, 1)
