@@ -42,6 +42,25 @@ pub struct pmx_valu_peak {
     pub launches: c_int,
 }
 
+#[repr(C)]
+pub struct pmx_engine_info {
+    pub engine: [c_char; 64],
+    pub width: c_int,
+    pub threads: c_int,
+    pub waves_per_simd: c_int,
+    pub lds_bytes: c_int,
+    pub optimised: c_int,
+    pub row_tables: c_int,
+    pub lane_tables: c_int,
+    pub mfma_dense: c_int,
+    pub launches: c_int,
+}
+pub const PMX_OP_PERMUTE: c_int = 0;
+pub const PMX_OP_HASH: c_int = 1;
+pub const PMX_OP_COMPRESS: c_int = 2;
+pub const PMX_OP_ABSORB: c_int = 3;
+pub const PMX_OP_SQUEEZE: c_int = 4;
+
 pub const PMX_MODE_ABSORBING: u32 = 0;
 pub const PMX_MODE_SQUEEZING: u32 = 1;
 
@@ -65,6 +84,7 @@ extern "C" {
     pub fn pmx_abi_version() -> c_int;
     pub fn pmx_device_count() -> c_int;
     pub fn pmx_ctx_width(ctx: *const pmx_ctx) -> c_int;
+    pub fn pmx_ctx_engine_info(ctx: *const pmx_ctx, op: c_int, n: usize, len: usize, out: *mut pmx_engine_info) -> c_int;
     pub fn pmx_mont_constants(modulus: *const u64, inv: *mut u64, r: *mut u64, r2: *mut u64) -> c_int;
     pub fn pmx_to_mont(modulus: *const u64, elems: *mut u64, n: usize) -> c_int;
     pub fn pmx_from_mont(modulus: *const u64, elems: *mut u64, n: usize) -> c_int;

@@ -129,6 +129,31 @@ int pmx_ctx_cache_clear(void);
 /* width t = rate + capacity of the context's config */
 int pmx_ctx_width(const pmx_ctx *ctx);
 
+/* ---- which engine a call runs on --------------------------------------------------------------------
+ * The launchers pick a kernel family by width, exponent, schedule, modulus and batch size.  This
+ * reports the choice for one call, through the launchers' own conditions, so that a benchmark's instruction accounting
+ * cannot drift from the kernels: op = one of PMX_OP_*, n = units of the call (states, rows, compressions of one tree
+ * level, sponges), len = in_len / out_len of an absorb / squeeze call (ignored otherwise).  Host only; nothing is
+ * launched.  The reference has no counterpart (one code path, src/poseidon/mod.rs:95-118). */
+#define PMX_OP_PERMUTE 0
+#define PMX_OP_HASH 1
+#define PMX_OP_COMPRESS 2
+#define PMX_OP_ABSORB 3
+#define PMX_OP_SQUEEZE 4
+typedef struct pmx_engine_info {
+    char engine[64];     /* e.g. "RegEngine<3,5,opt,tab>", "HybridEngine<9,5,mfma>", "HybridEngine<9,5,mfma> x passes", "QuadEngine<5>" */
+    int width;           /* t */
+    int threads;         /* per workgroup */
+    int waves_per_simd;  /* the kernel's launch bound (what its register allocation is held to) */
+    int lds_bytes;       /* dynamic LDS per workgroup */
+    int optimised;       /* 1: optimised round schedule (sparse partial rounds, normalised layers), 0: the reference's dense one */
+    int row_tables;      /* 1: t-term matrix rows consume shifted tables (81 t + 18 multiplies), 0: element form (81 t + 81) */
+    int lane_tables;     /* 1: identity-lane updates of the sparse layers consume shifted tables */
+    int mfma_dense;      /* 1: rows of the dense layers come from the matrix cores (int8 GEMM, pmx_mfma.hpp) */
+    int launches;        /* kernel launches of the call: 1, or the passes of an absorb / squeeze call on wide states */
+} pmx_engine_info;
+int pmx_ctx_engine_info(const pmx_ctx *ctx, int op, size_t n, size_t len, pmx_engine_info *out);
+
 /* ---- permutation ------------------------------------------------------------------------------
  * PoseidonSponge::permute (src/poseidon/mod.rs:95-118 with apply_ark :76-80, apply_s_box :63-74,
  * apply_mds :82-93) applied independently to n states, in place.  states: [n][t][4].

@@ -51,6 +51,17 @@ class PmxMgpuInfo(ctypes.Structure):
     ]
 
 
+OP_PERMUTE, OP_HASH, OP_COMPRESS, OP_ABSORB, OP_SQUEEZE = range(5)
+
+
+class PmxEngineInfo(ctypes.Structure):
+    _fields_ = [
+        ("engine", ctypes.c_char * 64), ("width", ctypes.c_int), ("threads", ctypes.c_int), ("waves_per_simd", ctypes.c_int),
+        ("lds_bytes", ctypes.c_int), ("optimised", ctypes.c_int), ("row_tables", ctypes.c_int), ("lane_tables", ctypes.c_int),
+        ("mfma_dense", ctypes.c_int), ("launches", ctypes.c_int),
+    ]
+
+
 class PmxValuPeak(ctypes.Structure):
     _fields_ = [
         ("lane_mads_per_s", ctypes.c_double), ("lane_mads_per_s_vcc", ctypes.c_double),
@@ -87,6 +98,7 @@ SIGNATURES = {
     "pmx_ctx_release": (ctypes.c_int, [ctypes.c_void_p]),
     "pmx_ctx_cache_clear": (ctypes.c_int, []),
     "pmx_ctx_width": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_ctx_engine_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _sz, _sz, ctypes.POINTER(PmxEngineInfo)]),
     "pmx_permute_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz]),
     "pmx_permute_batch_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, ctypes.c_void_p]),
     "pmx_hash_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p, _sz, _sz]),

@@ -322,6 +322,12 @@ extern "C" int pmx_ctx_cache_clear(void) {
 
 extern "C" int pmx_ctx_width(const pmx_ctx *ctx) { return ctx ? (int)ctx->t : 0; }
 
+extern "C" int pmx_ctx_engine_info(const pmx_ctx *ctx, int op, size_t n, size_t len, pmx_engine_info *out) {
+    if (!ctx || !out) return set_error(PMX_ERR_ARG, "pmx_ctx_engine_info: null pointer");
+    if (describe_launch(ctx->dev, ctx->t, op, n, len, out) != hipSuccess) return set_error(PMX_ERR_ARG, "pmx_ctx_engine_info: unknown op %d", op);
+    return PMX_OK;
+}
+
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 // ---- pinned host memory ----------------------------------------------------------------------------

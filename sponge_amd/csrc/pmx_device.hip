@@ -22,11 +22,15 @@
 //   squeeze        src/poseidon/mod.rs:321-341 + squeeze_internal :153-182
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstring>
+
 #include "../../include/poseidon_mi355x.h"
 #include "pmx_field.hpp"
 #include "pmx_internal.hpp"
 #include "pmx_launch.hpp"
 #include "pmx_permute.hpp"
+#include "pmx_sponge_plan.hpp"
 
 // The file is compiled three times (Makefile, in parallel): PMX_TU = 0 holds the t = 3 engine, the run-time-width
 // engine, the cooperative kernel and the public launchers; PMX_TU = 1 / 2 hold the hybrid engines for alpha = 5 and
@@ -200,6 +204,14 @@ struct RegEngine {
 #pragma unroll
             for (int w = 0; w < kN; ++w) s[k].l[w] = (i == (uint32_t)k) ? v.l[w] : s[k].l[w];
         }
+    }
+
+    static void describe(EngineInfo &o) {
+        std::snprintf(o.engine, sizeof o.engine, "RegEngine<%d,%d,%s>", T, ALPHA, TAB ? "opt,tab" : OPT ? "opt" : "dense");
+        o.threads = kThreads;
+        o.optimised = OPT;
+        o.row_tables = o.lane_tables = TAB;
+        o.mfma_dense = 0;
     }
 
     // lanes [want_lo, want_hi) of the result are all the caller will read (see permute_opt); default: the whole state
@@ -430,6 +442,40 @@ struct HybridEngine {
 
 #endif
 
+    // store_states for the sponges of this wave whose `keep` is set (sponge_pass_kernel: the permutation ran for the whole
+    // workgroup, only the sponges that needed it take its result).  Staged through the wave's region like store_states: a
+    // 16-byte write instruction covers whole states, so the predicate travels as the wave's ballot.
+    __device__ __forceinline__ void store_states_where(uint64_t *g_states, size_t n, bool keep) {
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+        const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
+        const size_t valid = n > first ? (n - first < (size_t)64 ? n - first : (size_t)64) : 0;
+        uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * kChunks;
+        const uint32_t n_chunks = (uint32_t)valid * kChunks;
+        __syncthreads();
+        static_for<0, T>([&](auto i) {
+            const Abi a = to_abi(s[i]);
+            region[lane * kChunks + 2 * i] = abi_lo(a);
+            region[lane * kChunks + 2 * i + 1] = abi_hi(a);
+            PMX_SCHED_FENCE();
+        });
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            const uint32_t q = lane + k * 64;
+            if (q < n_chunks && ((mask >> (q / kChunks)) & 1)) g[q] = region[q];
+        }
+        __syncthreads();
+    }
+
+    static void describe(EngineInfo &o) {
+        std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,%s>", T, ALPHA, MFMA ? "mfma" : "valu");
+        o.threads = kThreads;
+        o.optimised = 1;
+        o.row_tables = T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB;
+        o.lane_tables = T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB;
+        o.mfma_dense = MFMA;
+    }
+
     __device__ __forceinline__ Fe get(uint32_t i) const {
         Fe r = s[0];
         static_for<1, T>([&](auto k) {
@@ -550,6 +596,12 @@ struct LdsEngine {
             if (q < n_chunks) g[q] = st[q];
         }
         __syncthreads();
+    }
+
+    static void describe(EngineInfo &o) {
+        std::snprintf(o.engine, sizeof o.engine, "LdsEngine<%d>", ALPHA);
+        o.threads = kThreads;
+        o.optimised = o.row_tables = o.lane_tables = o.mfma_dense = 0;
     }
 
     __device__ __forceinline__ void permute(uint32_t /*want_lo*/ = 0, uint32_t /*want_hi*/ = PMX_MAX_WIDTH) {
@@ -1019,6 +1071,61 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
     }
 }
 
+// The absorb / squeeze driver of the wide states as wave-uniform PASSES (pmx_sponge_plan.hpp; mod.rs:121-182, 232-254,
+// 321-341).  Pass p: every lane moves chunk p-1 of its own sponge in global memory - input elements added into the rate
+// portion (field addition on the ABI residues, mod.rs:128,143) or rate elements copied out (mod.rs:159-170) -, then the
+// workgroup permutes if any of its sponges needs permutation p, and only those sponges take the result.  The last pass
+// moves the last chunk and rewrites the mode words (mod.rs:130-132, 162-164); until then every pass re-derives its share
+// from the ORIGINAL mode words.  Nothing per-lane is live across the permutation, so this is permute_kernel's register
+// allocation - and its matrix-core rows at t = 7..9.
+template <class Engine, bool SQUEEZE>
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
+    sponge_pass_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
+                       uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len,
+                       size_t n, uint32_t pass, uint32_t last_pass) {
+    const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
+    const bool active = gid < n;
+    const uint32_t rate = d.rounds.rate, capacity = d.rounds.capacity, t_all = rate + capacity;
+    auto plan = [&]() {
+        SpongePass sp;
+        sp.permute = false;
+        sp.count = 0;
+        if (active) {
+            const uint32_t tag = mode_tag[gid], index = mode_index[gid];
+            sp = SQUEEZE ? squeeze_pass(tag, index, len, rate, capacity, pass) : absorb_pass(tag, index, len, rate, capacity, pass);
+        }
+        return sp;
+    };
+    {
+        const SpongePass sp = plan();
+        if (sp.count) {
+            uint32_t *st = reinterpret_cast<uint32_t *>(states + (gid * t_all + sp.state_pos) * 4);
+            uint32_t *row = reinterpret_cast<uint32_t *>(io + (gid * len + sp.first) * 4);
+            for (uint32_t j = 0; j < sp.count; ++j) {
+                if constexpr (SQUEEZE) {
+                    abi_store(row + 8 * j, abi_load(st + 8 * j));
+                } else {
+                    // state[capacity + i] += element: both fully reduced residues, the sum reduced exactly (no multiplication)
+                    const Fe sum = fe_normalize(fe_add_lazy(fe_from_abi_scaled(abi_load(st + 8 * j)), fe_from_abi_scaled(abi_load(row + 8 * j))));
+                    abi_store(st + 8 * j, fe_to_abi_scaled(sum, d.field));
+                }
+            }
+        }
+        if (pass == last_pass) {      // wave-uniform (kernel arguments)
+            if (active) {
+                mode_tag[gid] = SQUEEZE ? PMX_MODE_SQUEEZING : PMX_MODE_ABSORBING;
+                mode_index[gid] = sp.end_index;
+            }
+            return;
+        }
+        if (!__syncthreads_or(sp.permute ? 1 : 0)) return;   // no sponge of this workgroup permutes in this pass
+    }
+    Engine e(d, consts);
+    e.load_states(states, n);
+    e.permute(0, e.c.rate + e.c.capacity);
+    e.store_states_where(states, n, plan().permute);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
@@ -1061,6 +1168,29 @@ struct Launch {
         hipLaunchKernelGGL(squeeze_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
                            c.consts, states, tag, index, out, out_len, n);
         return hipGetLastError();
+    }
+    // the whole absorb / squeeze call as passes of sponge_pass_kernel (pmx_sponge_plan.hpp)
+    template <bool SQUEEZE>
+    static hipError_t sponge_passes(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index, uint64_t *io,
+                                    size_t len, size_t n, hipStream_t st) {
+        const size_t passes = SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate);
+        allow_lds(sponge_pass_kernel<Engine, SQUEEZE>, Engine::lds_bytes(c, t));
+        for (size_t p = 0; p < passes; ++p) {
+            hipLaunchKernelGGL((sponge_pass_kernel<Engine, SQUEEZE>), dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
+                               c.consts, states, tag, index, io, len, n, (uint32_t)p, (uint32_t)(passes - 1));
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    // what a launch of `op` would run on (pmx_ctx_engine_info): filled by the engine, completed per kernel family here
+    static hipError_t describe(const DevConfig &c, uint32_t t, int op, size_t len, EngineInfo *o) {
+        Engine::describe(*o);
+        const bool driver = op == PMX_OP_ABSORB || op == PMX_OP_SQUEEZE;
+        o->waves_per_simd = driver ? Engine::kMinWavesDriver : Engine::kMinWaves;
+        o->lds_bytes = (uint32_t)Engine::lds_bytes(c, t);
+        o->launches = 1;
+        return hipSuccess;
     }
 };
 
@@ -1111,13 +1241,64 @@ hipError_t PMX_HYB_NAME(compress)(const DevConfig &c, uint32_t t, const uint64_t
     PMX_HYB_MFMA(compress(c, t, in, out, n, st));
     PMX_HYB_DISPATCH(compress(c, t, in, out, n, st));
 }
+// absorb / squeeze: widths from PMX_HYB_PASS_MIN_T up run as passes on the permutation engine of their width (the matrix-core
+// one where the config has its tables) - measured against the per-lane-loop kernels in profiles/r04; below it the
+// per-lane-loop kernels absorb_kernel / squeeze_kernel.  (Set it to 10 for the round-3 behaviour.)
+#ifndef PMX_HYB_PASS_MIN_T
+#define PMX_HYB_PASS_MIN_T 4
+#endif
+template <int W>
+static bool hyb_use_mfma(const DevConfig &c, uint32_t t) {
+    if constexpr (W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T) return c.mfma_dense && lds_fits_engine<HybridEngine<W, PMX_HYB_ALPHA, true>>(c, t);
+    else return false;
+}
+template <int W, bool SQUEEZE>
+static hipError_t hyb_driver(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index, uint64_t *io, size_t len,
+                             size_t n, hipStream_t st) {
+    if constexpr (W >= PMX_HYB_PASS_MIN_T) {
+        if constexpr (W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T) {
+            if (hyb_use_mfma<W>(c, t))
+                return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::template sponge_passes<SQUEEZE>(c, t, states, tag, index, io, len, n, st);
+        }
+        return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::template sponge_passes<SQUEEZE>(c, t, states, tag, index, io, len, n, st);
+    } else {
+        if constexpr (SQUEEZE) return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::squeeze(c, t, states, tag, index, io, len, n, st);
+        else return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::absorb(c, t, states, tag, index, io, len, n, st);
+    }
+}
+#define PMX_HYB_DRIVER(SQ, IO)                                                     \
+    switch (t) {                                                                   \
+        case 4: return hyb_driver<4, SQ>(c, t, states, tag, index, IO, len, n, st); \
+        case 5: return hyb_driver<5, SQ>(c, t, states, tag, index, IO, len, n, st); \
+        case 6: return hyb_driver<6, SQ>(c, t, states, tag, index, IO, len, n, st); \
+        case 7: return hyb_driver<7, SQ>(c, t, states, tag, index, IO, len, n, st); \
+        case 8: return hyb_driver<8, SQ>(c, t, states, tag, index, IO, len, n, st); \
+        case 9: return hyb_driver<9, SQ>(c, t, states, tag, index, IO, len, n, st); \
+        default: return hipErrorInvalidValue;                                      \
+    }
 hipError_t PMX_HYB_NAME(absorb)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                                const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {
-    PMX_HYB_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st));
+                                const uint64_t *in, size_t len, size_t n, hipStream_t st) {
+    PMX_HYB_DRIVER(false, const_cast<uint64_t *>(in));   // (the absorb form of the pass kernel only reads `io`)
 }
 hipError_t PMX_HYB_NAME(squeeze)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                                 uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
-    PMX_HYB_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
+                                 uint64_t *out, size_t len, size_t n, hipStream_t st) {
+    PMX_HYB_DRIVER(true, out);
+}
+// pmx_ctx_engine_info for the hybrid family: the very conditions of the launchers above
+hipError_t PMX_HYB_NAME(describe)(const DevConfig &c, uint32_t t, int op, size_t len, EngineInfo *o) {
+    const bool driver = op == PMX_OP_ABSORB || op == PMX_OP_SQUEEZE;
+    const bool passes = driver && (int)t >= PMX_HYB_PASS_MIN_T;
+    hipError_t e = hipErrorInvalidValue;
+    const int op_engine = passes ? PMX_OP_PERMUTE : op;        // a pass is the permutation engine's launch
+    auto plain = [&]() -> hipError_t { PMX_HYB_DISPATCH(describe(c, t, op_engine, len, o)); };
+    auto fast = [&]() -> hipError_t { PMX_HYB_MFMA(describe(c, t, op_engine, len, o)); return hipErrorInvalidValue; };
+    if (!driver || passes) e = fast();
+    if (e != hipSuccess) e = plain();
+    if (e == hipSuccess && passes) {
+        o->launches = (int)(op == PMX_OP_SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate));
+        std::snprintf(o->engine + std::strlen(o->engine), sizeof o->engine - std::strlen(o->engine), " x passes");
+    }
+    return e;
 }
 
 #else  // PMX_TU == 0
@@ -1127,7 +1308,8 @@ hipError_t PMX_HYB_NAME(squeeze)(const DevConfig &c, uint32_t t, uint64_t *state
     hipError_t P##hash(const DevConfig &, uint32_t, const uint64_t *, size_t, uint64_t *, size_t, size_t, hipStream_t);          \
     hipError_t P##compress(const DevConfig &, uint32_t, const uint64_t *, uint64_t *, size_t, hipStream_t);                      \
     hipError_t P##absorb(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, const uint64_t *, size_t, size_t, hipStream_t); \
-    hipError_t P##squeeze(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint64_t *, size_t, size_t, hipStream_t);
+    hipError_t P##squeeze(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint64_t *, size_t, size_t, hipStream_t); \
+    hipError_t P##describe(const DevConfig &, uint32_t, int, size_t, EngineInfo *);
 PMX_HYB_DECL(hybrid5_)
 PMX_HYB_DECL(hybridg_)
 
@@ -1253,6 +1435,40 @@ hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
     PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st));
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
+}
+
+// ---- pmx_ctx_engine_info: the same conditions, describing instead of launching ------------------------------------------
+static hipError_t describe_quad(const DevConfig &c, EngineInfo *o) {
+    std::snprintf(o->engine, sizeof o->engine, "QuadEngine<%d>", c.rounds.alpha == 5 ? 5 : c.rounds.alpha == 17 ? 17 : 0);
+    o->threads = 256;            // 64 states, one per quad of lanes
+    o->waves_per_simd = 2;       // __launch_bounds__(256, 2)
+    o->lds_bytes = (uint32_t)QuadEngine<0>::lds_bytes(c);
+    o->optimised = 1;            // element form, sparse rounds folded three multiplications deep
+    o->launches = 1;
+    return hipSuccess;
+}
+hipError_t describe_launch(const DevConfig &c, uint32_t t, int op, size_t n, size_t len, EngineInfo *o) {
+    std::memset(o, 0, sizeof *o);
+    o->width = (int)t;
+    switch (op) {
+        case PMX_OP_PERMUTE:
+            if (quad_table(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) return describe_quad(c, o);
+            PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
+            break;
+        case PMX_OP_HASH:
+        case PMX_OP_ABSORB:
+        case PMX_OP_SQUEEZE:
+            if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) return describe_quad(c, o);
+            PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
+            break;
+        case PMX_OP_COMPRESS:
+            if (quad_shape(c, t) && n <= kCoopMaxUnits) return describe_quad(c, o);
+            PMX_SMALL_BATCH(kTabMinCompress, describe(c, t, op, len, o));
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    PMX_DISPATCH(describe(c, t, op, len, o));
 }
 
 // ---- authentication paths (pmx_merkle_verify_paths_dev) --------------------------------------------------------------

@@ -2,9 +2,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/poseidon_mi355x.h"
 #include "pmx_internal.hpp"
 
 namespace pmx {
+
+using EngineInfo = ::pmx_engine_info;
+// pmx_ctx_engine_info: the engine `op` over n units would be launched on, decided by the launchers' own conditions
+hipError_t describe_launch(const DevConfig &c, uint32_t t, int op, size_t n, size_t len, EngineInfo *o);
 
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st);
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,

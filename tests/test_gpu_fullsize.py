@@ -54,6 +54,46 @@ def test_c3_full_batch_2e18_bn254_t9_alpha5():
     assert np.array_equal(got, want)
 
 
+def test_c3_wide_sponge_driver_2e18_hash_8_to_1_through_absorb_and_squeeze():
+    """The absorb / squeeze batch driver at BASELINE configs[2]'s size: 2^18 fresh BN254 Fr t = 9 sponges, device-resident
+    with explicit mode words, absorb(8) then squeeze_native(1) - `new; absorb; squeeze` per row, mod.rs:219-254, 321-341 -
+    the whole batch against the C port's hash rows; then absorb(11) + squeeze(9) into the same sponges (now Squeezing{1}:
+    every one permutes first) against the C port run on a sample sponge by sponge."""
+    name = "bn254_t9_a5_8_57"
+    cfg = product_config(name)
+    cr = c_oracle(name)
+    n, t, r = 1 << 18, 9, 8
+    st = torch.zeros((n, t, 4), dtype=torch.int64, device="cuda:0")
+    tag = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    idx = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    msgs = synth.random_elements(cfg.field, n * r, seed=0x5EED0009).reshape(n, r, 4)
+    d_in = dev_tensor(msgs)
+    d_out = torch.zeros((n, 1, 4), dtype=torch.int64, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = cfg.context()
+    ctx.sponge_absorb_batch_dev(st.data_ptr(), tag.data_ptr(), idx.data_ptr(), d_in.data_ptr(), r, n, stream)
+    torch.cuda.synchronize()
+    assert int(tag.max()) == 0 and int(idx.min()) == int(idx.max()) == r      # the rate filled exactly: no permutation yet
+    ctx.sponge_squeeze_batch_dev(st.data_ptr(), tag.data_ptr(), idx.data_ptr(), d_out.data_ptr(), 1, n, stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_numpy(d_out).reshape(n, 1, 4), cr.hash_batch(msgs, r, 1, threads=0))
+    assert int(tag.min()) == 1 and int(idx.min()) == int(idx.max()) == 1
+    before = to_numpy(st).reshape(n, t, 4).copy()
+    more = synth.random_elements(cfg.field, n * 11, seed=0x5EED000A).reshape(n, 11, 4)
+    d_more = dev_tensor(more)
+    d_out9 = torch.zeros((n, 9, 4), dtype=torch.int64, device="cuda:0")
+    ctx.sponge_absorb_batch_dev(st.data_ptr(), tag.data_ptr(), idx.data_ptr(), d_more.data_ptr(), 11, n, stream)
+    ctx.sponge_squeeze_batch_dev(st.data_ptr(), tag.data_ptr(), idx.data_ptr(), d_out9.data_ptr(), 9, n, stream)
+    torch.cuda.synchronize()
+    after, out9 = to_numpy(st).reshape(n, t, 4), to_numpy(d_out9).reshape(n, 9, 4)
+    sample = np.unique(np.concatenate([np.arange(300), np.arange(n - 300, n), np.linspace(0, n - 1, 400).astype(np.int64)]))
+    for j in sample:
+        s, m, i = cr.sponge_absorb(before[j], 1, 1, more[j])
+        s, m, i, o = cr.sponge_squeeze(s, m, i, 9)
+        assert np.array_equal(after[j], s) and np.array_equal(out9[j], o), j
+        assert (int(tag[j]), int(idx[j])) == (m, i), j
+
+
 def test_c5_merkle_2e20_leaves_root_and_decomposition():
     """Level-by-level tree on the GPU; root == root rebuilt from 8 subtree roots (the multi-GPU split);
     lowest level == 2-to-1 compression == permute([0, l, r])[capacity] checked against the restatement."""

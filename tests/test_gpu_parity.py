@@ -296,7 +296,7 @@ def test_t9_dense_layers_on_and_off_the_matrix_cores(field_name, modulus):
     leaves = synth.random_elements(f, 512, seed=6)
     nodes, _ = cfg.context().merkle_2to1(leaves)
     assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
-    # the per-lane drivers (absorb / squeeze) stay on the element-form rows at every modulus: new; absorb(11); squeeze(9) = a hash row
+    # the absorb / squeeze drivers (passes on the same engines, tests/test_gpu_sponge_passes.py): new; absorb(11); squeeze(9) = a hash row
     msgs = synth.random_elements(f, 130 * 11, seed=7).reshape(130, 11, 4)
     b = S.BatchPoseidonSponge.new(cfg, 130)
     b.absorb(msgs)

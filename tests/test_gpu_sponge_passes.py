@@ -1,0 +1,119 @@
+"""The absorb / squeeze batch driver on wide states (t = 4..9): passes of a wave-uniform permutation kernel
+(sponge_amd/csrc/pmx_sponge_plan.hpp, pmx_device.hip: sponge_pass_kernel) instead of a per-lane state machine, so that the
+driver runs on the permutation engine of its width - the matrix-core one at t = 7..9.
+
+Reference semantics: absorb src/poseidon/mod.rs:232-254 + absorb_internal :121-150; squeeze_native_field_elements
+:321-341 + squeeze_internal :153-182 (incl. the `!= rate` test of :175).  Every sponge is checked against the C
+restatement run sponge by sponge; all calls go through the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before the library touches HIP: torch bundles its own HIP runtime and must be the first to load one)
+
+import sponge_amd as S
+from sponge_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+PALLAS = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001
+P25519 = (1 << 255) - 19
+# (field name, modulus, prime bits, rate, alpha, RF, RP, expect the matrix-core engine)
+CASES = [
+    ("bn254_fr", None, 254, 8, 5, 8, 57, True),          # BASELINE configs[2]'s width
+    ("bls12_381_fr", None, 255, 8, 17, 8, 57, True),     # the generic-exponent build of the hybrid engines
+    ("bls12_381_fr", None, 255, 7, 5, 8, 57, True),
+    ("bls12_381_fr", None, 255, 6, 5, 8, 57, True),
+    ("pallas_fp", PALLAS, 255, 8, 5, 8, 57, True),       # a third field on the matrix-core side of the modulus rule ...
+    ("p25519", P25519, 255, 8, 5, 8, 57, False),         # ... and one on the other (top byte 127: VALU rows)
+    ("bls12_381_fr", None, 255, 5, 5, 8, 57, False),     # t = 6, 5, 4: passes on the VALU-row engines
+    ("bls12_381_fr", None, 255, 4, 5, 8, 56, False),
+    ("bls12_381_fr", None, 255, 3, 3, 8, 56, False),
+]
+
+
+def _config(field_name, modulus, bits, rate, alpha, rf, rp):
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.FIELDS[field_name] if modulus is None else S.Field(field_name, modulus)
+    p = f.modulus
+    return f, S.poseidon_config_from_lfsr(f, rate, alpha, rf, rp), cref.CRef(O.make_config(p, bits, rate, alpha, rf, rp))
+
+
+def _engine_info(cfg, op, n, length):
+    info = _lib.PmxEngineInfo()
+    _lib.check(_lib.lib().pmx_ctx_engine_info(cfg.context()._h, op, n, length, ctypes.byref(info)))
+    return info
+
+
+@pytest.mark.parametrize("layout", ["random", "blocks"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-t{c[3] + 1}-a{c[4]}")
+def test_wide_driver_mixed_modes_vs_c_oracle(case, layout):
+    """n sponges (more than two workgroups, the last one ragged) in different modes and positions advance together
+    through absorbs and squeezes of every interesting length: longer than the rate, exactly the rate (the lazy
+    permutation; on the squeeze side the `:175` case), one element, nothing (squeeze(0) of an absorbing sponge
+    permutes), several rates.  `blocks`: whole workgroups in ONE mode, so that some workgroups skip a pass others take."""
+    field_name, modulus, bits, rate, alpha, rf, rp, mfma = case
+    f, cfg, cr = _config(field_name, modulus, bits, rate, alpha, rf, rp)
+    t, r = rate + 1, rate
+    n = 2 * 256 + 77
+    info = _engine_info(cfg, _lib.OP_ABSORB, n, r + 3)
+    assert b"passes" in info.engine and bool(info.mfma_dense) == mfma and info.launches == 1 + -(-(r + 3) // r), (info.engine, info.launches)
+    assert _engine_info(cfg, _lib.OP_PERMUTE, n, 0).mfma_dense == int(mfma)
+    rng = np.random.default_rng(1000 * rate + alpha)
+    batch = S.BatchPoseidonSponge.new(cfg, n)
+    batch.state = synth.random_elements(f, n * t, seed=7 + rate).reshape(n, t, 4)
+    if layout == "random":
+        batch.mode_tag = rng.integers(0, 2, n).astype(np.uint32)
+        batch.mode_index = rng.integers(0, r + 1, n).astype(np.uint32)
+    else:
+        tag = np.zeros(n, dtype=np.uint32)
+        idx = np.zeros(n, dtype=np.uint32)
+        tag[256:512] = 1                       # workgroup 1: Squeezing{rate} (permutes first), workgroup 0: Absorbing{0} (does not)
+        idx[256:512] = r
+        tag[512:] = rng.integers(0, 2, n - 512)
+        idx[512:] = rng.integers(0, r + 1, n - 512)
+        batch.mode_tag, batch.mode_index = tag, idx
+    ref = [(batch.state[i].copy(), int(batch.mode_tag[i]), int(batch.mode_index[i])) for i in range(n)]
+    ops = [("absorb", r + 1), ("squeeze", r), ("squeeze", 0), ("absorb", r), ("squeeze", 1), ("absorb", 1), ("squeeze", 2 * r + 1),
+           ("squeeze", r), ("absorb", 2 * r + 2), ("absorb", 0), ("squeeze", r - 1)]
+    for step, (op, length) in enumerate(ops):
+        if op == "absorb":
+            elems = synth.random_elements(f, n * max(length, 1), seed=100 + step).reshape(n, max(length, 1), 4)[:, :length]
+            batch.absorb(np.ascontiguousarray(elems))
+            if length:
+                ref = [cr.sponge_absorb(s, m, i, elems[j]) for j, (s, m, i) in enumerate(ref)]
+        else:
+            out = batch.squeeze_native_field_elements(length)
+            nxt = []
+            for j, (s, m, i) in enumerate(ref):
+                s2, m2, i2, o = cr.sponge_squeeze(s, m, i, length)
+                assert np.array_equal(out[j], o), (op, length, step, j)
+                nxt.append((s2, m2, i2))
+            ref = nxt
+        want_state = np.stack([s for s, _, _ in ref])
+        bad = np.nonzero((batch.state != want_state).any(axis=(1, 2)))[0]
+        assert bad.size == 0, (op, length, step, bad[:8])
+        assert [int(x) for x in batch.mode_tag] == [m for _, m, _ in ref], (op, length, step)
+        assert [int(x) for x in batch.mode_index] == [i for _, _, i in ref], (op, length, step)
+
+
+def test_wide_driver_device_resident_modes_out_of_range_are_clamped():
+    """Device-resident mode words are not validated by the host (the host-buffer entry points are): an index above the rate
+    behaves as the rate, exactly as in the per-lane kernels (pmx_device.hip: absorb_kernel)."""
+    f, cfg, cr = _config("bn254_fr", None, 254, 8, 5, 8, 57)
+    n, t, r = 300, 9, 8
+    st = synth.random_elements(f, n * t, seed=21).reshape(n, t, 4)
+    tag = np.zeros(n, dtype=np.int32)
+    idx = np.full(n, r + 5, dtype=np.int32)
+    idx[::2] = r
+    elems = synth.random_elements(f, n * 3, seed=22).reshape(n, 3, 4)
+    d_st, d_tag, d_idx = (torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x).to("cuda:0") for x in (st.copy(), tag, idx))
+    d_in = torch.from_numpy(elems.view(np.int64).copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    cfg.context().sponge_absorb_batch_dev(d_st.data_ptr(), d_tag.data_ptr(), d_idx.data_ptr(), d_in.data_ptr(), 3, n, 0)
+    torch.cuda.synchronize()
+    got = d_st.cpu().numpy().view(np.uint64)
+    for j in range(n):
+        s, m, i = cr.sponge_absorb(st[j], 0, r, elems[j])
+        assert np.array_equal(got[j], s) and int(d_idx[j]) == i == 3 and int(d_tag[j]) == 0, j

@@ -390,3 +390,99 @@ def test_odd_full_rounds_follow_the_reference_split(hc, rate, rf, rp):
             assert cref.limbs_to_elems(out, p) == want, fn.__name__
         else:
             assert rc != 0, fn.__name__
+
+
+# ---- the absorb / squeeze driver as passes (sponge_amd/csrc/pmx_sponge_plan.hpp) -----------------------------------------------
+class _ToySponge(O.PoseidonSponge):
+    """The oracle's sponge (mod.rs:121-182, 232-254, 321-341) over a toy permutation that makes the NUMBER and the ORDER
+    of permutations visible in the state: every call mixes in a running counter."""
+
+    def _permute(self):
+        self.n_perm = getattr(self, "n_perm", 0) + 1
+        p = self.cfg.p
+        s = self.state
+        self.state = [(3 * s[(i + 1) % len(s)] + 7 * s[i] + i + 1) % p for i in range(len(s))]
+
+
+def _toy_cfg(rate, capacity):
+    t = rate + capacity
+    return O.PoseidonConfig(O.BLS12_381_FR, 2, 1, 5, [[0] * t for _ in range(3)], [[1] * t for _ in range(t)], rate, capacity)
+
+
+def _run_passes(hc, cfg, state, tag, index, squeeze, elems_or_len):
+    """What pmx_device.hip's launch loop + sponge_pass_kernel do for ONE sponge: pass p moves chunk p-1 in memory, then
+    permutes where the plan says; the mode words are read-only until the last pass."""
+    hc.hc_sponge_pass.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32,
+                                  ctypes.c_size_t, ctypes.c_void_p]
+    hc.hc_sponge_passes.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32]
+    hc.hc_sponge_passes.restype = ctypes.c_size_t
+    length = elems_or_len if squeeze else len(elems_or_len)
+    passes = hc.hc_sponge_passes(int(squeeze), length, cfg.rate)
+    toy = _ToySponge(cfg, list(state), tag, index)
+    out = [None] * length
+    n_perm = 0
+    plan = np.zeros(5, dtype=np.uint64)
+    end = None
+    moved = 0
+    for p in range(passes):
+        hc.hc_sponge_pass(int(squeeze), tag, index, length, cfg.rate, cfg.capacity, p, plan.ctypes.data)
+        permute, pos, first, count, end_index = (int(v) for v in plan)
+        assert (count == 0 or first == moved) and pos + count <= cfg.t, (p, plan)
+        for j in range(count):
+            if squeeze:
+                out[first + j] = toy.state[pos + j]
+            else:
+                toy.state[pos + j] = (toy.state[pos + j] + elems_or_len[first + j]) % cfg.p
+        moved += count
+        if p == passes - 1:
+            assert not permute, "the last pass only moves data and rewrites the mode words"
+            end = end_index
+        elif permute:
+            toy._permute()
+            n_perm += 1
+    assert moved == length
+    return toy.state, end, out, n_perm
+
+
+@pytest.mark.parametrize("rate,capacity", [(1, 1), (2, 1), (3, 2), (8, 1)])
+def test_sponge_pass_plan_reproduces_the_reference_driver(hc, rate, capacity):
+    """Every (mode, index, length) of absorb and squeeze: the pass plan must perform the same permutations in the same
+    order between the same data movements as the reference's absorb / absorb_internal / squeeze_native_field_elements /
+    squeeze_internal - the `:175` test, the lazy permutation of a rate filled exactly, squeeze(0) of an absorbing sponge,
+    an index equal to the rate, all included."""
+    cfg = _toy_cfg(rate, capacity)
+    rng = random.Random(rate * 16 + capacity)
+    for tag in (O.ABSORBING, O.SQUEEZING):
+        for index in range(rate + 1):
+            for length in range(0, 3 * rate + 3):
+                state = [rng.randrange(cfg.p) for _ in range(cfg.t)]
+                elems = [rng.randrange(cfg.p) for _ in range(length)]
+                ref = _ToySponge(cfg, list(state), tag, index)
+                ref.absorb(elems)
+                if length == 0:
+                    assert hc.hc_sponge_passes(0, 0, rate) == 0          # an empty absorb is no call at all (mod.rs:234-236)
+                else:
+                    got_state, end, _, n_perm = _run_passes(hc, cfg, state, tag, index, False, elems)
+                    assert got_state == ref.state and n_perm == getattr(ref, "n_perm", 0), ("absorb", tag, index, length)
+                    assert (ref.mode, ref.index) == (O.ABSORBING, end), ("absorb", tag, index, length)
+                ref = _ToySponge(cfg, list(state), tag, index)
+                want = ref.squeeze_native_field_elements(length)
+                got_state, end, out, n_perm = _run_passes(hc, cfg, state, tag, index, True, length)
+                assert out == want and got_state == ref.state and n_perm == getattr(ref, "n_perm", 0), ("squeeze", tag, index, length)
+                assert (ref.mode, ref.index) == (O.SQUEEZING, end), ("squeeze", tag, index, length)
+
+
+@pytest.mark.parametrize("p", [O.BLS12_381_FR, O.BN254_FR])
+def test_absorb_addition_on_abi_residues(hc, p):
+    """state[capacity + i] += element of the pass kernel: both operands are fully reduced Montgomery residues; their sum,
+    reduced exactly, is the residue of the sum (mod.rs:128,143) - no multiplication involved."""
+    rng = random.Random(p & 0xFFF)
+    mod = np.array(O.to_limbs(p), dtype=np.uint64)
+    cases = [(0, 0), (p - 1, p - 1), (p - 1, 1), (1, p - 1), (p - 1, 0), ((p - 1) // 2, (p + 1) // 2)]
+    cases += [(rng.randrange(p), rng.randrange(p)) for _ in range(200)]
+    for a, b in cases:
+        aa = np.array(O.to_limbs(a), dtype=np.uint64)      # raw residues: the ABI form IS the operand here
+        bb = np.array(O.to_limbs(b), dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        assert hc.hc_field_op(mod.ctypes.data, 4, aa.ctypes.data, bb.ctypes.data, out.ctypes.data) == 0
+        assert O.from_limbs([int(x) for x in out]) == (a + b) % p
