@@ -101,6 +101,9 @@ def parse_args():
                     help="N>1 permutation batches: 'final' = one RCCL all-gather of the result shards after the K steps (inside "
                          "the timed region); 'step' = an all-gather after EVERY step")
     ap.add_argument("--spinup-seconds", type=float, default=0.25, help="untimed device spin-up before the W warmup steps")
+    ap.add_argument("--allow-torch-gather", action="store_true",
+                    help="N>1: if the C ABI's device group (RCCL through pmx_mgpu_*) cannot be formed, gather through torch.distributed "
+                         "instead of exiting non-zero (a second code path: off by default, and the line says so when taken)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the all-cores cpu_baseline sample")
@@ -225,6 +228,14 @@ def main():
     # ---- per-run integer-VALU roofline of THIS device, before anything is timed -----------------------------------------
     peak = _lib.PmxValuPeak()
     _lib.check(_lib.lib().pmx_diag_int_valu_peak(local_rank, 0.1, peak))
+    slot = {}          # waves per SIMD -> in-run issue-slot measurement (pmx_diag_issue_slot), filled for the kernel's occupancy below
+
+    def issue_slot(waves):
+        if waves not in slot:
+            r = _lib.PmxIssueSlot()
+            _lib.check(_lib.lib().pmx_diag_issue_slot(local_rank, waves, 0.06, r))
+            slot[waves] = r
+        return slot[waves]
 
     # ---- the engine: one context at N = 1, the C ABI's device group (RCCL) at N > 1 -------------------------------------
     group, group_error, rccl = None, None, None
@@ -238,16 +249,30 @@ def main():
             info = group.info()
             rccl = {"ranks": info["comm_ranks"], "version": info["rccl_version_str"], "rank0_is": info["comm_first_rank"],
                     "via": "pmx_mgpu_create_rank (ncclCommInitRank); gather = pmx_mgpu_all_gather_dev (ncclAllGather)"}
-        except S.PmxError as e:          # still RCCL on the GPUs, through torch.distributed, and said so in the line
+        except S.PmxError as e:
             group_error = str(e)
-            rccl = {"ranks": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
-                    "via": "torch.distributed (the C ABI's device group failed: %s)" % group_error}
         ok = torch.tensor([1 if group is not None else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok) == 0 and group is not None:      # all ranks take the same path
-            group.close()
-            group = None
+        if int(ok) == 0:
+            # The product's gather is pmx_mgpu_all_gather_dev.  A run that cannot form the device group is a failed run, not a
+            # run on another code path - unless the caller asked for the torch.distributed gather explicitly.
+            if group is not None:      # all ranks take the same path
+                group.close()
+                group = None
+            if not args.allow_torch_gather:
+                sys.stderr.write("rank %d: the C ABI's device group could not be formed on every rank (%s); "
+                                 "--allow-torch-gather would gather through torch.distributed instead\n" % (rank, group_error or "another rank failed"))
+                dist.barrier()
+                dist.destroy_process_group()
+                sys.exit(4)
+            rccl = {"ranks": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                    "via": "torch.distributed, by --allow-torch-gather (the C ABI's device group failed: %s)" % (group_error or "on another rank")}
     ctx = cfg.context(local_rank)
+    if rank == 0:       # the issue slot at the dominant kernel's occupancy, measured before anything is timed
+        early = _lib.PmxEngineInfo()
+        _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, _lib.OP_COMPRESS if args.workload == "c5" else (_lib.OP_HASH if args.workload in HASH_SHAPES else _lib.OP_PERMUTE),
+                                                  (n // 2 if args.workload == "c5" else n), 0, early))
+        issue_slot(max(1, min(8, early.waves_per_simd)))
     if group is not None:
         stream = torch.cuda.ExternalStream(group.stream(0), device=dev)     # the library's stream of this device
     else:
@@ -383,23 +408,25 @@ def main():
             bytes_per_unit = (in_len + out_len) * 32 / perms_per_row
         algo_bytes = bytes_per_unit * per_gpu_units
         achieved = algo_bytes / kernel_s / 1e9
-        # engines as dispatched (pmx_device.hip): t = 3..9 run the optimised schedule, with every matrix as shifted tables up
-        # to t = 5 and the identity lanes only above.  ABI <-> internal conversions cost no multiplies there (the schedule's
-        # own scaling makes the ABI residue the internal form, pmx_field.hpp: fe_from_abi_scaled).
-        # t = 9, alpha = 5, permutation / hash / compression kernels: dense layers on the matrix cores when the modulus' top byte
-        # allows (pmx_prepare.hpp: mfma_dense; both benchmarked fields do)
-        mfma_dense = t == 9 and alpha == 5 and (field.modulus >> 248) <= 126
-        mads = mads_per_permutation(t, alpha, rf, rp, optimised=3 <= t <= 9, row_tables=3 <= t <= 5, lane_tables=3 <= t <= 9, mfma_dense=mfma_dense)
+        # The engine as the library's own launchers dispatch it for this call (pmx_ctx_engine_info: schedule, table forms,
+        # matrix-core rows, launch bound) - the instruction accounting below follows the kernels, not a copy of their rules.
+        # ABI <-> internal conversions cost no multiplies on the optimised schedule (pmx_field.hpp: fe_from_abi_scaled).
+        info = _lib.PmxEngineInfo()
+        op = _lib.OP_COMPRESS if merkle else (_lib.OP_HASH if hashing else _lib.OP_PERMUTE)
+        _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, op, (n // 2 if merkle else n), 0, info))
+        mfma_dense = bool(info.mfma_dense)
+        mads = mads_per_permutation(t, alpha, rf, rp, optimised=bool(info.optimised), row_tables=bool(info.row_tables),
+                                    lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense)
         # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
         # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
-        last_row = 20 if mfma_dense else 81 * t + (18 if 3 <= t <= 5 else 81)
+        last_row = 20 if mfma_dense else 81 * t + (18 if info.row_tables else 81)
         if merkle:
             mads -= (t - 1) * last_row
         elif hashing:
             mads -= (t - out_len) * last_row / perms_per_row
         mad_rate = mads * per_gpu_units / kernel_s
         traffic, traffic_src = load_traffic(args.workload, per_gpu_units)
-        valu_issue = load_valu_issue(args.workload, per_gpu_units, kernel_s, peak.compute_units, mads)
+        valu_issue = load_valu_issue(args.workload, per_gpu_units, kernel_s, peak.compute_units, mads, info, slot)
         out = {
             "metric": "Poseidon permutations/sec (%s, t=%d)" % ({"bls12_381_fr": "BLS12-381 Fr", "bn254_fr": "BN254 Fr"}[field_name], t),
             "value": value, "unit": "permutations/s",
@@ -414,6 +441,10 @@ def main():
                        "sharding": f"contiguous x{world}", **({"REHEARSAL": "ranks share one GPU, gloo: not a measurement"} if rehearsal else {}),
                        "series": "N=1 runs configs[1] (2^20 states); N>1 shard configs[3]'s 2^24 states (strong scaling)"
                                  if args.workload == "c2" and baseline_cfg else None},
+            "engine": {"name": info.engine.decode(), "threads_per_workgroup": info.threads, "waves_per_simd": info.waves_per_simd,
+                       "lds_bytes_per_workgroup": info.lds_bytes, "optimised_schedule": bool(info.optimised),
+                       "row_tables": bool(info.row_tables), "lane_tables": bool(info.lane_tables), "mfma_dense": mfma_dense,
+                       "source": "pmx_ctx_engine_info (the launchers' own dispatch conditions)" + (", widest level of the tree" if merkle else "")},
             "rccl": rccl,
             "verified": (verify["ok"] if verify else None), "verify": verify,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -554,41 +585,51 @@ def run_verification(env):
 
 def load_traffic(workload, per_gpu_units):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json); it
-    cannot be collected inside a timed run.  Only quoted when the profile was taken at this run's size."""
+    cannot be collected inside a timed run (counter collection serialises the kernels).  Only quoted when the profile was
+    taken at this run's size; otherwise the line says that nothing was measured for this workload."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
-        rec = json.load(open(path))[workload]
-        if "units_per_launch" in rec and abs(rec["units_per_launch"] - per_gpu_units) > 1:
-            return None, None
-        return rec["bytes_per_launch"], "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        recs = json.load(open(path))
+        rec = next((r for k, r in recs.items() if k.split("_")[0] == workload and abs(r.get("units_per_launch", per_gpu_units) - per_gpu_units) <= 1), None)
+        if rec is None:
+            return None, "not measured for this workload at this size"
+        return rec["bytes_per_launch"], ("profiles/hbm_traffic.json: a committed constant, not a measurement of this run (separate rocprofv3 --pmc "
+                                         "FETCH_SIZE / WRITE_SIZE passes of this command, %s)" % rec.get("taken", "round 3"))
     except Exception:
-        return None, None
+        return None, "not measured for this workload"
 
 
-def load_valu_issue(workload, per_gpu_units, kernel_s, compute_units, mads):
+def load_valu_issue(workload, per_gpu_units, kernel_s, compute_units, mads, info, slot):
     """The binding resource, one level below `int_valu`: a SIMD of this part takes ONE VALU instruction per ~4 shader clocks
     from any stream that holds multiplies, whatever the instruction is and whichever wave it comes from
     (tools/issue_model_microbench.hip -> profiles/r03/f_issue_model_microbench.txt), so a kernel's floor is its VALU
-    instruction count, not its multiply count.  The count per permutation comes from the committed SQ_INSTS_VALU pass of
-    this command (profiles/valu_instructions.json, tools/valu_slots.py); the time per instruction is this run's."""
-    path = os.path.join(ROOT, "profiles", "valu_instructions.json")
+    instruction count, not its multiply count.  The slot is measured IN THIS RUN on this device at the kernel's occupancy
+    (pmx_diag_issue_slot: three calibration streams, the fastest is the floor); the instruction count per permutation is a
+    property of the build and comes from the committed SQ_INSTS_VALU pass of this command (profiles/valu_instructions.json)."""
+    waves = max(1, min(8, info.waves_per_simd))
+    r = slot.get(waves)
+    out = {"bound": "VALU issue slots (one instruction per SIMD and ~4 clocks in a stream with multiplies)", "waves_per_simd": waves}
+    if r is not None:
+        out["calibration_ns_per_instruction_and_simd"] = {"12 mad + 4 simple (the kernels' mix)": r.ns_12mad_4simple, "4 mad + 12 simple": r.ns_4mad_12simple,
+                                                          "16 mad": r.ns_16mad}
+        out["floor_ns_per_instruction_and_simd"] = r.ns_floor
+        out["floor_source"] = "pmx_diag_issue_slot on this device before the warm-up, %d launches, exactly %d waves resident per SIMD; floor = the fastest stream" % (r.launches, waves)
     try:
-        rec = json.load(open(path))
-        w = rec[workload]
-        if abs(w["units_per_launch"] - per_gpu_units) > 1 or not compute_units:
-            return None
-        per_unit = w["valu_instructions_per_wave"]   # one state per lane: what every lane executes
-        simds = compute_units * 4
-        ns = kernel_s * 1e9 * simds / (per_unit * per_gpu_units / 64.0)
-        floor = rec["floor_ns_per_instruction"]
-        return {"bound": "VALU issue slots (one instruction per SIMD and ~4 clocks in a stream with multiplies)",
-                "valu_instructions_per_permutation": per_unit, "multiply_share": mads / per_unit,
-                "ns_per_instruction_and_simd": ns, "floor_ns_per_instruction_and_simd": floor,
-                "frac": floor[str(w["waves_per_simd"])] / ns, "waves_per_simd": w["waves_per_simd"],
-                "source": "profiles/valu_instructions.json (rocprofv3 --pmc SQ_INSTS_VALU pass of this command; floors: "
-                          "tools/issue_model_microbench.hip, the '12 mad, then 4 and' stream at that many waves per SIMD)"}
+        w = json.load(open(os.path.join(ROOT, "profiles", "valu_instructions.json")))[workload]
+        if abs(w["units_per_launch"] - per_gpu_units) > 1 or not compute_units or w.get("engine", info.engine.decode()) != info.engine.decode():
+            raise KeyError(workload)
+        per_unit = w.get("valu_instructions_per_permutation", w["valu_instructions_per_wave"])   # what a lane executes per permutation
+        ns = kernel_s * 1e9 * compute_units * 4 / (per_unit * per_gpu_units / 64.0)
+        out.update({"valu_instructions_per_permutation": per_unit, "multiply_share": mads / per_unit, "ns_per_instruction_and_simd": ns,
+                    "count_source": "profiles/valu_instructions.json (rocprofv3 --pmc SQ_INSTS_VALU pass of this command, " + w.get("source", "") + ")"})
+        if r is not None:
+            out["frac"] = r.ns_floor / ns
+            out["ratio_to_own_mix_stream"] = r.ns_12mad_4simple / ns    # a calibration, not a bound: may exceed 1 by the noise of two timings
     except Exception:
-        return None
+        out["valu_instructions_per_permutation"] = None
+        out["frac"] = None
+        out["count_source"] = "no SQ_INSTS_VALU pass committed for this workload / engine"
+    return out
 
 
 if __name__ == "__main__":

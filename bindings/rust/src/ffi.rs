@@ -55,6 +55,16 @@ pub struct pmx_engine_info {
     pub mfma_dense: c_int,
     pub launches: c_int,
 }
+#[repr(C)]
+pub struct pmx_issue_slot {
+    pub ns_12mad_4simple: f64,
+    pub ns_4mad_12simple: f64,
+    pub ns_16mad: f64,
+    pub ns_floor: f64,
+    pub waves_per_simd: c_int,
+    pub compute_units: c_int,
+    pub launches: c_int,
+}
 pub const PMX_OP_PERMUTE: c_int = 0;
 pub const PMX_OP_HASH: c_int = 1;
 pub const PMX_OP_COMPRESS: c_int = 2;
@@ -131,4 +141,5 @@ extern "C" {
     pub fn pmx_mgpu_merkle_2to1(g: *mut pmx_mgpu, leaves: *const u64, n_leaves: usize, root: *mut u64) -> c_int;
     // diagnostics
     pub fn pmx_diag_int_valu_peak(device: c_int, seconds: f64, out: *mut pmx_valu_peak) -> c_int;
+    pub fn pmx_diag_issue_slot(device: c_int, waves_per_simd: c_int, seconds: f64, out: *mut pmx_issue_slot) -> c_int;
 }

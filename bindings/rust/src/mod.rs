@@ -274,3 +274,6 @@ impl<F: PrimeField> DeviceStates<F> {
 impl<F: PrimeField> Drop for DeviceStates<F> {
     fn drop(&mut self) { unsafe { ffi::pmx_device_free(self.device, self.ptr); } }
 }
+
+#[cfg(test)]
+mod tests;   // needs an MI355X: the reference's KATs and a differential test against the crate's own PoseidonSponge

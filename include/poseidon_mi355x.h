@@ -295,6 +295,21 @@ typedef struct pmx_valu_peak {
 } pmx_valu_peak;
 int pmx_diag_int_valu_peak(int device, double seconds, pmx_valu_peak *out);
 
+/* The VALU issue slot: nanoseconds per VALU instruction and SIMD of three calibration streams (12 multiplies + 4 simple
+ * instructions - the permutation kernels' own mix -, 4 + 12, multiplies only) with exactly `waves_per_simd` waves resident
+ * on every SIMD, measured on this device for about `seconds` (default 0.03).  A kernel's issue floor is its VALU instruction
+ * count x ns_floor (the fastest of the three: no stream that holds multiplies was seen to issue faster in this run). */
+typedef struct pmx_issue_slot {
+    double ns_12mad_4simple;
+    double ns_4mad_12simple;
+    double ns_16mad;
+    double ns_floor;
+    int waves_per_simd;
+    int compute_units;
+    int launches;
+} pmx_issue_slot;
+int pmx_diag_issue_slot(int device, int waves_per_simd, double seconds, pmx_issue_slot *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,13 @@ class PmxValuPeak(ctypes.Structure):
     ]
 
 
+class PmxIssueSlot(ctypes.Structure):
+    _fields_ = [
+        ("ns_12mad_4simple", ctypes.c_double), ("ns_4mad_12simple", ctypes.c_double), ("ns_16mad", ctypes.c_double),
+        ("ns_floor", ctypes.c_double), ("waves_per_simd", ctypes.c_int), ("compute_units", ctypes.c_int), ("launches", ctypes.c_int),
+    ]
+
+
 _u64p = ctypes.c_void_p
 _u32p = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -135,6 +142,7 @@ SIGNATURES = {
     "pmx_mgpu_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p]),
     # diagnostics
     "pmx_diag_int_valu_peak": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.POINTER(PmxValuPeak)]),
+    "pmx_diag_issue_slot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(PmxIssueSlot)]),
 }
 
 # include/poseidon_mi355x_testing.h: inert unless the process runs with PMX_TEST_HOOKS=1 (the library's own tests)

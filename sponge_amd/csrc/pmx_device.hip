@@ -442,11 +442,23 @@ struct HybridEngine {
 
 #endif
 
-    // store_states for the sponges of this wave whose `keep` is set (sponge_pass_kernel: the permutation ran for the whole
+    // One state per lane at a per-lane address (permute_listed_kernel: the sponges of a pass, gathered through an index
+    // list).  Every lane reads and writes its own 32 T contiguous bytes with 16-byte accesses: each line is used in full by
+    // the lane that owns it.
+    __device__ __forceinline__ void load_state_at(const uint64_t *mine) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(mine);
+        if constexpr (PMX_HYB_ROLLED_LOAD(T)) {
+            zero();
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            for (uint32_t i = 0; i < (uint32_t)T; ++i) set(i, from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])));
+        } else {
+            static_for<0, T>([&](auto i) { s[i] = from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])); });
+        }
+    }
+    // store_states for the sponges of this wave whose `keep` bit is set (sponge_first_kernel: the permutation ran for the whole
     // workgroup, only the sponges that needed it take its result).  Staged through the wave's region like store_states: a
     // 16-byte write instruction covers whole states, so the predicate travels as the wave's ballot.
-    __device__ __forceinline__ void store_states_where(uint64_t *g_states, size_t n, bool keep) {
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(keep);
+    __device__ __forceinline__ void store_states_where(uint64_t *g_states, size_t n, uint64_t keep_mask) {
         const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
         const size_t valid = n > first ? (n - first < (size_t)64 ? n - first : (size_t)64) : 0;
         uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * kChunks;
@@ -462,7 +474,35 @@ struct HybridEngine {
 #pragma unroll
         for (int k = 0; k < kChunks; ++k) {
             const uint32_t q = lane + k * 64;
-            if (q < n_chunks && ((mask >> (q / kChunks)) & 1)) g[q] = region[q];
+            if (q < n_chunks && ((keep_mask >> (q / kChunks)) & 1)) g[q] = region[q];
+        }
+        __syncthreads();
+    }
+
+    // `together`: the wave's active lanes hold CONSECUTIVE states starting at wave_base (a prefix of the lanes) - then the
+    // wave's span goes out as whole kilobytes like store_states does; otherwise every lane writes its own state.  Either
+    // way the T exact reductions happen once, into the wave's LDS region.
+    __device__ __forceinline__ void store_state_at(uint64_t *mine, bool keep, bool together, uint64_t *wave_base, uint32_t valid) {
+        __syncthreads();
+        static_for<0, T>([&](auto i) {
+            const Abi a = to_abi(s[i]);
+            region[lane * kChunks + 2 * i] = abi_lo(a);
+            region[lane * kChunks + 2 * i + 1] = abi_hi(a);
+            PMX_SCHED_FENCE();   // one conversion at a time (see store_states)
+        });
+        __syncthreads();
+        if (together) {          // wave-uniform
+            uint4 *g = reinterpret_cast<uint4 *>(wave_base);
+            const uint32_t n_chunks = valid * kChunks;
+#pragma unroll
+            for (int k = 0; k < kChunks; ++k) {
+                const uint32_t q = lane + k * 64;
+                if (q < n_chunks) g[q] = region[q];
+            }
+        } else if (keep) {
+            uint4 *g = reinterpret_cast<uint4 *>(mine);
+#pragma clang loop unroll(disable)
+            for (int k = 0; k < kChunks; ++k) g[k] = region[lane * kChunks + k];
         }
         __syncthreads();
     }
@@ -1071,59 +1111,110 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
     }
 }
 
-// The absorb / squeeze driver of the wide states as wave-uniform PASSES (pmx_sponge_plan.hpp; mod.rs:121-182, 232-254,
-// 321-341).  Pass p: every lane moves chunk p-1 of its own sponge in global memory - input elements added into the rate
-// portion (field addition on the ABI residues, mod.rs:128,143) or rate elements copied out (mod.rs:159-170) -, then the
-// workgroup permutes if any of its sponges needs permutation p, and only those sponges take the result.  The last pass
-// moves the last chunk and rewrites the mode words (mod.rs:130-132, 162-164); until then every pass re-derives its share
-// from the ORIGINAL mode words.  Nothing per-lane is live across the permutation, so this is permute_kernel's register
-// allocation - and its matrix-core rows at t = 7..9.
+// The absorb / squeeze driver of the wide states as PASSES (pmx_sponge_plan.hpp; mod.rs:121-182, 232-254, 321-341).
+// A sponge's call alternates data movement and permutations; pass p is "the sponge's own p-th permutation, then whatever
+// follows it up to the next one".  Every lane WALKS its own sponge between permutations (sponge_walk): chunks are moved in
+// global memory - input elements added into the rate portion (field addition on the ABI residues, mod.rs:128,143) or rate
+// elements copied out (mod.rs:159-170) - until a permutation is due or the call is over (the mode words are rewritten,
+// mod.rs:130-132, 162-164); until then every step re-derives its share from the sponge's ORIGINAL mode words.
+//   sponge_first_kernel    pass 0 over the whole batch in place: walk, then the workgroup permutes if any of its sponges is
+//                          due and only those take the result; walk on; sponges due again go onto list 1 (one atomic per wave).
+//   permute_listed_kernel  pass p >= 1: the permutation of the sponges on list p, then walk on -> list p + 1 or finished.
+// Both run the permutation wave-uniform on the permutation engine of the width (the matrix-core one at t = 7..9) with
+// nothing per-sponge live across it but one ballot; the walks hide under the other waves' arithmetic; and from the second
+// permutation on a batch in mixed modes costs the permutations the reference would execute, not max-over-a-wave of them.
+template <bool SQUEEZE>
+__device__ __forceinline__ bool sponge_walk(const Rounds &c, const FieldRt &f, uint64_t *__restrict__ states, uint32_t *__restrict__ mode_tag,
+                                            uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len, size_t sponge, bool active,
+                                            uint32_t pass, uint32_t last_pass) {
+    if (!active) return false;
+    const uint32_t tag = mode_tag[sponge], index = mode_index[sponge], t_all = c.rate + c.capacity;
+    for (uint32_t q = pass;; ++q) {
+        const SpongePass sp = SQUEEZE ? squeeze_pass(tag, index, len, c.rate, c.capacity, q) : absorb_pass(tag, index, len, c.rate, c.capacity, q);
+        uint32_t *st = reinterpret_cast<uint32_t *>(states + (sponge * t_all + sp.state_pos) * 4);
+        uint32_t *row = reinterpret_cast<uint32_t *>(io + (sponge * len + sp.first) * 4);
+        for (uint32_t j = 0; j < sp.count; ++j) {
+            if constexpr (SQUEEZE) {
+                abi_store(row + 8 * j, abi_load(st + 8 * j));
+            } else {
+                // state[capacity + i] += element: both fully reduced residues, the sum reduced exactly (no multiplication)
+                const Fe sum = fe_normalize(fe_add_lazy(fe_from_abi_scaled(abi_load(st + 8 * j)), fe_from_abi_scaled(abi_load(row + 8 * j))));
+                abi_store(st + 8 * j, fe_to_abi_scaled(sum, f));
+            }
+        }
+        if (sp.permute) return true;   // its permutation q follows: only q == pass can get here (permutations are numbered consecutively)
+        if (q >= last_pass) {          // the call is over for this sponge
+            mode_tag[sponge] = SQUEEZE ? PMX_MODE_SQUEEZING : PMX_MODE_ABSORBING;
+            mode_index[sponge] = sp.end_index;
+            return false;
+        }
+    }
+}
+
+// the sponges of this wave whose next permutation is due go onto the next pass's list, in lane order (one atomic per wave)
+__device__ __forceinline__ void sponge_queue(bool queued, size_t sponge, uint32_t *__restrict__ list_next, uint32_t *__restrict__ count_next) {
+    const uint64_t want = __builtin_amdgcn_ballot_w64(queued);
+    if (want) {
+        const uint32_t lane = threadIdx.x & 63, leader = (uint32_t)__builtin_ctzll(want);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(count_next, (uint32_t)__builtin_popcountll(want));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (queued) list_next[base + (uint32_t)__builtin_popcountll(want & ((1ull << lane) - 1))] = (uint32_t)sponge;
+    }
+}
+
+// Pass 0 over the whole batch, in place: most calls send (nearly) every sponge through a first permutation - any absorb that
+// overflows the rate, any squeeze of an absorbing sponge - so it is not worth a list; a workgroup none of whose sponges
+// permutes leaves early, and the moves in front of the permutation hide under the other workgroups' arithmetic.
 template <class Engine, bool SQUEEZE>
 __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
-    sponge_pass_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
-                       uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len,
-                       size_t n, uint32_t pass, uint32_t last_pass) {
+    sponge_first_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
+                        uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len, size_t n,
+                        uint32_t last_pass, uint32_t *__restrict__ list1, uint32_t *__restrict__ count1) {
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
-    const bool active = gid < n;
-    const uint32_t rate = d.rounds.rate, capacity = d.rounds.capacity, t_all = rate + capacity;
-    auto plan = [&]() {
-        SpongePass sp;
-        sp.permute = false;
-        sp.count = 0;
-        if (active) {
-            const uint32_t tag = mode_tag[gid], index = mode_index[gid];
-            sp = SQUEEZE ? squeeze_pass(tag, index, len, rate, capacity, pass) : absorb_pass(tag, index, len, rate, capacity, pass);
-        }
-        return sp;
-    };
+    const bool due = sponge_walk<SQUEEZE>(d.rounds, d.field, states, mode_tag, mode_index, io, len, gid, gid < n, 0, last_pass);
+    if (!__syncthreads_or(due ? 1 : 0)) return;
+    const uint64_t due_mask = __builtin_amdgcn_ballot_w64(due);       // wave-uniform: the only thing live across the permutation
     {
-        const SpongePass sp = plan();
-        if (sp.count) {
-            uint32_t *st = reinterpret_cast<uint32_t *>(states + (gid * t_all + sp.state_pos) * 4);
-            uint32_t *row = reinterpret_cast<uint32_t *>(io + (gid * len + sp.first) * 4);
-            for (uint32_t j = 0; j < sp.count; ++j) {
-                if constexpr (SQUEEZE) {
-                    abi_store(row + 8 * j, abi_load(st + 8 * j));
-                } else {
-                    // state[capacity + i] += element: both fully reduced residues, the sum reduced exactly (no multiplication)
-                    const Fe sum = fe_normalize(fe_add_lazy(fe_from_abi_scaled(abi_load(st + 8 * j)), fe_from_abi_scaled(abi_load(row + 8 * j))));
-                    abi_store(st + 8 * j, fe_to_abi_scaled(sum, d.field));
-                }
-            }
-        }
-        if (pass == last_pass) {      // wave-uniform (kernel arguments)
-            if (active) {
-                mode_tag[gid] = SQUEEZE ? PMX_MODE_SQUEEZING : PMX_MODE_ABSORBING;
-                mode_index[gid] = sp.end_index;
-            }
-            return;
-        }
-        if (!__syncthreads_or(sp.permute ? 1 : 0)) return;   // no sponge of this workgroup permutes in this pass
+        Engine e(d, consts);
+        e.load_states(states, n);
+        e.permute(0, e.c.rate + e.c.capacity);   // (run-time width: see permute_kernel)
+        e.store_states_where(states, n, due_mask);
     }
-    Engine e(d, consts);
-    e.load_states(states, n);
-    e.permute(0, e.c.rate + e.c.capacity);
-    e.store_states_where(states, n, plan().permute);
+    const bool mine_due = (due_mask >> (threadIdx.x & 63)) & 1;
+    // (the wave's span was written by other lanes of the SAME wave after a workgroup barrier: make it visible to this lane's loads)
+    __threadfence_block();
+    const bool again = sponge_walk<SQUEEZE>(d.rounds, d.field, states, mode_tag, mode_index, io, len, gid, mine_due, 1, last_pass);
+    sponge_queue(again, gid, list1, count1);
+}
+
+template <class Engine, bool SQUEEZE>
+__global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
+    permute_listed_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
+                          uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len,
+                          uint32_t pass, uint32_t last_pass, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count,
+                          uint32_t *__restrict__ list_next, uint32_t *__restrict__ count_next) {
+    const uint32_t count = *list_count;
+    if ((size_t)blockIdx.x * Engine::kThreads >= count) return;      // (the grid is sized for the whole batch)
+    const size_t slot = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
+    const bool active = slot < count;
+    const size_t sponge = list[active ? slot : 0];
+    {
+        Engine e(d, consts);
+        uint64_t *mine = states + sponge * (size_t)(e.c.rate + e.c.capacity) * 4;
+        e.load_state_at(mine);
+        e.permute(0, e.c.rate + e.c.capacity);   // (run-time width: see permute_kernel)
+        // a batch in ONE mode lists whole waves of consecutive sponges (the start kernel appends a wave's sponges in lane order)
+        const uint32_t lane = threadIdx.x & 63;
+        const size_t lead = (size_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sponge) | ((size_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sponge >> 32)) << 32);
+        const uint64_t live = __builtin_amdgcn_ballot_w64(active);
+        const bool together = __builtin_amdgcn_ballot_w64(!active || sponge == lead + lane) == ~0ull;
+        e.store_state_at(mine, active, together, states + lead * (size_t)(e.c.rate + e.c.capacity) * 4, (uint32_t)__builtin_popcountll(live));
+    }
+    // (written through the wave's LDS region by the lanes of the SAME wave: make it visible to this lane's loads)
+    __threadfence_block();
+    const bool again = sponge_walk<SQUEEZE>(d.rounds, d.field, states, mode_tag, mode_index, io, len, sponge, active, pass + 1, last_pass);
+    sponge_queue(again, sponge, list_next, count_next);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1169,19 +1260,42 @@ struct Launch {
                            c.consts, states, tag, index, out, out_len, n);
         return hipGetLastError();
     }
-    // the whole absorb / squeeze call as passes of sponge_pass_kernel (pmx_sponge_plan.hpp)
+    // the whole absorb / squeeze call as passes (pmx_sponge_plan.hpp): the start kernel, then one launch per permutation a
+    // sponge of the batch can need.  The two lists and the per-pass counters live in stream-ordered scratch (the _dev entry
+    // points stay re-entrant: nothing of the context is written).
     template <bool SQUEEZE>
     static hipError_t sponge_passes(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index, uint64_t *io,
                                     size_t len, size_t n, hipStream_t st) {
         const size_t passes = SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate);
-        allow_lds(sponge_pass_kernel<Engine, SQUEEZE>, Engine::lds_bytes(c, t));
-        for (size_t p = 0; p < passes; ++p) {
-            hipLaunchKernelGGL((sponge_pass_kernel<Engine, SQUEEZE>), dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
-                               c.consts, states, tag, index, io, len, n, (uint32_t)p, (uint32_t)(passes - 1));
-            const hipError_t e = hipGetLastError();
+        if (passes == 0 || n == 0) return hipSuccess;
+        if (n > 0xffffffffull) return hipErrorInvalidValue;
+        allow_lds(permute_listed_kernel<Engine, SQUEEZE>, Engine::lds_bytes(c, t));
+        allow_lds(sponge_first_kernel<Engine, SQUEEZE>, Engine::lds_bytes(c, t));
+        const uint32_t last = (uint32_t)(passes - 1);    // (no sponge permutes in the last pass)
+        uint32_t *scratch = nullptr;                     // [counters, padded to 64 words | list A: n | list B: n]
+        const size_t head = (passes + 63) / 64 * 64;
+        hipError_t e = hipSuccess;
+        uint32_t *lists[2] = {nullptr, nullptr};
+        if (last > 1) {                                  // a second permutation is possible: its sponges travel on a list
+            e = hipMallocAsync((void **)&scratch, (head + 2 * n) * 4, st);
             if (e != hipSuccess) return e;
+            lists[0] = scratch + head;
+            lists[1] = scratch + head + n;
+            e = hipMemsetAsync(scratch, 0, head * 4, st);
         }
-        return hipSuccess;
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((sponge_first_kernel<Engine, SQUEEZE>), dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c, c.consts,
+                               states, tag, index, io, len, n, last, lists[1], scratch ? scratch + 1 : nullptr);
+            e = hipGetLastError();
+        }
+        for (uint32_t p = 1; p < last && e == hipSuccess; ++p) {
+            hipLaunchKernelGGL((permute_listed_kernel<Engine, SQUEEZE>), dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
+                               c.consts, states, tag, index, io, len, p, last, lists[p & 1], scratch + p, lists[(p + 1) & 1], scratch + p + 1);
+            e = hipGetLastError();
+        }
+        if (!scratch) return e;
+        const hipError_t e_free = hipFreeAsync(scratch, st);
+        return e != hipSuccess ? e : e_free;
     }
     // what a launch of `op` would run on (pmx_ctx_engine_info): filled by the engine, completed per kernel family here
     static hipError_t describe(const DevConfig &c, uint32_t t, int op, size_t len, EngineInfo *o) {
@@ -1295,7 +1409,8 @@ hipError_t PMX_HYB_NAME(describe)(const DevConfig &c, uint32_t t, int op, size_t
     if (!driver || passes) e = fast();
     if (e != hipSuccess) e = plain();
     if (e == hipSuccess && passes) {
-        o->launches = (int)(op == PMX_OP_SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate));
+        const int passes = (int)(op == PMX_OP_SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate));
+        o->launches = passes > 1 ? passes - 1 : passes;  // one launch per permutation a sponge of the batch can need
         std::snprintf(o->engine + std::strlen(o->engine), sizeof o->engine - std::strlen(o->engine), " x passes");
     }
     return e;

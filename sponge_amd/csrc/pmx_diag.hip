@@ -130,3 +130,110 @@ extern "C" int pmx_diag_int_valu_peak(int device, double seconds, pmx_valu_peak 
     out->theoretical_lane_mads_per_s = (double)n_cu * 4 * 16 * out->shader_clock_hz;
     return PMX_OK;
 }
+
+// ---- the VALU issue slot, measured in the run ----------------------------------------------------------------------------
+// A SIMD of this part takes one VALU instruction per ~4 shader clocks from any stream that contains multiplies, whatever
+// the instruction is (tools/issue_model_microbench.hip), so a kernel's floor is its VALU instruction
+// count times that slot.  The slot depends on the clock the chip holds under the stream, so - like the multiply peak above -
+// it is measured on this device in this run, at the occupancy of the kernel it prices: exactly `waves_per_simd` waves resident
+// on every SIMD (pinned by the LDS each block asks for; the dispatcher alone does not spread a launch evenly), three
+// calibration streams written as single asm statements, timed by the wall clock.
+namespace {
+#define PMX_R2(x) x "\n\t" x
+#define PMX_R4(x) PMX_R2(x) "\n\t" PMX_R2(x)
+#define PMX_R16(x) PMX_R4(x) "\n\t" PMX_R4(x) "\n\t" PMX_R4(x) "\n\t" PMX_R4(x)
+#define PMX_MAD4 "v_mad_u64_u32 %0, vcc, %8, %10, %0\n\tv_mad_u64_u32 %1, vcc, %9, %10, %1\n\tv_mad_u64_u32 %2, vcc, %8, %10, %2\n\tv_mad_u64_u32 %3, vcc, %9, %10, %3"
+#define PMX_AND4 "v_and_b32 %4, %4, %10\n\tv_and_b32 %5, %5, %10\n\tv_and_b32 %6, %6, %10\n\tv_and_b32 %7, %7, %10"
+// MIX 0: 12 multiplies then 4 simple instructions (the permutation kernels' own mix: three multiplies per other instruction)
+// MIX 1: 4 multiplies then 12 simple instructions;  MIX 2: 16 multiplies.  16 instructions per step, 16 steps per trip.
+template <int MIX>
+__global__ void __launch_bounds__(256) issue_stream_kernel(unsigned *out, int trips, unsigned seed) {
+    extern __shared__ unsigned pin[];   // only its size matters
+    unsigned long long a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;
+    unsigned x0 = threadIdx.x * 2654435761u + seed, x1 = x0 ^ 0x9E3779B9u, x2 = x0 + 77, x3 = x1 + 99;
+    const unsigned y = seed | 0x10001u, z0 = x0 ^ 0x55, z1 = x1 ^ 0xaa;
+    for (int it = 0; it < trips; ++it) {
+        if constexpr (MIX == 0) {
+            asm volatile(PMX_R16(PMX_MAD4 "\n\t" PMX_MAD4 "\n\t" PMX_MAD4 "\n\t" PMX_AND4)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(z0), "v"(z1), "v"(y) : "vcc");
+        } else if constexpr (MIX == 1) {
+            asm volatile(PMX_R16(PMX_MAD4 "\n\t" PMX_AND4 "\n\t" PMX_AND4 "\n\t" PMX_AND4)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(z0), "v"(z1), "v"(y) : "vcc");
+        } else {
+            asm volatile(PMX_R16(PMX_MAD4 "\n\t" PMX_MAD4 "\n\t" PMX_MAD4 "\n\t" PMX_MAD4)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(z0), "v"(z1), "v"(y) : "vcc");
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(a0 ^ a1 ^ a2 ^ a3) ^ (unsigned)((a0 ^ a1 ^ a2 ^ a3) >> 32) ^ x0 ^ x1 ^ x2 ^ x3 ^ pin[0];
+}
+}  // namespace
+
+extern "C" int pmx_diag_issue_slot(int device, int waves_per_simd, double seconds, pmx_issue_slot *out) {
+    if (!out) return set_error(PMX_ERR_ARG, "pmx_diag_issue_slot: null pointer");
+    *out = pmx_issue_slot{};
+    const int ndev = pmx_device_count();
+    if (ndev == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    if (waves_per_simd < 1 || waves_per_simd > 8) return set_error(PMX_ERR_ARG, "waves_per_simd %d out of range [1,8]", waves_per_simd);
+    if (!(seconds > 0)) seconds = 0.03;
+    if (seconds > 5) seconds = 5;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    hipDeviceProp_t prop;
+    PMX_HIP(hipGetDeviceProperties(&prop, device));
+    const int n_cu = prop.multiProcessorCount, blocks = n_cu * waves_per_simd;   // a block = one wave on each SIMD of a CU
+    int cu_lds = 0;
+    if (hipDeviceGetAttribute(&cu_lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess || cu_lds <= 0) cu_lds = 160 * 1024;
+    const size_t lds = (size_t)(cu_lds / waves_per_simd) - 1024;                 // k blocks fit a CU, k + 1 do not
+    const int trips = 256;                                                       // 65,536 instructions per lane and launch
+    unsigned *d_out = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void **)&d_out, (size_t)blocks * 256 * 4);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const void *kernels[3] = {(const void *)issue_stream_kernel<0>, (const void *)issue_stream_kernel<1>, (const void *)issue_stream_kernel<2>};
+    for (int m = 0; m < 3 && e == hipSuccess; ++m) e = hipFuncSetAttribute(kernels[m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::vector<double> ns[3];
+    int launches = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    while (e == hipSuccess) {   // the three streams in turn, so that all of them see the same clock ramp
+        for (int m = 0; m < 3 && e == hipSuccess; ++m) {
+            e = hipEventRecord(e0, st);
+            if (m == 0) hipLaunchKernelGGL(issue_stream_kernel<0>, dim3(blocks), dim3(256), lds, st, d_out, trips, 1u + launches);
+            else if (m == 1) hipLaunchKernelGGL(issue_stream_kernel<1>, dim3(blocks), dim3(256), lds, st, d_out, trips, 1u + launches);
+            else hipLaunchKernelGGL(issue_stream_kernel<2>, dim3(blocks), dim3(256), lds, st, d_out, trips, 1u + launches);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) break;
+            // instructions one SIMD issued: waves_per_simd waves x trips x 16 steps x 16 instructions
+            ns[m].push_back(ms * 1e6 / ((double)waves_per_simd * trips * 256.0));
+            ++launches;
+        }
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        if (elapsed >= seconds && ns[0].size() >= 4) break;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(e, "pmx_diag_issue_slot");
+    double med[3];
+    for (int m = 0; m < 3; ++m) {
+        std::vector<double> tail(ns[m].begin() + ns[m].size() / 2, ns[m].end());   // past the clock ramp
+        std::sort(tail.begin(), tail.end());
+        med[m] = tail[tail.size() / 2];
+    }
+    out->ns_12mad_4simple = med[0];
+    out->ns_4mad_12simple = med[1];
+    out->ns_16mad = med[2];
+    out->ns_floor = std::min(med[0], std::min(med[1], med[2]));
+    out->waves_per_simd = waves_per_simd;
+    out->compute_units = n_cu;
+    out->launches = launches;
+    return PMX_OK;
+}

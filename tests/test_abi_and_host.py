@@ -70,9 +70,21 @@ def test_rust_binding_source_declares_the_whole_header():
 def test_integration_md_shows_the_binding_files_verbatim():
     """INTEGRATION.md embeds bindings/rust/{build.rs, src/ffi.rs, src/mod.rs}: the document and the files must not drift."""
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for rel in ("build.rs", os.path.join("src", "ffi.rs"), os.path.join("src", "mod.rs")):
+    for rel in ("build.rs", os.path.join("src", "ffi.rs"), os.path.join("src", "mod.rs"), os.path.join("src", "tests.rs")):
         text = open(os.path.join(ROOT, "bindings", "rust", rel)).read().rstrip("\n")
         assert "```rust\n" + text + "\n```" in doc, rel
+
+
+def test_rust_binding_tests_restate_the_reference_kat_and_a_differential_test():
+    """bindings/rust/src/tests.rs cannot run here; keep what it must contain from drifting: the three KAT outputs of
+    src/poseidon/mod.rs:376-399 (data, the same numbers oracle/kats.py pins), a differential test against the crate's own
+    PoseidonSponge, and the `mod tests;` hook in mod.rs."""
+    text = open(os.path.join(ROOT, "bindings", "rust", "src", "tests.rs")).read()
+    for value in K.SPONGE_CONSISTENCY_OUTPUT:
+        assert f'MontFp!("{value}")' in text, value
+    assert "PoseidonSponge::<Fr>::new" in text and "Mi355xPoseidonSponge::<Fr>::new" in text and "fn differential_" in text
+    assert "mod tests;" in open(os.path.join(ROOT, "bindings", "rust", "src", "mod.rs")).read()
+    assert "mi355x" in open(os.path.join(ROOT, "bindings", "rust", "Cargo.fragment.toml")).read()
 
 
 def test_no_device_means_loud_failure_not_fallback():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_r04.sh <tag> [stages]
-# stages: any of  test smoke bench wide widepmc levels cov widths   (default: "test smoke bench")
+# stages: any of  test smoke bench wide widepmc levels cov widths slots pmc prof   (default: "test smoke bench")
 TAG=${1:-r04a}
 STAGES=${2:-"test smoke bench"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -52,7 +52,49 @@ if has widepmc; then
   f=$(find $OUT/prof_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/wide_kernel_stats.csv
   python3 $R/tools/pmc_kernel_summary.py $OUT/pmc_wide > $OUT/wide_pmc_summary.txt 2>&1
 fi
+if has slots; then
+  # SQ_INSTS_VALU of the dominant kernel of each bench workload -> profiles/valu_instructions.json entries
+  for w in c2 c3 w7 w8 h3 h9; do
+    timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/slots_$w -- python3 $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/slots_$w.log 2>&1
+  done
+fi
+if has pmc; then
+  for w in c2 c3 h3 h9; do
+    timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$w -- python3 $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_fetch_$w.log 2>&1
+    timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$w -- python3 $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_write_$w.log 2>&1
+  done
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c2_2e21 -- python3 $R/bench.py --workload c2 --total-log2 21 --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_fetch_c2_2e21.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c2_2e21 -- python3 $R/bench.py --workload c2 --total-log2 21 --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_write_c2_2e21.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c5 -- python3 $R/bench.py --workload c5 --total-log2 21 --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_fetch_c5.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c5 -- python3 $R/bench.py --workload c5 --total-log2 21 --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_write_c5.log 2>&1
+fi
+if has prof; then
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c2 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_c2.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c3 -- python3 $R/bench.py --workload c3 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_c3.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5 -- python3 $R/bench.py --workload c5 --total-log2 21 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_c5.log 2>&1
+  for w in c2 c3 c5; do f=$(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${w}_kernel_stats.csv; done
+fi
 cd $R
+if has slots; then
+  J=$OUT/valu_instructions.json; rm -f $J
+  python tools/valu_count.py $OUT/slots_c2 permute_kernel c2 1048576 "RegEngine<3,5,opt,tab>" 4 $J "profiles/r04" > $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_c3 permute_kernel c3 262144 "HybridEngine<9,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w7 permute_kernel w7 262144 "HybridEngine<7,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w8 permute_kernel w8 262144 "HybridEngine<8,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_h3 hash_kernel h3 2097152 "RegEngine<3,5,opt,tab>" 4 $J "profiles/r04" 2 >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_h9 hash_kernel h9 262144 "HybridEngine<9,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  cat $OUT/valu_count.log
+fi
+if has pmc; then
+  T=$OUT/hbm_traffic.json; rm -f $T
+  python tools/extract_traffic.py $OUT/pmc_fetch_c2 $OUT/pmc_write_c2 permute_kernel c2 $T 1 1048576 > $OUT/traffic.log 2>&1
+  python tools/extract_traffic.py $OUT/pmc_fetch_c3 $OUT/pmc_write_c3 permute_kernel c3 $T 1 262144 >> $OUT/traffic.log 2>&1
+  python tools/extract_traffic.py $OUT/pmc_fetch_h3 $OUT/pmc_write_h3 hash_kernel h3 $T 1 2097152 >> $OUT/traffic.log 2>&1
+  python tools/extract_traffic.py $OUT/pmc_fetch_h9 $OUT/pmc_write_h9 hash_kernel h9 $T 1 262144 >> $OUT/traffic.log 2>&1
+  python tools/extract_traffic.py $OUT/pmc_fetch_c2_2e21 $OUT/pmc_write_c2_2e21 permute_kernel c2_2e21 $T 1 2097152 >> $OUT/traffic.log 2>&1
+  python tools/extract_traffic.py $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 compress c5 $T 21 2097151 >> $OUT/traffic.log 2>&1
+  cat $OUT/traffic.log
+fi
 for f in sponge_rate merkle_levels wide_pmc_summary; do [ -f $OUT/$f.txt ] && cat $OUT/$f.txt; done
 [ -f $OUT/wide_kernel_stats.csv ] && head -8 $OUT/wide_kernel_stats.csv | cut -c1-220
 [ -f $OUT/mgpu_cov/coverage_summary.txt ] && head -40 $OUT/mgpu_cov/coverage_summary.txt
