@@ -73,6 +73,7 @@ struct RegEngine {
     // the large-batch (table) kernels live on four waves per SIMD: held to 128 VGPRs (left alone the allocator has taken
     // anything between 105 and 138 for the same source); the element-form kernels serve launches that cannot fill the chip
     static constexpr int kMinWaves = TAB ? PMX_REG_TAB_MIN_WAVES : 1, kMinWavesDriver = PMX_REG_DRIVER_MIN_WAVES;
+    static constexpr bool kWaveUniformOnly = false;   // permute() may be called under a partial EXEC mask (per-lane driver kernels)
     static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
 
     Fe s[T];
@@ -259,6 +260,10 @@ struct HybridEngine {
     // waves per SIMD the register allocation must allow (4: <= 128 VGPRs, 3: <= 168, 2: <= 256)
     static constexpr int kMinWaves = T <= PMX_HYB_4WAVE_MAX_T ? 4 : T <= PMX_HYB_3WAVE_MAX_T ? 3 : 2;
     static constexpr int kMinWavesDriver = 2;   // absorb / squeeze kernels (per-lane modes: more live state) spill under the tighter bounds
+    // the matrix-core rows exchange operands between the lanes of a pair (l, l + 32) and share an LDS tile behind workgroup
+    // barriers: permute() must be reached by every lane of the workgroup - never from a per-lane loop (absorb_kernel /
+    // squeeze_kernel static_assert on this; the drivers of these widths run as passes, sponge_first_kernel)
+    static constexpr bool kWaveUniformOnly = MFMA;
     static constexpr int kChunks = 2 * T;
     // one wave's LDS region: scratch slots for elements 0..T-2 (2304 B each) or the ABI staging of its 64 states
     // (2048 T B), whichever is larger
@@ -546,6 +551,7 @@ template <int ALPHA>
 struct LdsEngine {
     static constexpr int kThreads = 128;
     static constexpr int kMinWaves = 1, kMinWavesDriver = 1;
+    static constexpr bool kWaveUniformOnly = false;
 
     Rounds c;
     FieldRt f;
@@ -1071,6 +1077,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
     absorb_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
                   uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, const uint64_t *__restrict__ in,
                   size_t in_len, size_t n) {
+    static_assert(!Engine::kWaveUniformOnly, "this engine's permutation cannot run under the per-lane EXEC masks of absorb_elements");
     Engine e(d, consts);
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
@@ -1091,6 +1098,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
     squeeze_kernel(const DevConfig d, const uint32_t *__restrict__ consts, uint64_t *__restrict__ states,
                    uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ out,
                    size_t out_len, size_t n) {
+    static_assert(!Engine::kWaveUniformOnly, "this engine's permutation cannot run under the per-lane EXEC masks of squeeze_elements");
     Engine e(d, consts);
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = gid < n;
