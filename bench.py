@@ -21,6 +21,8 @@ src/poseidon/mod.rs:95-118) over one device-resident batch of synthetic random s
 Rank 0 prints ONE JSON line.  `value` = permutations per second over all ranks, inputs already in HBM.
 `roofline` prices the dominant kernel against HBM (algorithmic 2*t*32 bytes per permutation); `int_valu` against
 the v_mad_u64_u32 issue rate measured on this device in this run (pmx_diag_int_valu_peak), which is what binds it;
+`engine` is what the library's launchers dispatch for this call (pmx_ctx_engine_info) and feeds the multiply count;
+`valu_issue` prices the kernel's VALU instruction count against the issue slot measured in this run (pmx_diag_issue_slot);
 `cpu_baseline` times the C restatement of the reference algorithm (oracle/, kind "port") on the host cores for a
 bounded sample of the same workload (rank 0, N=1 only).  After the timed region one extra untimed pass over a fresh
 copy of the seeded batch is compared with the C restatement on a sample ("verified"); a mismatch exits non-zero.

@@ -9,9 +9,10 @@
  * Element representation (everywhere in this ABI): a field element is 4 little-endian uint64_t limbs
  * holding the fully reduced Montgomery residue  x * 2^256 mod p  -- byte-identical to ark-ff's
  * Fp<MontBackend<_,4>,4>, so a Rust &[Fr] / Vec<Fr> is passed as-is (src/poseidon/mod.rs:57 `state`).
- * "Bit-exact" means limb-for-limb equality of these residues.  Inputs must be fully reduced, as ark-ff keeps them
- * (an unreduced state or message element is still processed modulo p, but an output that depends on it may come back
- * unreduced; config constants are checked, batch data is not).
+ * "Bit-exact" means limb-for-limb equality of these residues.  Inputs must be fully reduced, as ark-ff keeps them:
+ * config constants are checked, batch data is not, and the result for an unreduced state or message element is
+ * unspecified (the permutation kernels happen to process it modulo p; the absorb driver adds elements into the state
+ * as 256-bit residues with ONE conditional subtraction, which is exact only for reduced operands).
  *
  * State order inside one sponge state is the reference's: capacity elements first, then the rate
  * elements (src/poseidon/mod.rs:128,143,159).
@@ -175,7 +176,10 @@ int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64
  * src/poseidon/mod.rs:344-367): states [n][t][4], mode_tag [n], mode_index [n]; all updated in place.
  * absorb: CryptographicSponge::absorb for in_len native elements per sponge (mod.rs:232-254, 121-150).
  * squeeze: FieldBasedCryptographicSponge::squeeze_native_field_elements(out_len) (mod.rs:321-341,
- * 153-182, including the `!= rate` test of :175).  Sponges in one call may be in different modes. */
+ * 153-182, including the `!= rate` test of :175).  Sponges in one call may be in different modes.
+ * Widths 4..9 run a call as PASSES on the permutation engine of the width (one launch per permutation a sponge of the
+ * batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would permute it); the _dev
+ * variants take their pass lists from the stream-ordered allocator (hipMallocAsync on `stream`).  in_len, out_len < 2^31. */
 int pmx_sponge_absorb_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
                             const uint64_t *in, size_t in_len, size_t n);
 int pmx_sponge_squeeze_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,

@@ -1132,13 +1132,13 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
 // nothing per-sponge live across it but one ballot; the walks hide under the other waves' arithmetic; and from the second
 // permutation on a batch in mixed modes costs the permutations the reference would execute, not max-over-a-wave of them.
 template <bool SQUEEZE>
-__device__ __forceinline__ bool sponge_walk(const Rounds &c, const FieldRt &f, uint64_t *__restrict__ states, uint32_t *__restrict__ mode_tag,
+__device__ __forceinline__ bool sponge_walk(const Rounds &c, const uint32_t *__restrict__ p32, uint64_t *__restrict__ states, uint32_t *__restrict__ mode_tag,
                                             uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len, size_t sponge, bool active,
                                             uint32_t pass, uint32_t last_pass) {
     if (!active) return false;
     const uint32_t tag = mode_tag[sponge], index = mode_index[sponge], t_all = c.rate + c.capacity;
     for (uint32_t q = pass;; ++q) {
-        const SpongePass sp = SQUEEZE ? squeeze_pass(tag, index, len, c.rate, c.capacity, q) : absorb_pass(tag, index, len, c.rate, c.capacity, q);
+        const SpongePass sp = SQUEEZE ? squeeze_pass(tag, index, (uint32_t)len, c.rate, c.capacity, q) : absorb_pass(tag, index, (uint32_t)len, c.rate, c.capacity, q);
         uint32_t *st = reinterpret_cast<uint32_t *>(states + (sponge * t_all + sp.state_pos) * 4);
         uint32_t *row = reinterpret_cast<uint32_t *>(io + (sponge * len + sp.first) * 4);
         for (uint32_t j = 0; j < sp.count; ++j) {
@@ -1146,8 +1146,7 @@ __device__ __forceinline__ bool sponge_walk(const Rounds &c, const FieldRt &f, u
                 abi_store(row + 8 * j, abi_load(st + 8 * j));
             } else {
                 // state[capacity + i] += element: both fully reduced residues, the sum reduced exactly (no multiplication)
-                const Fe sum = fe_normalize(fe_add_lazy(fe_from_abi_scaled(abi_load(st + 8 * j)), fe_from_abi_scaled(abi_load(row + 8 * j))));
-                abi_store(st + 8 * j, fe_to_abi_scaled(sum, f));
+                abi_store(st + 8 * j, abi_add_mod(abi_load(st + 8 * j), abi_load(row + 8 * j), p32));
             }
         }
         if (sp.permute) return true;   // its permutation q follows: only q == pass can get here (permutations are numbered consecutively)
@@ -1180,7 +1179,8 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
                         uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len, size_t n,
                         uint32_t last_pass, uint32_t *__restrict__ list1, uint32_t *__restrict__ count1) {
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
-    const bool due = sponge_walk<SQUEEZE>(d.rounds, d.field, states, mode_tag, mode_index, io, len, gid, gid < n, 0, last_pass);
+    const uint32_t *p32 = consts + d.io_offset + kIoP32;   // the modulus as 8 x 32-bit limbs (wave-uniform: scalar loads)
+    const bool due = sponge_walk<SQUEEZE>(d.rounds, p32, states, mode_tag, mode_index, io, len, gid, gid < n, 0, last_pass);
     if (!__syncthreads_or(due ? 1 : 0)) return;
     const uint64_t due_mask = __builtin_amdgcn_ballot_w64(due);       // wave-uniform: the only thing live across the permutation
     {
@@ -1192,7 +1192,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     const bool mine_due = (due_mask >> (threadIdx.x & 63)) & 1;
     // (the wave's span was written by other lanes of the SAME wave after a workgroup barrier: make it visible to this lane's loads)
     __threadfence_block();
-    const bool again = sponge_walk<SQUEEZE>(d.rounds, d.field, states, mode_tag, mode_index, io, len, gid, mine_due, 1, last_pass);
+    const bool again = sponge_walk<SQUEEZE>(d.rounds, p32, states, mode_tag, mode_index, io, len, gid, mine_due, 1, last_pass);
     sponge_queue(again, gid, list1, count1);
 }
 
@@ -1221,7 +1221,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     }
     // (written through the wave's LDS region by the lanes of the SAME wave: make it visible to this lane's loads)
     __threadfence_block();
-    const bool again = sponge_walk<SQUEEZE>(d.rounds, d.field, states, mode_tag, mode_index, io, len, sponge, active, pass + 1, last_pass);
+    const bool again = sponge_walk<SQUEEZE>(d.rounds, consts + d.io_offset + kIoP32, states, mode_tag, mode_index, io, len, sponge, active, pass + 1, last_pass);
     sponge_queue(again, sponge, list_next, count_next);
 }
 
@@ -1276,7 +1276,7 @@ struct Launch {
                                     size_t len, size_t n, hipStream_t st) {
         const size_t passes = SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate);
         if (passes == 0 || n == 0) return hipSuccess;
-        if (n > 0xffffffffull) return hipErrorInvalidValue;
+        if (n > 0xffffffffull || len > kSpongeMaxLen) return hipErrorInvalidValue;
         allow_lds(permute_listed_kernel<Engine, SQUEEZE>, Engine::lds_bytes(c, t));
         allow_lds(sponge_first_kernel<Engine, SQUEEZE>, Engine::lds_bytes(c, t));
         const uint32_t last = (uint32_t)(passes - 1);    // (no sponge permutes in the last pass)

@@ -665,6 +665,30 @@ PMX_FN Abi fe_to_abi_scaled(const Fe &x, const FieldRt &f) {
     return limbs_29_to_32(t);
 }
 
+// a + b mod p on two fully reduced ABI residues (p32: the modulus as 8 x 32-bit limbs, FieldRt::io + kIoP32): one carry chain
+// up, one borrow chain down, a select - the `state[capacity + i] += element` of the sponge drivers (mod.rs:128,143), which is
+// a field addition and needs no Montgomery arithmetic.  a, b < p < 2^255: the sum fits 256 bits and one subtraction reduces it.
+PMX_FN Abi abi_add_mod(const Abi &a, const Abi &b, const uint32_t *p32) {
+    uint32_t sum[8], dif[8];
+    uint32_t carry = 0, borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t v = (uint64_t)a.w[i] + b.w[i] + carry;
+        sum[i] = (uint32_t)v;
+        carry = (uint32_t)(v >> 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t v = (uint64_t)sum[i] - p32[i] - borrow;
+        dif[i] = (uint32_t)v;
+        borrow = (uint32_t)(v >> 32) & 1u;
+    }
+    Abi r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.w[i] = borrow ? sum[i] : dif[i];
+    return r;
+}
+
 #if defined(__HIPCC__)
 // 32-byte ABI element <-> two 16-byte vectors
 __device__ __forceinline__ Abi abi_from_u4(const uint4 &lo, const uint4 &hi) {

@@ -309,7 +309,7 @@ extern "C" int hc_field_op(const uint64_t modulus[4], int op, const uint64_t *a,
         store_abi(out, fe_to_abi(fe_from_abi(load_abi(a), f), f));
     } else if (op == 4) {
         // the absorb step of sponge_pass_kernel: a + b on the ABI residues, no multiplication (pmx_device.hip)
-        store_abi(out, fe_to_abi_scaled(fe_normalize(fe_add_lazy(fe_from_abi_scaled(load_abi(a)), fe_from_abi_scaled(load_abi(b)))), f));
+        store_abi(out, abi_add_mod(load_abi(a), load_abi(b), f.io + kIoP32));
     } else {
         return PMX_ERR_ARG;
     }
@@ -502,7 +502,7 @@ extern "C" void hc_worst_sqr_column(uint32_t amax, uint64_t *hi, uint64_t *lo) {
 // ---- the absorb / squeeze driver as passes (pmx_sponge_plan.hpp): the plan of one sponge and one pass -------------------
 // out = {permute, state_pos, first, count, end_index}
 extern "C" void hc_sponge_pass(int squeeze, uint32_t tag, uint32_t index, size_t len, uint32_t rate, uint32_t capacity, size_t pass, uint64_t out[5]) {
-    const SpongePass sp = squeeze ? squeeze_pass(tag, index, len, rate, capacity, pass) : absorb_pass(tag, index, len, rate, capacity, pass);
+    const SpongePass sp = squeeze ? squeeze_pass(tag, index, (uint32_t)len, rate, capacity, (uint32_t)pass) : absorb_pass(tag, index, (uint32_t)len, rate, capacity, (uint32_t)pass);
     out[0] = sp.permute ? 1 : 0;
     out[1] = sp.state_pos;
     out[2] = sp.first;
