@@ -115,11 +115,11 @@ def parse_args():
 # ----------------------------------------------------------------------------------------------------------------------
 # the checker (oracle/): cpu_baseline and the post-run verification - never inside the timed region
 # ----------------------------------------------------------------------------------------------------------------------
-def oracle_engine(field_name, rate, alpha, rf, rp):
+def oracle_engine(field_name, rate, alpha, rf, rp, handle=None):
     from oracle import cref
     from oracle import poseidon_oracle as O
     p, bits = {"bls12_381_fr": (O.BLS12_381_FR, 255), "bn254_fr": (O.BN254_FR, 254)}[field_name]
-    return cref.CRef(O.make_config(p, bits, rate, alpha, rf, rp))
+    return cref.CRef(O.make_config(p, bits, rate, alpha, rf, rp), handle)
 
 
 def cpu_baseline(field_name, rate, alpha, rf, rp, seed, target_seconds):
@@ -129,10 +129,18 @@ def cpu_baseline(field_name, rate, alpha, rf, rp, seed, target_seconds):
     import sponge_amd as S
     from sponge_amd import synth
 
-    cr = oracle_engine(field_name, rate, alpha, rf, rp)
+    # BASELINE.md quotes the CPU path built with -march=native: compile the restatement for THIS host if gcc is here (the
+    # build that travels with the repo is x86-64-v3, portable but without ADX), after checking it against the portable build
+    native = cref.native_lib()
+    cr = oracle_engine(field_name, rate, alpha, rf, rp, native)
     t = rate + 1
     threads = cref.max_threads()      # affinity mask capped by the cgroup CPU quota
     field = S.FIELDS[field_name]
+    build = "-O3 -march=native, built on this host" if native else "-O3 -march=x86-64-v3 (portable build)"
+    if native:
+        probe = synth.random_elements(field, 64 * t, seed + 1).reshape(64, t, 4)
+        if not np.array_equal(cr.permute_batch(probe, threads=1), oracle_engine(field_name, rate, alpha, rf, rp).permute_batch(probe, threads=1)):
+            cr, build = oracle_engine(field_name, rate, alpha, rf, rp), "-O3 -march=x86-64-v3 (the native build disagreed with it: not used)"
 
     def timed(n_threads, seconds):
         probe = synth.random_elements(field, 1024 * t, seed).reshape(1024, t, 4)
@@ -152,7 +160,7 @@ def cpu_baseline(field_name, rate, alpha, rf, rp, seed, target_seconds):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    what = "C restatement of mod.rs:63-118 (dense MDS, square-and-multiply pow)"
+    what = "C restatement of mod.rs:63-118 (dense MDS, square-and-multiply pow), gcc " + build
     return {"value": n / dt, "unit": "permutations/s", "cores": threads, "kind": "port",
             "sample": f"first {n} states of the same seeded batch, {what}, OpenMP x{threads}, {dt:.2f} s, CPU: {model}",
             "single_thread": {"value": n1 / dt1, "unit": "permutations/s", "cores": 1, "kind": "port",

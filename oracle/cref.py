@@ -44,6 +44,35 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+_native = None
+
+
+def native_lib():
+    """The same C restatement compiled on THIS machine with -march=native (BASELINE.md section 2 quotes the CPU path with
+    -march=native): bench.py's cpu_baseline uses it when gcc is there, so that the CPU figure is the host's own ceiling and
+    not that of the portable build (x86-64-v3: no ADX) which has to travel between machines.  Built into a private
+    temporary directory, never into the repo; None when it cannot be built.  The checker proper (tests, smoke, bench.py's
+    verification) stays on the portable build."""
+    global _native
+    if _native is None:
+        import shutil
+        import tempfile
+        _native = False
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if cc:
+            d = tempfile.mkdtemp(prefix="pmx_oracle_native_")
+            out = os.path.join(d, "libposeidon_oracle_native.so")
+            cmd = [cc, "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=c11", "-shared", "-o", out, os.path.join(HERE, "poseidon_ref.c")]
+            try:
+                subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+                h = ctypes.CDLL(out)
+                h.pref_max_threads.restype = ctypes.c_int
+                _native = h
+            except Exception:
+                _native = False
+    return _native or None
+
+
 def elems_to_limbs(vals, p: int, mont: bool = True) -> np.ndarray:
     """canonical ints (any nesting flattened by the caller) -> [n][4] u64 (Montgomery by default)."""
     out = np.empty((len(vals), 4), dtype=np.uint64)
@@ -66,8 +95,9 @@ def limbs_to_elems(arr: np.ndarray, p: int, mont: bool = True):
 class CRef:
     """One PoseidonConfig loaded into the C restatement."""
 
-    def __init__(self, cfg: O.PoseidonConfig):
+    def __init__(self, cfg: O.PoseidonConfig, handle=None):
         self.cfg = cfg
+        self._h = handle            # None: the portable build (lib()); bench.py's cpu_baseline passes native_lib()
         p = cfg.p
         self._ark = np.ascontiguousarray(
             elems_to_limbs([v for row in cfg.ark for v in row], p).reshape(-1))
@@ -93,8 +123,8 @@ class CRef:
         threads = threads or max_threads()
         out = np.ascontiguousarray(states, dtype=np.uint64).copy()
         n = out.size // (self.cfg.t * 4)
-        rc = lib().pref_permute_batch(ctypes.byref(self._c), self._ptr(out), ctypes.c_size_t(n),
-                                      ctypes.c_int(threads))
+        rc = (self._h or lib()).pref_permute_batch(ctypes.byref(self._c), self._ptr(out), ctypes.c_size_t(n),
+                                                   ctypes.c_int(threads))
         assert rc == 0
         return out
 

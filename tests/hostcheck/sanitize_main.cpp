@@ -40,6 +40,36 @@ int main() {
             if (hc_permute_coop(&cfg, g.data(), n) || g != a) return 7;
         }
     }
+    // the absorb / squeeze pass plan (pmx_sponge_plan.hpp) over every mode, index and length at several rates, and at the
+    // extremes of its 32-bit arithmetic: every element moved exactly once, in order, and no permutation in the last pass
+    for (int squeeze = 0; squeeze < 2; ++squeeze) {
+        for (uint32_t rate : {1u, 2u, 3u, 8u, 15u}) {
+            for (uint32_t tag = 0; tag < 2; ++tag) {
+                for (uint32_t index = 0; index <= rate + 1; ++index) {
+                    for (size_t len : {(size_t)0, (size_t)1, (size_t)rate - 0, (size_t)rate + 1, (size_t)3 * rate + 2, (size_t)1000003, (size_t)0x7fffffff}) {
+                        const size_t passes = hc_sponge_passes(squeeze, len, rate);
+                        if (!squeeze && len == 0) { if (passes != 0) return 8; continue; }
+                        uint64_t moved = 0, out[5];
+                        const size_t walk = len > 2000000 ? 4 : passes;    // (the longest lengths: the first passes and the last one)
+                        for (size_t p = 0; p < passes; ++p) {
+                            if (p >= walk && p + 1 < passes) continue;
+                            hc_sponge_pass(squeeze, tag, index, len, rate, 1, p, out);
+                            if (walk == passes) { if (out[3] && out[2] != moved) return 9; moved += out[3]; }
+                            if (out[1] + out[3] > rate + 1 || out[4] > rate) return 10;
+                            if (p + 1 == passes && out[0]) return 11;
+                        }
+                        if (walk == passes && moved != len) return 12;
+                    }
+                }
+            }
+        }
+    }
+    {   // a + b mod p on the ABI residues at the edges
+        const uint64_t pm1[4] = {bls[0] - 1, bls[1], bls[2], bls[3]}, one[4] = {1, 0, 0, 0};
+        uint64_t r[4];
+        if (hc_field_op(bls, 4, pm1, one, r) || r[0] || r[1] || r[2] || r[3]) return 13;
+        if (hc_field_op(bls, 4, pm1, pm1, r) || r[0] != bls[0] - 2 || r[3] != bls[3]) return 14;
+    }
     std::printf("sanitized ok\n");
     return 0;
 }
