@@ -48,6 +48,10 @@ WORKLOADS = {
     # the absorb/squeeze batch driver (pmx_hash_batch_dev): per row new; absorb(L); squeeze_native(1)
     "h3": ("bls12_381_fr", 2, 5, 8, 31, 20, None, 0x5EED0006, "bls12_381_fr t=3 alpha=5 hash of 4 elements -> 1 (2 permutations/row)"),
     "h9": ("bn254_fr", 8, 5, 8, 57, 18, None, 0x5EED0007, "bn254_fr t=9 alpha=5 hash of 8 elements -> 1 (1 permutation/row)"),
+    # the duplex driver on device-resident sponges with explicit mode words (pmx_sponge_absorb_batch_dev + pmx_sponge_squeeze_batch_dev):
+    # every step absorbs L elements into every sponge and squeezes K out of it, the sponges carried from step to step
+    "d3": ("bls12_381_fr", 2, 5, 8, 31, 20, None, 0x5EED0008, "bls12_381_fr t=3 alpha=5 duplex driver: absorb(4) + squeeze(3) per sponge and step (4 permutations)"),
+    "d9": ("bn254_fr", 8, 5, 8, 57, 18, None, 0x5EED0009, "bn254_fr t=9 alpha=5 duplex driver: absorb(11) + squeeze(9) per sponge and step (4 permutations)"),
     # the other widths of the reference's default table (src/test.rs:14-31), for tuning the wide-state engines
     "w4": ("bls12_381_fr", 3, 5, 8, 56, 19, None, 0x5EED0014, "bls12_381_fr t=4 alpha=5 RF=8 RP=56 permutation batch"),
     "w5": ("bls12_381_fr", 4, 5, 8, 56, 19, None, 0x5EED0015, "bls12_381_fr t=5 alpha=5 RF=8 RP=56 permutation batch"),
@@ -56,6 +60,9 @@ WORKLOADS = {
     "w8": ("bls12_381_fr", 7, 5, 8, 57, 18, None, 0x5EED0018, "bls12_381_fr t=8 alpha=5 RF=8 RP=57 permutation batch"),
 }
 HASH_SHAPES = {"h3": (4, 1, 2), "h9": (8, 1, 1)}     # workload -> (in_len, out_len, permutations per row)
+# workload -> (absorb length, squeeze length, permutations per sponge and step once the sponges are in their steady cycle:
+# a sponge left Squeezing{1} by squeeze(rate + 1) permutes at once when it absorbs, again when its rate fills, and twice in the squeeze)
+DUPLEX_SHAPES = {"d3": (4, 3, 4), "d9": (11, 9, 4)}
 BASELINE_CONFIG = {("c2", False): "BASELINE.json configs[1] (C2)", ("c2", True): "BASELINE.json configs[3] (C4)",
                    ("c3", False): "BASELINE.json configs[2] (C3)", ("c5", False): "BASELINE.json configs[4] (C5) on one GPU",
                    ("c5", True): "BASELINE.json configs[4] (C5)"}
@@ -216,6 +223,9 @@ def main():
     t = rate + 1
     merkle = args.workload == "c5"
     hashing = args.workload in HASH_SHAPES
+    duplex = args.workload in DUPLEX_SHAPES
+    if duplex and (world > 1 or args.warmup < 1):
+        raise SystemExit("the duplex-driver workloads run on one GPU and need --warmup >= 1 (the first step takes the fresh sponges into their steady cycle)")
     # ---- sizes: the BASELINE configuration of this (workload, N), unless overridden -----------------------------------
     if args.total_units is not None:
         n_total, scaling, baseline_cfg = args.total_units, "strong", None
@@ -280,8 +290,9 @@ def main():
     ctx = cfg.context(local_rank)
     if rank == 0:       # the issue slot at the dominant kernel's occupancy, measured before anything is timed
         early = _lib.PmxEngineInfo()
-        _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, _lib.OP_COMPRESS if args.workload == "c5" else (_lib.OP_HASH if args.workload in HASH_SHAPES else _lib.OP_PERMUTE),
-                                                  (n // 2 if args.workload == "c5" else n), 0, early))
+        _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, _lib.OP_COMPRESS if args.workload == "c5" else (_lib.OP_HASH if args.workload in HASH_SHAPES else
+                                                  (_lib.OP_ABSORB if args.workload in DUPLEX_SHAPES else _lib.OP_PERMUTE)),
+                                                  (n // 2 if args.workload == "c5" else n), DUPLEX_SHAPES.get(args.workload, (0,))[0], early))
         issue_slot(max(1, min(8, early.waves_per_simd)))
     if group is not None:
         stream = torch.cuda.ExternalStream(group.stream(0), device=dev)     # the library's stream of this device
@@ -295,7 +306,7 @@ def main():
 
     def fresh_inputs():
         """this rank's shard of the global seeded input, uploaded (used for the timed buffers and again for the check)"""
-        if hashing:
+        if hashing or duplex:
             host = synth.random_elements(field, n * in_len, seed, offset=start * in_len)
         elif merkle:
             host = synth.random_elements(field, n, seed, offset=start)
@@ -303,7 +314,22 @@ def main():
             host = synth.random_elements(field, n * t, seed, offset=start * t)
         return host, torch.from_numpy(host.view(np.int64).copy()).to(dev)
 
-    if hashing:
+    if duplex:
+        in_len, out_len, perms_per_row = DUPLEX_SHAPES[args.workload]
+        host_in, d_in = fresh_inputs()
+        d_out = torch.zeros((n, out_len, 4), dtype=torch.int64, device=dev)
+        d_st = torch.zeros((n, t, 4), dtype=torch.int64, device=dev)        # CryptographicSponge::new: zero state, Absorbing{0}
+        d_tag = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+        units_per_step = float(n_total) * perms_per_row
+
+        def step(i):
+            ctx.sponge_absorb_batch_dev(d_st.data_ptr(), d_tag.data_ptr(), d_idx.data_ptr(), d_in.data_ptr(), in_len, n, stream.cuda_stream)
+            ctx.sponge_squeeze_batch_dev(d_st.data_ptr(), d_tag.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), out_len, n, stream.cuda_stream)
+
+        def final_gather():
+            pass
+    elif hashing:
         in_len, out_len, perms_per_row = HASH_SHAPES[args.workload]
         host_in, d_in = fresh_inputs()
         d_out = torch.zeros((n, out_len, 4), dtype=torch.int64, device=dev)
@@ -416,14 +442,16 @@ def main():
         bytes_per_unit = 96 if merkle else 2 * t * 32       # 2*t*32 B per permutation; 64 in + 32 out per 2-to-1
         if hashing:
             bytes_per_unit = (in_len + out_len) * 32 / perms_per_row
+        if duplex:      # per sponge and step: the input row, the output row, and every permutation's state once in and once out
+            bytes_per_unit = ((in_len + out_len) * 32 + perms_per_row * 2 * t * 32) / perms_per_row
         algo_bytes = bytes_per_unit * per_gpu_units
         achieved = algo_bytes / kernel_s / 1e9
         # The engine as the library's own launchers dispatch it for this call (pmx_ctx_engine_info: schedule, table forms,
         # matrix-core rows, launch bound) - the instruction accounting below follows the kernels, not a copy of their rules.
         # ABI <-> internal conversions cost no multiplies on the optimised schedule (pmx_field.hpp: fe_from_abi_scaled).
         info = _lib.PmxEngineInfo()
-        op = _lib.OP_COMPRESS if merkle else (_lib.OP_HASH if hashing else _lib.OP_PERMUTE)
-        _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, op, (n // 2 if merkle else n), 0, info))
+        op = _lib.OP_COMPRESS if merkle else (_lib.OP_HASH if hashing else (_lib.OP_ABSORB if duplex else _lib.OP_PERMUTE))
+        _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, op, (n // 2 if merkle else n), (in_len if duplex else 0), info))
         mfma_dense = bool(info.mfma_dense)
         mads = mads_per_permutation(t, alpha, rf, rp, optimised=bool(info.optimised), row_tables=bool(info.row_tables),
                                     lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense)
@@ -460,7 +488,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "pmx::compress_kernel / compress_coop_kernel (per tree level)" if merkle else
-                                   ("pmx::hash_kernel" if hashing else "pmx::permute_kernel"),
+                                   ("pmx::hash_kernel" if hashing else ("the driver's kernels: " + info.engine.decode() if duplex else "pmx::permute_kernel")),
                          "kernel_ms": 1e3 * kernel_s, "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer-VALU bound, not HBM bound (DESIGN.md): see int_valu"},
             "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": peak.lane_mads_per_s,
@@ -511,7 +539,32 @@ def run_verification(env):
     def to_np(x):
         return x.cpu().numpy().view(np.uint64)
 
-    if env["hashing"]:
+    if env["duplex"]:
+        # two steps from fresh sponges (the second one runs the steady cycle the timed region runs), a sample sponge by sponge
+        in_len, out_len = env["in_len"], env["out_len"]
+        host, d_in = env["fresh_inputs"]()
+        st = torch.zeros((n, t, 4), dtype=torch.int64, device=dev)
+        tag = torch.zeros(n, dtype=torch.int32, device=dev)
+        idx_t = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_out = torch.zeros((n, out_len, 4), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ctx.sponge_absorb_batch_dev(st.data_ptr(), tag.data_ptr(), idx_t.data_ptr(), d_in.data_ptr(), in_len, n, stream.cuda_stream)
+            ctx.sponge_squeeze_batch_dev(st.data_ptr(), tag.data_ptr(), idx_t.data_ptr(), d_out.data_ptr(), out_len, n, stream.cuda_stream)
+        torch.cuda.synchronize()
+        idx = sample_indices(n, 512)
+        got_st, got_out = to_np(st).reshape(n, t, 4), to_np(d_out).reshape(n, out_len, 4)
+        rows = host.reshape(n, in_len, 4)
+        ok = True
+        for j in idx:
+            s_j, m_j, i_j = np.zeros((t, 4), dtype=np.uint64), 0, 0
+            for _ in range(2):
+                s_j, m_j, i_j = cr.sponge_absorb(s_j, m_j, i_j, rows[j])
+                s_j, m_j, i_j, o_j = cr.sponge_squeeze(s_j, m_j, i_j, out_len)
+            ok &= bool(np.array_equal(got_st[j], s_j) and np.array_equal(got_out[j], o_j) and int(tag[j]) == m_j and int(idx_t[j]) == i_j)
+        res["ok"] = ok
+        res["what"] = f"{len(idx)} of this rank's {n} sponges after two absorb + squeeze steps from fresh sponges: state, output and mode words"
+    elif env["hashing"]:
         in_len, out_len = env["in_len"], env["out_len"]
         host, d_in = env["fresh_inputs"]()
         d_out = torch.zeros((n, out_len, 4), dtype=torch.int64, device=dev)

@@ -25,6 +25,8 @@ if has bench; then
   timeout 600 python bench.py --workload c2 --total-log2 21 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_c2_2e21.json 2> $OUT/bench_c2_2e21.err
   timeout 600 python bench.py --workload h3 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_h3.json 2> $OUT/bench_h3.err
   timeout 600 python bench.py --workload h9 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_h9.json 2> $OUT/bench_h9.err
+  timeout 600 python bench.py --workload d3 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_d3.json 2> $OUT/bench_d3.err
+  timeout 600 python bench.py --workload d9 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_d9.json 2> $OUT/bench_d9.err
 fi
 if has widths; then
   for w in w4 w5 w6 w7 w8; do timeout 600 python bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
