@@ -25,7 +25,7 @@
  *
  * Threading: the host-buffer entry points of one pmx_ctx serialise on a lock inside the context (they share its
  * staging buffers and streams); the *_dev entry points only enqueue on the caller's stream and may be called
- * concurrently.  Distinct contexts are independent.  Every call runs with its context's device current and restores
+ * concurrently (the absorb / squeeze ones take a short lock inside the context while they enqueue).  Distinct contexts are independent.  Every call runs with its context's device current and restores
  * the calling thread's current HIP device before it returns; a `stream` argument must belong to the context's device.
  */
 #ifndef POSEIDON_MI355X_H
@@ -178,8 +178,9 @@ int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64
  * squeeze: FieldBasedCryptographicSponge::squeeze_native_field_elements(out_len) (mod.rs:321-341,
  * 153-182, including the `!= rate` test of :175).  Sponges in one call may be in different modes.
  * Widths 4..9 run a call as PASSES on the permutation engine of the width (one launch per permutation a sponge of the
- * batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would permute it); the _dev
- * variants take their pass lists from the stream-ordered allocator (hipMallocAsync on `stream`).  in_len, out_len < 2^31. */
+ * batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would permute it); the pass
+ * lists of the _dev variants live in a block the context keeps per caller stream (calls on different streams stay
+ * independent; concurrent calls of ONE context serialise while they enqueue).  in_len, out_len < 2^31. */
 int pmx_sponge_absorb_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
                             const uint64_t *in, size_t in_len, size_t n);
 int pmx_sponge_squeeze_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,

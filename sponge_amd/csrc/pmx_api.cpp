@@ -152,6 +152,10 @@ static int ctx_free(pmx_ctx *ctx) {
     }
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    // (the caller's streams are the caller's to drain before it destroys the context, as with every *_dev call)
+    for (auto &kv : ctx->pass_blocks)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (void *p : ctx->pass_retired) (void)hipFree(p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->d_consts) (void)hipFree(ctx->d_consts);
     delete ctx;
@@ -502,6 +506,24 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
 }
 
 // ---- duplex sponge driver ------------------------------------------------------------------------
+// PassScratch::get for a context: the block of this caller stream, grown if needed (called with ctx->pass_lock held)
+static hipError_t ctx_pass_scratch(void *owner, hipStream_t st, size_t bytes, uint32_t **out) {
+    pmx_ctx *ctx = static_cast<pmx_ctx *>(owner);
+    pmx_ctx::PassBlock &b = ctx->pass_blocks[st];
+    if (b.bytes < bytes) {
+        size_t want = b.bytes * 2 > bytes ? b.bytes * 2 : bytes;
+        want = (want + 4095) & ~(size_t)4095;
+        void *fresh = nullptr;
+        const hipError_t e = hipMalloc(&fresh, want);
+        if (e != hipSuccess) return e;
+        if (b.ptr) ctx->pass_retired.push_back(b.ptr);   // work already enqueued on `st` may still read it
+        b.ptr = fresh;
+        b.bytes = want;
+    }
+    *out = static_cast<uint32_t *>(b.ptr);
+    return hipSuccess;
+}
+
 extern "C" int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_tag, uint32_t *d_index,
                                            const uint64_t *d_in, size_t in_len, size_t n, void *stream) {
     if (!ctx || ((!d_states || !d_tag || !d_index) && n) || (!d_in && n && in_len))
@@ -509,9 +531,12 @@ extern "C" int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uin
     if (n == 0 || in_len == 0) return PMX_OK;  // absorbing an empty input changes nothing (mod.rs:234-236)
     if (!aligned16(d_states) || !aligned16(d_in)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
+    PMX_ABI_BEGIN("pmx_sponge_absorb_batch_dev")
     PMX_BIND(ctx);
-    PMX_HIP(launch_absorb(ctx->dev, ctx->t, d_states, d_tag, d_index, d_in, in_len, n, (hipStream_t)stream));
+    std::lock_guard<std::mutex> lock(ctx->pass_lock);
+    PMX_HIP(launch_absorb(ctx->dev, ctx->t, d_states, d_tag, d_index, d_in, in_len, n, (hipStream_t)stream, PassScratch{ctx, ctx_pass_scratch}));
     return PMX_OK;
+    PMX_ABI_END
 }
 
 extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_tag, uint32_t *d_index,
@@ -521,9 +546,12 @@ extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, ui
     if (n == 0) return PMX_OK;
     if (!aligned16(d_states) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
+    PMX_ABI_BEGIN("pmx_sponge_squeeze_batch_dev")
     PMX_BIND(ctx);
-    PMX_HIP(launch_squeeze(ctx->dev, ctx->t, d_states, d_tag, d_index, d_out, out_len, n, (hipStream_t)stream));
+    std::lock_guard<std::mutex> lock(ctx->pass_lock);
+    PMX_HIP(launch_squeeze(ctx->dev, ctx->t, d_states, d_tag, d_index, d_out, out_len, n, (hipStream_t)stream, PassScratch{ctx, ctx_pass_scratch}));
     return PMX_OK;
+    PMX_ABI_END
 }
 
 static constexpr size_t kSmallCallBytes = 64 * 1024;

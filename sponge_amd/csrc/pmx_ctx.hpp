@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <unordered_map>
+#include <vector>
 
 #include "../../include/poseidon_mi355x.h"
 #include "pmx_internal.hpp"
@@ -23,6 +25,15 @@ struct pmx_ctx {
     // handed out by pmx_ctx_acquire are shared between sponges (and threads), so those entry points take this lock;
     // the *_dev entry points only read the immutable fields and enqueue on the caller's stream.
     std::mutex host_lock;
+    // Pass lists of the wide-state absorb / squeeze drivers (pmx_device.hip: sponge_passes): one grow-only device block per
+    // CALLER STREAM - calls enqueued on one stream run one after the other, so they can share a block; calls on different
+    // streams get different ones and stay independent.  A block that is outgrown may still be in use by work already
+    // enqueued: it is retired, not freed, until the context goes.  pass_lock is held while a driver call enqueues, which
+    // also keeps two threads from interleaving their launches on one stream of this context.
+    struct PassBlock { void *ptr = nullptr; size_t bytes = 0; };
+    std::mutex pass_lock;
+    std::unordered_map<hipStream_t, PassBlock> pass_blocks;
+    std::vector<void *> pass_retired;
     // pmx_ctx_acquire / pmx_ctx_release bookkeeping (0 for contexts made by pmx_ctx_create)
     uint64_t cache_key = 0;
     long cache_refs = 0;

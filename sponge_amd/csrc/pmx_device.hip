@@ -1202,11 +1202,15 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
                           uint32_t *__restrict__ mode_tag, uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len,
                           uint32_t pass, uint32_t last_pass, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count,
                           uint32_t *__restrict__ list_next, uint32_t *__restrict__ count_next) {
-    const uint32_t count = *list_count;
+    // The count and the list were produced by the atomics and stores of the PREVIOUS launch, at addresses an earlier launch of
+    // this very call has already read (the two lists alternate, the counters share a cache line): they are read with
+    // device-scope atomic loads, past the scalar cache and the vector L1, which a back-to-back launch does not always
+    // find invalidated (tools/soak.py: calls with two or more listed passes lost sponges to a stale zero count).
+    const uint32_t count = __hip_atomic_load(const_cast<uint32_t *>(list_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((size_t)blockIdx.x * Engine::kThreads >= count) return;      // (the grid is sized for the whole batch)
     const size_t slot = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const bool active = slot < count;
-    const size_t sponge = list[active ? slot : 0];
+    const size_t sponge = __hip_atomic_load(const_cast<uint32_t *>(list) + (active ? slot : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
         Engine e(d, consts);
         uint64_t *mine = states + sponge * (size_t)(e.c.rate + e.c.capacity) * 4;
@@ -1257,23 +1261,23 @@ struct Launch {
         return hipGetLastError();
     }
     static hipError_t absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                             const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {
+                             const uint64_t *in, size_t in_len, size_t n, hipStream_t st, const PassScratch & = PassScratch{}) {
         hipLaunchKernelGGL(absorb_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
                            c.consts, states, tag, index, in, in_len, n);
         return hipGetLastError();
     }
     static hipError_t squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                              uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
+                              uint64_t *out, size_t out_len, size_t n, hipStream_t st, const PassScratch & = PassScratch{}) {
         hipLaunchKernelGGL(squeeze_kernel<Engine>, dim3(grid(n)), dim3(Engine::kThreads), Engine::lds_bytes(c, t), st, c,
                            c.consts, states, tag, index, out, out_len, n);
         return hipGetLastError();
     }
-    // the whole absorb / squeeze call as passes (pmx_sponge_plan.hpp): the start kernel, then one launch per permutation a
-    // sponge of the batch can need.  The two lists and the per-pass counters live in stream-ordered scratch (the _dev entry
-    // points stay re-entrant: nothing of the context is written).
+    // the whole absorb / squeeze call as passes (pmx_sponge_plan.hpp): pass 0 over the batch, then one launch per further
+    // permutation a sponge of the batch can need.  The two lists and the per-pass counters live in scratch the caller's
+    // context keeps per stream (PassScratch).
     template <bool SQUEEZE>
     static hipError_t sponge_passes(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index, uint64_t *io,
-                                    size_t len, size_t n, hipStream_t st) {
+                                    size_t len, size_t n, hipStream_t st, const PassScratch &provider) {
         const size_t passes = SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate);
         if (passes == 0 || n == 0) return hipSuccess;
         if (n > 0xffffffffull || len > kSpongeMaxLen) return hipErrorInvalidValue;
@@ -1285,7 +1289,9 @@ struct Launch {
         hipError_t e = hipSuccess;
         uint32_t *lists[2] = {nullptr, nullptr};
         if (last > 1) {                                  // a second permutation is possible: its sponges travel on a list
-            e = hipMallocAsync((void **)&scratch, (head + 2 * n) * 4, st);
+            // (NOT hipMallocAsync / hipFreeAsync: with several contexts - several streams - alive, ROCm 7.0's stream-ordered pool
+            // handed out blocks whose earlier use was still in flight; tools/soak.py lost sponges and took a memory fault that way)
+            e = provider.get(provider.owner, st, (head + 2 * n) * 4, &scratch);
             if (e != hipSuccess) return e;
             lists[0] = scratch + head;
             lists[1] = scratch + head + n;
@@ -1301,9 +1307,7 @@ struct Launch {
                                c.consts, states, tag, index, io, len, p, last, lists[p & 1], scratch + p, lists[(p + 1) & 1], scratch + p + 1);
             e = hipGetLastError();
         }
-        if (!scratch) return e;
-        const hipError_t e_free = hipFreeAsync(scratch, st);
-        return e != hipSuccess ? e : e_free;
+        return e;
     }
     // what a launch of `op` would run on (pmx_ctx_engine_info): filled by the engine, completed per kernel family here
     static hipError_t describe(const DevConfig &c, uint32_t t, int op, size_t len, EngineInfo *o) {
@@ -1376,13 +1380,13 @@ static bool hyb_use_mfma(const DevConfig &c, uint32_t t) {
 }
 template <int W, bool SQUEEZE>
 static hipError_t hyb_driver(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index, uint64_t *io, size_t len,
-                             size_t n, hipStream_t st) {
+                             size_t n, hipStream_t st, const PassScratch &scratch) {
     if constexpr (W >= PMX_HYB_PASS_MIN_T) {
         if constexpr (W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T) {
             if (hyb_use_mfma<W>(c, t))
-                return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::template sponge_passes<SQUEEZE>(c, t, states, tag, index, io, len, n, st);
+                return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::template sponge_passes<SQUEEZE>(c, t, states, tag, index, io, len, n, st, scratch);
         }
-        return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::template sponge_passes<SQUEEZE>(c, t, states, tag, index, io, len, n, st);
+        return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::template sponge_passes<SQUEEZE>(c, t, states, tag, index, io, len, n, st, scratch);
     } else {
         if constexpr (SQUEEZE) return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::squeeze(c, t, states, tag, index, io, len, n, st);
         else return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::absorb(c, t, states, tag, index, io, len, n, st);
@@ -1390,20 +1394,20 @@ static hipError_t hyb_driver(const DevConfig &c, uint32_t t, uint64_t *states, u
 }
 #define PMX_HYB_DRIVER(SQ, IO)                                                     \
     switch (t) {                                                                   \
-        case 4: return hyb_driver<4, SQ>(c, t, states, tag, index, IO, len, n, st); \
-        case 5: return hyb_driver<5, SQ>(c, t, states, tag, index, IO, len, n, st); \
-        case 6: return hyb_driver<6, SQ>(c, t, states, tag, index, IO, len, n, st); \
-        case 7: return hyb_driver<7, SQ>(c, t, states, tag, index, IO, len, n, st); \
-        case 8: return hyb_driver<8, SQ>(c, t, states, tag, index, IO, len, n, st); \
-        case 9: return hyb_driver<9, SQ>(c, t, states, tag, index, IO, len, n, st); \
+        case 4: return hyb_driver<4, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
+        case 5: return hyb_driver<5, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
+        case 6: return hyb_driver<6, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
+        case 7: return hyb_driver<7, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
+        case 8: return hyb_driver<8, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
+        case 9: return hyb_driver<9, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
         default: return hipErrorInvalidValue;                                      \
     }
 hipError_t PMX_HYB_NAME(absorb)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                                const uint64_t *in, size_t len, size_t n, hipStream_t st) {
+                                const uint64_t *in, size_t len, size_t n, hipStream_t st, const PassScratch &scratch) {
     PMX_HYB_DRIVER(false, const_cast<uint64_t *>(in));   // (the absorb form of the pass kernel only reads `io`)
 }
 hipError_t PMX_HYB_NAME(squeeze)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                                 uint64_t *out, size_t len, size_t n, hipStream_t st) {
+                                 uint64_t *out, size_t len, size_t n, hipStream_t st, const PassScratch &scratch) {
     PMX_HYB_DRIVER(true, out);
 }
 // pmx_ctx_engine_info for the hybrid family: the very conditions of the launchers above
@@ -1430,8 +1434,8 @@ hipError_t PMX_HYB_NAME(describe)(const DevConfig &c, uint32_t t, int op, size_t
     hipError_t P##permute(const DevConfig &, uint32_t, uint64_t *, size_t, hipStream_t);                                         \
     hipError_t P##hash(const DevConfig &, uint32_t, const uint64_t *, size_t, uint64_t *, size_t, size_t, hipStream_t);          \
     hipError_t P##compress(const DevConfig &, uint32_t, const uint64_t *, uint64_t *, size_t, hipStream_t);                      \
-    hipError_t P##absorb(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, const uint64_t *, size_t, size_t, hipStream_t); \
-    hipError_t P##squeeze(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint64_t *, size_t, size_t, hipStream_t); \
+    hipError_t P##absorb(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, const uint64_t *, size_t, size_t, hipStream_t, const PassScratch &); \
+    hipError_t P##squeeze(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint64_t *, size_t, size_t, hipStream_t, const PassScratch &); \
     hipError_t P##describe(const DevConfig &, uint32_t, int, size_t, EngineInfo *);
 PMX_HYB_DECL(hybrid5_)
 PMX_HYB_DECL(hybridg_)
@@ -1548,16 +1552,16 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
 }
 
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                         const uint64_t *in, size_t in_len, size_t n, hipStream_t st) {
+                         const uint64_t *in, size_t in_len, size_t n, hipStream_t st, const PassScratch &scratch) {
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(absorb_quad_kernel, states, tag, index, in, in_len, n);
-    PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st));
-    PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st));
+    PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
+    PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
 }
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                          uint64_t *out, size_t out_len, size_t n, hipStream_t st) {
+                          uint64_t *out, size_t out_len, size_t n, hipStream_t st, const PassScratch &scratch) {
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
-    PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st));
-    PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st));
+    PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
+    PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
 }
 
 // ---- pmx_ctx_engine_info: the same conditions, describing instead of launching ------------------------------------------

@@ -16,10 +16,17 @@ hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_
                        size_t n, hipStream_t st);
 // out[i] = 2-to-1 compression of in[2i], in[2i+1]   (rate >= 2)
 hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st);
+// Device scratch for the pass lists of the wide-state drivers (pmx_device.hip: sponge_passes): `get` hands out at least
+// `bytes` bytes that stay valid for everything enqueued on `st` by this call (pmx_api.cpp: one grow-only block per caller
+// stream, owned by the context).  Engines that need no lists never call it.
+struct PassScratch {
+    void *owner;
+    hipError_t (*get)(void *owner, hipStream_t st, size_t bytes, uint32_t **out);
+};
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                         const uint64_t *in, size_t in_len, size_t n, hipStream_t st);
+                         const uint64_t *in, size_t in_len, size_t n, hipStream_t st, const PassScratch &scratch);
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
-                          uint64_t *out, size_t out_len, size_t n, hipStream_t st);
+                          uint64_t *out, size_t out_len, size_t n, hipStream_t st, const PassScratch &scratch);
 
 // Authentication paths, one level per step (pmx_merkle_verify_paths_dev): pairs[i] = (cur[i], sibling) or (sibling, cur[i])
 // by bit `level` of indices[i], sibling = paths[i][level]; then ok[i] = (cur[i] == root) && indices[i] < 2^depth.

@@ -117,3 +117,23 @@ def test_wide_driver_device_resident_modes_out_of_range_are_clamped():
     for j in range(n):
         s, m, i = cr.sponge_absorb(st[j], 0, r, elems[j])
         assert np.array_equal(got[j], s) and int(d_idx[j]) == i == 3 and int(d_tag[j]) == 0, j
+
+
+def test_many_contexts_alive_and_calls_of_every_size_interleaved():
+    """Regression test for a failure only the soak found (tools/soak.py): with a dozen contexts - a dozen streams - alive and
+    calls of very different sizes following each other, the driver's pass lists, then taken from the stream-ordered
+    allocator (hipMallocAsync / hipFreeAsync), came back from the pool while still in use: calls with two or more listed
+    passes lost sponges (mode words never rewritten; the first one at the soak's tenth launch set) and one run ended in a
+    memory fault.  Only on the SYSTEM's HIP runtime (/opt/rocm, what a Rust or C++ caller gets): a process that has imported
+    torch runs on torch's bundled runtime, which did not show it - so this runs in a child process without torch.  The lists
+    now live in a block the context keeps per caller stream.  The soak's own first 60 launch sets: sixteen configs in turn,
+    sizes from 1 to 70001, lengths up to 3 rate + 2, random modes; every sponge (a sample above 300) of absorb + squeeze,
+    a permutation batch and a hash batch against the C port."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "600", "60"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=900, cwd=root)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "soak ok: 60 launches-sets" in out, out[-3000:]
