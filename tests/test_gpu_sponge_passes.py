@@ -9,7 +9,6 @@ import ctypes
 
 import numpy as np
 import pytest
-import torch  # noqa: F401  (before the library touches HIP: torch bundles its own HIP runtime and must be the first to load one)
 
 import sponge_amd as S
 from sponge_amd import _lib, synth
@@ -100,23 +99,35 @@ def test_wide_driver_mixed_modes_vs_c_oracle(case, layout):
 
 def test_wide_driver_device_resident_modes_out_of_range_are_clamped():
     """Device-resident mode words are not validated by the host (the host-buffer entry points are): an index above the rate
-    behaves as the rate, exactly as in the per-lane kernels (pmx_device.hip: absorb_kernel)."""
+    behaves as the rate, exactly as in the per-lane kernels (pmx_device.hip: absorb_kernel).  Through the ABI's own device
+    memory helpers (no torch: this file also runs in a torch-free child process, tests/test_gpu_system_runtime.py)."""
     f, cfg, cr = _config("bn254_fr", None, 254, 8, 5, 8, 57)
+    lib = _lib.lib()
     n, t, r = 300, 9, 8
     st = synth.random_elements(f, n * t, seed=21).reshape(n, t, 4)
-    tag = np.zeros(n, dtype=np.int32)
-    idx = np.full(n, r + 5, dtype=np.int32)
+    tag = np.zeros(n, dtype=np.uint32)
+    idx = np.full(n, r + 5, dtype=np.uint32)
     idx[::2] = r
     elems = synth.random_elements(f, n * 3, seed=22).reshape(n, 3, 4)
-    d_st, d_tag, d_idx = (torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x).to("cuda:0") for x in (st.copy(), tag, idx))
-    d_in = torch.from_numpy(elems.view(np.int64).copy()).to("cuda:0")
-    torch.cuda.synchronize()
-    cfg.context().sponge_absorb_batch_dev(d_st.data_ptr(), d_tag.data_ptr(), d_idx.data_ptr(), d_in.data_ptr(), 3, n, 0)
-    torch.cuda.synchronize()
-    got = d_st.cpu().numpy().view(np.uint64)
+
+    def to_device(arr):
+        p = ctypes.c_void_p()
+        _lib.check(lib.pmx_device_alloc(0, ctypes.byref(p), arr.nbytes))
+        _lib.check(lib.pmx_device_upload(0, p, ctypes.c_void_p(arr.ctypes.data), arr.nbytes, None))
+        return p
+
+    d_st, d_tag, d_idx, d_in = (to_device(np.ascontiguousarray(x)) for x in (st, tag, idx, elems))
+    _lib.check(lib.pmx_stream_synchronize(0, None))
+    cfg.context().sponge_absorb_batch_dev(d_st.value, d_tag.value, d_idx.value, d_in.value, 3, n, 0)
+    got, got_tag, got_idx = np.zeros_like(st), np.zeros_like(tag), np.zeros_like(idx)
+    for dst, src in ((got, d_st), (got_tag, d_tag), (got_idx, d_idx)):
+        _lib.check(lib.pmx_device_download(0, ctypes.c_void_p(dst.ctypes.data), src, dst.nbytes, None))
+    _lib.check(lib.pmx_stream_synchronize(0, None))
+    for p in (d_st, d_tag, d_idx, d_in):
+        lib.pmx_device_free(0, p)
     for j in range(n):
         s, m, i = cr.sponge_absorb(st[j], 0, r, elems[j])
-        assert np.array_equal(got[j], s) and int(d_idx[j]) == i == 3 and int(d_tag[j]) == 0, j
+        assert np.array_equal(got[j], s) and int(got_idx[j]) == i == 3 and int(got_tag[j]) == 0, j
 
 
 def test_many_contexts_alive_and_calls_of_every_size_interleaved():
