@@ -105,6 +105,10 @@ extern "C" {
     pub fn pmx_sponge_squeeze_batch_dev(ctx: *mut pmx_ctx, d_states: *mut u64, d_mode_tag: *mut u32, d_mode_index: *mut u32,
                                         d_out: *mut u64, out_len: usize, n: usize, stream: *mut c_void) -> c_int;
     pub fn pmx_merkle_2to1_dev(ctx: *mut pmx_ctx, d_nodes: *mut u64, n_leaves: usize, stream: *mut c_void) -> c_int;
+    pub fn pmx_merkle_2to1_forest(ctx: *mut pmx_ctx, leaves: *const u64, n_trees: usize, leaves_per_tree: usize, nodes: *mut u64,
+                                  roots: *mut u64) -> c_int;
+    pub fn pmx_merkle_2to1_forest_dev(ctx: *mut pmx_ctx, d_nodes: *mut u64, n_trees: usize, leaves_per_tree: usize,
+                                      stream: *mut c_void) -> c_int;
     pub fn pmx_merkle_paths(nodes: *const u64, n_leaves: usize, indices: *const u64, k: usize, paths_out: *mut u64) -> c_int;
     pub fn pmx_merkle_verify_paths(ctx: *mut pmx_ctx, leaves: *const u64, indices: *const u64, paths: *const u64, depth: usize,
                                    k: usize, root: *const u64, ok_out: *mut u8) -> c_int;

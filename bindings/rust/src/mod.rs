@@ -231,6 +231,15 @@ impl<F: PrimeField> BatchPoseidon<F> {
                                                     limbs(core::slice::from_ref(root)), ok.as_mut_ptr()) });
         ok.into_iter().map(|b| b != 0).collect()
     }
+    /// Roots of `n_trees` trees over `leaves` (tree after tree, each a power of two long), advanced together level by level:
+    /// the narrow top levels of a single tree are latency-bound, a level of the forest is `n_trees` times as wide.
+    pub fn merkle_forest_roots(&self, leaves: &[F], n_trees: usize) -> Vec<F> {
+        assert!(n_trees > 0 && leaves.len() % n_trees == 0, "leaves is not [n_trees][leaves_per_tree]");
+        let mut roots = vec![F::zero(); n_trees];
+        check(unsafe { ffi::pmx_merkle_2to1_forest(self.ctx.0, limbs(leaves), n_trees, leaves.len() / n_trees, core::ptr::null_mut(),
+                                                   limbs_mut(&mut roots)) });
+        roots
+    }
     /// 2-to-1 tree over `leaves` (power of two): all nodes, leaves first, root last.
     pub fn merkle(&self, leaves: &[F]) -> Vec<F> {
         let mut nodes = vec![F::zero(); 2 * leaves.len() - 1];

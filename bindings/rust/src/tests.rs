@@ -166,6 +166,8 @@ fn batch_entry_points_equal_n_reference_sponges() {
         level = parents;
     }
     assert_eq!(batch.merkle_root(&leaves), *nodes.last().unwrap());
+    // a forest: four trees of 16 leaves over the same 64 leaves = the level of the one tree that has four nodes
+    assert_eq!(batch.merkle_forest_roots(&leaves, 4), nodes[2 * 64 - 8..2 * 64 - 4].to_vec());
     let idx = [0u64, 5, 63];
     let paths = batch.merkle_paths(&nodes, &idx);
     let picked: Vec<Fr> = idx.iter().map(|&i| leaves[i as usize]).collect();

@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-/* 3: PMX_ERR_HOST, pmx_merkle_verify_paths_dev, indices >= 2^depth fail verification, pmx_ctx_engine_info;
+/* 3: PMX_ERR_HOST, pmx_merkle_verify_paths_dev, indices >= 2^depth fail verification, pmx_ctx_engine_info,
+ *    pmx_diag_issue_slot, pmx_merkle_2to1_forest[_dev];
  *    the test hooks left this header (poseidon_mi355x_testing.h). */
 #define PMX_ABI_VERSION 3
 #define PMX_LIMBS 4        /* uint64_t limbs per field element */
@@ -197,6 +198,18 @@ int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_m
 int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint64_t *nodes, uint64_t *root);
 /* Device variant: d_nodes [2*n_leaves-1][4] must already hold the leaves in its first n_leaves rows. */
 int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_leaves, void *stream);
+
+/* n_trees independent 2-to-1 trees of leaves_per_tree leaves each (a power of two; n_trees is any number >= 1), advanced
+ * TOGETHER level by level: the narrow top levels of one tree are latency-bound (a level of <= 16384 compressions costs one
+ * permutation's dependent chain whatever its width), a level of the forest is n_trees times as wide.  Layout, level-major:
+ * leaves: [n_trees][leaves_per_tree][4] (tree after tree); nodes (may be NULL): [n_trees * (2*leaves_per_tree - 1)][4] receives
+ * the leaves, then level 1 of every tree (tree after tree), ..., then the n_trees roots; roots (may be NULL): [n_trees][4].
+ * Tree b's node j of level l (level 0 = leaves, m = leaves_per_tree) is row  n_trees*(2m - 2m/2^l) + b*(m/2^l) + j.
+ * The device variant takes d_nodes with the leaves in its first n_trees*leaves_per_tree rows and only enqueues.
+ * (No counterpart in the reference: a parent is new; absorb([l, r]); squeeze_native(1) as above.) */
+int pmx_merkle_2to1_forest(pmx_ctx *ctx, const uint64_t *leaves, size_t n_trees, size_t leaves_per_tree, uint64_t *nodes,
+                           uint64_t *roots);
+int pmx_merkle_2to1_forest_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_trees, size_t leaves_per_tree, void *stream);
 
 /* Authentication paths over the node array pmx_merkle_2to1 produces ([2*n_leaves-1][4]: leaves, then every level, root
  * last).  The container itself lives upstream (ark-crypto-primitives), not in arkworks-rs/sponge; a parent is

@@ -118,6 +118,8 @@ SIGNATURES = {
                                                     ctypes.c_void_p]),
     "pmx_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p, _u64p]),
     "pmx_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, ctypes.c_void_p]),
+    "pmx_merkle_2to1_forest": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _sz, _u64p, _u64p]),
+    "pmx_merkle_2to1_forest_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _sz, ctypes.c_void_p]),
     "pmx_merkle_paths": (ctypes.c_int, [_u64p, _sz, _u64p, _sz, _u64p]),
     "pmx_merkle_verify_paths": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u64p, _u64p, _sz, _sz, _u64p, ctypes.c_void_p]),
     "pmx_merkle_verify_paths_dev": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u64p, _u64p, _sz, _sz, _u64p, ctypes.c_void_p, _u64p,

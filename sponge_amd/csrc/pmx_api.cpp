@@ -658,6 +658,58 @@ extern "C" int pmx_merkle_2to1_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_lea
     return PMX_OK;
 }
 
+// ---- many trees at once ------------------------------------------------------------------------------
+// The levels of ONE tree narrow down to a single compression, and a level of at most 16384 compressions costs the same 65 us
+// whatever its width (one permutation's dependent chain): 15 such levels are a quarter of a 2^21-leaf tree's
+// time.  n_trees trees of the same size advance TOGETHER, level by level: with the leaves laid out tree after tree, level l of
+// every tree is one contiguous array, its pairs never straddle two trees (leaves_per_tree is a power of two), and the narrowest
+// level launched is n_trees compressions wide.  It is the first log2(leaves_per_tree) levels of one tree over all the leaves.
+static int forest_shape(size_t n_trees, size_t leaves_per_tree, size_t *total_leaves, size_t *total_nodes) {
+    if (n_trees == 0 || leaves_per_tree == 0 || (leaves_per_tree & (leaves_per_tree - 1)))
+        return set_error(PMX_ERR_ARG, "a forest needs n_trees >= 1 and leaves_per_tree a power of two");
+    if (n_trees > (SIZE_MAX / 128) / leaves_per_tree) return set_error(PMX_ERR_ARG, "forest byte size overflows size_t");
+    *total_leaves = n_trees * leaves_per_tree;
+    *total_nodes = n_trees * (2 * leaves_per_tree - 1);
+    return PMX_OK;
+}
+
+extern "C" int pmx_merkle_2to1_forest_dev(pmx_ctx *ctx, uint64_t *d_nodes, size_t n_trees, size_t leaves_per_tree, void *stream) {
+    if (!ctx || !d_nodes) return set_error(PMX_ERR_ARG, "pmx_merkle_2to1_forest_dev: null pointer");
+    size_t total = 0, n_nodes = 0;
+    if (int rc = forest_shape(n_trees, leaves_per_tree, &total, &n_nodes)) return rc;
+    if (ctx->dev.rounds.rate < 2) return set_error(PMX_ERR_CONFIG, "2-to-1 compression needs rate >= 2");
+    if (!aligned16(d_nodes)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
+    PMX_BIND(ctx);
+    size_t src = 0, width = total;
+    while (width > n_trees) {      // level l of all trees: [src, src + width) -> [src + width, src + width + width / 2)
+        PMX_HIP(launch_compress(ctx->dev, ctx->t, d_nodes + src * 4, d_nodes + (src + width) * 4, width / 2, (hipStream_t)stream));
+        src += width;
+        width /= 2;
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_merkle_2to1_forest(pmx_ctx *ctx, const uint64_t *leaves, size_t n_trees, size_t leaves_per_tree, uint64_t *nodes,
+                                      uint64_t *roots) {
+    PMX_ABI_BEGIN("pmx_merkle_2to1_forest")
+    if (!ctx || !leaves) return set_error(PMX_ERR_ARG, "pmx_merkle_2to1_forest: null pointer");
+    size_t total = 0, n_nodes = 0;
+    int rc = forest_shape(n_trees, leaves_per_tree, &total, &n_nodes);
+    if (rc) return rc;
+    PMX_BIND(ctx);
+    std::lock_guard<std::mutex> lock(ctx->host_lock);
+    void *d = nullptr;
+    if ((rc = ctx_scratch(ctx, 0, n_nodes * 32, &d))) return rc;
+    StreamDrain drain{ctx};
+    PMX_HIP(hipMemcpyAsync(d, leaves, total * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pmx_merkle_2to1_forest_dev(ctx, (uint64_t *)d, n_trees, leaves_per_tree, ctx->stream))) return rc;
+    if (nodes) PMX_HIP(hipMemcpyAsync(nodes, d, n_nodes * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (roots) PMX_HIP(hipMemcpyAsync(roots, (uint64_t *)d + (n_nodes - n_trees) * 4, n_trees * 32, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_ABI_END
+}
+
 extern "C" int pmx_merkle_2to1(pmx_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint64_t *nodes, uint64_t *root) {
     PMX_ABI_BEGIN("pmx_merkle_2to1")
     if (!ctx || !leaves) return set_error(PMX_ERR_ARG, "pmx_merkle_2to1: null pointer");

@@ -242,6 +242,20 @@ class Context:
         _lib.check(_lib.lib().pmx_merkle_2to1(self._h, _ptr(leaves), m, _ptr(nodes), _ptr(root)))
         return nodes, root
 
+    def merkle_2to1_forest(self, leaves: np.ndarray, n_trees: int, want_nodes: bool = True):
+        """n_trees trees over leaves [n_trees][m][4], advanced together level by level (pmx_merkle_2to1_forest).  Returns
+        (nodes, roots): nodes [n_trees * (2m - 1)][4] level-major - all leaves, then level 1 of every tree, ... - or None."""
+        leaves = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, 4)
+        m = leaves.shape[0] // n_trees
+        assert m * n_trees == leaves.shape[0]
+        nodes = np.zeros((n_trees * (2 * m - 1), 4), dtype=np.uint64) if want_nodes else None
+        roots = np.zeros((n_trees, 4), dtype=np.uint64)
+        _lib.check(_lib.lib().pmx_merkle_2to1_forest(self._h, _ptr(leaves), n_trees, m, _ptr(nodes), _ptr(roots)))
+        return nodes, roots
+
+    def merkle_2to1_forest_dev(self, d_nodes: int, n_trees: int, leaves_per_tree: int, stream: int = 0) -> None:
+        _lib.check(_lib.lib().pmx_merkle_2to1_forest_dev(self._h, d_nodes, n_trees, leaves_per_tree, stream))
+
     # ---- device-pointer entry points (only enqueue; pointers are raw device addresses) ---------
     def permute_batch_dev(self, d_states: int, n: int, stream: int = 0) -> None:
         _lib.check(_lib.lib().pmx_permute_batch_dev(self._h, d_states, n, stream))

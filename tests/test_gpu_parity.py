@@ -586,3 +586,48 @@ def test_one_lane_element_form_kernels_between_the_switches(name):
     assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0))
     msgs = synth.random_elements(cfg.field, n * 5, seed=0x5EED0061).reshape(n, 5, 4)
     assert np.array_equal(cfg.context().hash_batch(msgs, 5, 3), cr.hash_batch(msgs, 5, 3, threads=0))
+
+
+@pytest.mark.parametrize("n_trees,m", [(1, 64), (3, 16), (5, 1), (1000, 4), (77, 128), (40000, 2), (300, 1024)])
+def test_merkle_forest_vs_c_oracle(n_trees, m):
+    """pmx_merkle_2to1_forest: n_trees trees of m leaves advanced together level by level (a level of the forest is one launch
+    over all trees).  Every node of every tree against the C port's tree of that tree's leaves; the level-major layout of the
+    header; a forest of one tree is pmx_merkle_2to1's node array.  A parent is new; absorb([l, r]); squeeze_native(1)
+    (mod.rs:219-254, 321-341)."""
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    cr = c_oracle(name)
+    leaves = synth.random_elements(cfg.field, n_trees * m, seed=0x5EED00F0 + n_trees + m).reshape(n_trees, m, 4)
+    nodes, roots = cfg.context().merkle_2to1_forest(leaves, n_trees)
+    assert nodes.shape == (n_trees * (2 * m - 1), 4)
+    # the C port builds ONE tree over all the leaves: the forest is its first log2(m) levels, and those ARE level-major
+    # (pairs never straddle two trees); pad the tree count to a power of two for the checker only
+    pad = 1 << (n_trees - 1).bit_length()
+    padded = np.zeros((pad * m, 4), dtype=np.uint64)
+    padded[:n_trees * m] = leaves.reshape(-1, 4)
+    big = cr.merkle(padded, threads=0)
+    src_f = src_b = 0
+    width = m
+    while width >= 1:
+        assert np.array_equal(nodes[src_f:src_f + n_trees * width], big[src_b:src_b + n_trees * width]), (n_trees, m, width)
+        src_f += n_trees * width
+        src_b += pad * width
+        width //= 2
+    assert np.array_equal(roots, nodes[-n_trees:])
+    for b in sorted({0, n_trees // 2, n_trees - 1}):                       # and a few trees on their own
+        assert np.array_equal(roots[b], cr.merkle(leaves[b], threads=1)[-1])
+    if n_trees == 1:
+        one, root = cfg.context().merkle_2to1(leaves[0])
+        assert np.array_equal(one, nodes) and np.array_equal(root, roots[0])
+
+
+def test_merkle_forest_bad_arguments():
+    cfg = product_config("bls_t3_a5_8_31")
+    leaves = synth.random_elements(cfg.field, 12, seed=1)
+    with pytest.raises(S.PmxError):
+        cfg.context().merkle_2to1_forest(leaves, 4)                          # 3 leaves per tree: not a power of two
+    lib = S.lib()
+    import ctypes
+    assert lib.pmx_merkle_2to1_forest(cfg.context()._h, ctypes.c_void_p(leaves.ctypes.data), 0, 4, None, None) == -2
+    assert lib.pmx_merkle_2to1_forest(cfg.context()._h, None, 1, 4, None, None) == -2
+    assert lib.pmx_merkle_2to1_forest_dev(cfg.context()._h, None, 1, 4, None) == -2
