@@ -56,7 +56,7 @@ if has widepmc; then
 fi
 if has slots; then
   # SQ_INSTS_VALU of the dominant kernel of each bench workload -> profiles/valu_instructions.json entries
-  for w in c2 c3 w7 w8 h3 h9; do
+  for w in c2 c3 w4 w5 w6 w7 w8 h3 h9; do
     timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/slots_$w -- python3 $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-verify > $OUT/slots_$w.log 2>&1
   done
 fi
@@ -81,6 +81,9 @@ if has slots; then
   J=$OUT/valu_instructions.json; rm -f $J
   python tools/valu_count.py $OUT/slots_c2 permute_kernel c2 1048576 "RegEngine<3,5,opt,tab>" 4 $J "profiles/r04" > $OUT/valu_count.log 2>&1
   python tools/valu_count.py $OUT/slots_c3 permute_kernel c3 262144 "HybridEngine<9,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w4 permute_kernel w4 524288 "HybridEngine<4,5,valu>" 4 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w5 permute_kernel w5 524288 "HybridEngine<5,5,valu>" 3 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w6 permute_kernel w6 262144 "HybridEngine<6,5,valu>" 3 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
   python tools/valu_count.py $OUT/slots_w7 permute_kernel w7 262144 "HybridEngine<7,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
   python tools/valu_count.py $OUT/slots_w8 permute_kernel w8 262144 "HybridEngine<8,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
   python tools/valu_count.py $OUT/slots_h3 hash_kernel h3 2097152 "RegEngine<3,5,opt,tab>" 4 $J "profiles/r04" 2 >> $OUT/valu_count.log 2>&1
