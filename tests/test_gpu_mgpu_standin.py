@@ -1,5 +1,5 @@
 """World > 1 on ONE GPU: every multi-rank branch of the device-group code (sponge_amd/csrc/pmx_mgpu.cpp) through the real
-C ABI, with W = 2, 3, 8 "ranks" sharing cuda:0 behind a stand-in for librccl.so.1 (tests/fake_rccl: collectives performed
+C ABI, with W = 2, 3, 8, 16 "ranks" sharing cuda:0 behind a stand-in for librccl.so.1 (tests/fake_rccl: collectives performed
 as device-to-device copies on the caller's streams, every range and every rank's call sequence checked).
 
 Why: the boxes this is developed on have one GPU and RCCL refuses two ranks on one device, so BASELINE's configs[3]
@@ -39,7 +39,7 @@ def _child_env(libdir):
     return env
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("world", [2, 3, 8, 16])
 def test_every_multi_rank_branch_on_one_gpu(world, tmp_path):
     _ensure_fake()
     out = str(tmp_path / f"standin_w{world}.json")
