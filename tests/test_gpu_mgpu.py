@@ -331,3 +331,56 @@ def test_group_and_path_edge_cases():
     assert S.verify_paths(cfg, one, [0], np.zeros((1, 0, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64)).tolist() == [False]
     assert S.verify_paths(cfg, np.zeros((0, 4), dtype=np.uint64), [], np.zeros((0, 3, 4), dtype=np.uint64), one[0]).tolist() == []
     g.close()
+
+
+def test_wide_driver_dev_calls_from_several_threads_on_their_own_streams():
+    """The *_dev absorb / squeeze calls of ONE context from four host threads, each on its own stream with its own sponges:
+    the pass lists live in a block per caller stream (pmx_ctx::pass_blocks) and the calls serialise only while they enqueue,
+    so the threads' work overlaps on the device and must not disturb each other.  BN254 Fr t = 9 (passes on the matrix-core
+    engine), several listed passes per call; every thread's sponges against the C port."""
+    import threading
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BN254_FR
+    cfg = S.poseidon_config_from_lfsr(f, 8, 5, 8, 57)
+    cr = cref.CRef(O.make_config(O.BN254_FR, 254, 8, 5, 8, 57))
+    ctx = cfg.context(0)
+    n, t, L, K = 3000, 9, 19, 26
+    errors = []
+
+    def worker(k):
+        try:
+            rng = np.random.default_rng(100 + k)
+            st = synth.random_elements(f, n * t, seed=500 + k).reshape(n, t, 4)
+            tag = rng.integers(0, 2, n).astype(np.int32)
+            idx = rng.integers(0, 9, n).astype(np.int32)
+            msgs = synth.random_elements(f, n * L, seed=600 + k).reshape(n, L, 4)
+            stream = torch.cuda.Stream(device="cuda:0")
+            with torch.cuda.stream(stream):
+                d_st = torch.from_numpy(st.view(np.int64).copy()).to("cuda:0")
+                d_tag, d_idx = torch.from_numpy(tag).to("cuda:0"), torch.from_numpy(idx).to("cuda:0")
+                d_in = torch.from_numpy(msgs.view(np.int64).copy()).to("cuda:0")
+                d_out = torch.zeros((n, K, 4), dtype=torch.int64, device="cuda:0")
+            stream.synchronize()
+            for _ in range(3):          # absorb + squeeze three times over: the modes of one round feed the next
+                ctx.sponge_absorb_batch_dev(d_st.data_ptr(), d_tag.data_ptr(), d_idx.data_ptr(), d_in.data_ptr(), L, n, stream.cuda_stream)
+                ctx.sponge_squeeze_batch_dev(d_st.data_ptr(), d_tag.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), K, n, stream.cuda_stream)
+            stream.synchronize()
+            got_st, got_out = d_st.cpu().numpy().view(np.uint64), d_out.cpu().numpy().view(np.uint64)
+            got_tag, got_idx = d_tag.cpu().numpy(), d_idx.cpu().numpy()
+            for j in rng.choice(n, 150, replace=False):
+                s, m, i = st[j], int(tag[j]), int(idx[j])
+                for _ in range(3):
+                    s, m, i = cr.sponge_absorb(s, m, i, msgs[j])
+                    s, m, i, o = cr.sponge_squeeze(s, m, i, K)
+                if not (np.array_equal(got_st[j], s) and np.array_equal(got_out[j], o) and (int(got_tag[j]), int(got_idx[j])) == (m, i)):
+                    errors.append((k, int(j)))
+        except Exception as e:          # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
