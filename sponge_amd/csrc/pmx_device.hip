@@ -341,16 +341,39 @@ struct HybridEngine {
     // moves 64 T bytes in ~2 ms of arithmetic: nothing to gain from staging the wave's span through LDS, and without the
     // staging code (two barriers, the T-element gather) the register allocation of the permute kernel comes out like that of
     // the hash kernel (no spills inside the rounds).
-    __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
-        const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
-        const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + (gid < n ? gid : 0) * kChunks;
+    // the T elements at g into the registers; `adjust(i, element)` may replace an element on its way in (the absorb driver
+    // adds its input there, on the ABI residues, before the bit-slicing - absorb_adjust below)
+    template <class Adjust>
+    __device__ __forceinline__ void load_elements(const uint4 *g, const Adjust &adjust) {
         if constexpr (PMX_HYB_ROLLED_LOAD(T)) {
             zero();
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (uint32_t i = 0; i < (uint32_t)T; ++i) set(i, from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])));
+            for (uint32_t i = 0; i < (uint32_t)T; ++i) set(i, from_abi(adjust(i, abi_from_u4(g[2 * i], g[2 * i + 1]))));
         } else {
-            static_for<0, T>([&](auto i) { s[i] = from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])); });
+            static_for<0, T>([&](auto i) { s[i] = from_abi(adjust((uint32_t)i, abi_from_u4(g[2 * i], g[2 * i + 1]))); });
         }
+    }
+    struct NoAdjust {
+        __device__ __forceinline__ Abi operator()(uint32_t, const Abi &a) const { return a; }
+    };
+    // state[pos + j] += row[j] for j < count (mod.rs:128,143), as the state comes in: both fully reduced residues, one
+    // 256-bit add and one conditional subtraction (abi_add_mod); count is per lane, 0 for a lane that absorbs nothing here
+    struct AbsorbAdjust {
+        const uint32_t *row, *p32;
+        uint32_t pos, count;
+        __device__ __forceinline__ Abi operator()(uint32_t i, const Abi &a) const {
+            const uint32_t j = i - pos;
+            if (j < count) return abi_add_mod(a, abi_load(row + 8 * j), p32);
+            return a;
+        }
+    };
+    __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
+        const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
+        load_elements(reinterpret_cast<const uint4 *>(g_states) + (gid < n ? gid : 0) * kChunks, NoAdjust{});
+    }
+    __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n, const AbsorbAdjust &add) {
+        const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
+        load_elements(reinterpret_cast<const uint4 *>(g_states) + (gid < n ? gid : 0) * kChunks, add);
     }
 
 #if PMX_HYB_STAGED_STORE
@@ -450,20 +473,26 @@ struct HybridEngine {
     // One state per lane at a per-lane address (permute_listed_kernel: the sponges of a pass, gathered through an index
     // list).  Every lane reads and writes its own 32 T contiguous bytes with 16-byte accesses: each line is used in full by
     // the lane that owns it.
-    __device__ __forceinline__ void load_state_at(const uint64_t *mine) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(mine);
-        if constexpr (PMX_HYB_ROLLED_LOAD(T)) {
-            zero();
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (uint32_t i = 0; i < (uint32_t)T; ++i) set(i, from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])));
-        } else {
-            static_for<0, T>([&](auto i) { s[i] = from_abi(abi_from_u4(g[2 * i], g[2 * i + 1])); });
-        }
+    __device__ __forceinline__ void load_state_at(const uint64_t *mine, const AbsorbAdjust &add) {
+        load_elements(reinterpret_cast<const uint4 *>(mine), add);
     }
     // store_states for the sponges of this wave whose `keep` bit is set (sponge_first_kernel: the permutation ran for the whole
     // workgroup, only the sponges that needed it take its result).  Staged through the wave's region like store_states: a
     // 16-byte write instruction covers whole states, so the predicate travels as the wave's ballot.
-    __device__ __forceinline__ void store_states_where(uint64_t *g_states, size_t n, uint64_t keep_mask) {
+    // rate elements copied out of the state that is being stored (squeeze, mod.rs:159-170): out[j] = state[pos + j], j < count,
+    // read from the wave's LDS staging, where every element already sits fully reduced in ABI form; count is per lane
+    struct CopyOut {
+        uint32_t *row;
+        uint32_t pos, count;
+    };
+    __device__ __forceinline__ void copy_out_staged(const CopyOut &out) const {
+        for (uint32_t j = 0; j < out.count; ++j) {
+            uint4 *dst = reinterpret_cast<uint4 *>(out.row + 8 * j);
+            dst[0] = region[lane * kChunks + 2 * (out.pos + j)];
+            dst[1] = region[lane * kChunks + 2 * (out.pos + j) + 1];
+        }
+    }
+    __device__ __forceinline__ void store_states_where(uint64_t *g_states, size_t n, uint64_t keep_mask, const CopyOut &out) {
         const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
         const size_t valid = n > first ? (n - first < (size_t)64 ? n - first : (size_t)64) : 0;
         uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * kChunks;
@@ -481,13 +510,14 @@ struct HybridEngine {
             const uint32_t q = lane + k * 64;
             if (q < n_chunks && ((keep_mask >> (q / kChunks)) & 1)) g[q] = region[q];
         }
+        copy_out_staged(out);
         __syncthreads();
     }
 
     // `together`: the wave's active lanes hold CONSECUTIVE states starting at wave_base (a prefix of the lanes) - then the
     // wave's span goes out as whole kilobytes like store_states does; otherwise every lane writes its own state.  Either
     // way the T exact reductions happen once, into the wave's LDS region.
-    __device__ __forceinline__ void store_state_at(uint64_t *mine, bool keep, bool together, uint64_t *wave_base, uint32_t valid) {
+    __device__ __forceinline__ void store_state_at(uint64_t *mine, bool keep, bool together, uint64_t *wave_base, uint32_t valid, const CopyOut &out) {
         __syncthreads();
         static_for<0, T>([&](auto i) {
             const Abi a = to_abi(s[i]);
@@ -509,6 +539,7 @@ struct HybridEngine {
 #pragma clang loop unroll(disable)
             for (int k = 0; k < kChunks; ++k) g[k] = region[lane * kChunks + k];
         }
+        copy_out_staged(out);
         __syncthreads();
     }
 
@@ -1134,14 +1165,19 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
 template <bool SQUEEZE>
 __device__ __forceinline__ bool sponge_walk(const Rounds &c, const uint32_t *__restrict__ p32, uint64_t *__restrict__ states, uint32_t *__restrict__ mode_tag,
                                             uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len, size_t sponge, bool active,
-                                            uint32_t pass, uint32_t last_pass) {
+                                            uint32_t pass, uint32_t last_pass, bool first_move_done = false) {
     if (!active) return false;
     const uint32_t tag = mode_tag[sponge], index = mode_index[sponge], t_all = c.rate + c.capacity;
     for (uint32_t q = pass;; ++q) {
         const SpongePass sp = SQUEEZE ? squeeze_pass(tag, index, (uint32_t)len, c.rate, c.capacity, q) : absorb_pass(tag, index, (uint32_t)len, c.rate, c.capacity, q);
+        // absorb: the chunk in front of a permutation is added by the kernel that permutes, as the state comes into its
+        // registers (AbsorbAdjust) - only a chunk no permutation follows is added here, in memory
+        if (!SQUEEZE && sp.permute) return true;
         uint32_t *st = reinterpret_cast<uint32_t *>(states + (sponge * t_all + sp.state_pos) * 4);
         uint32_t *row = reinterpret_cast<uint32_t *>(io + (sponge * len + sp.first) * 4);
-        for (uint32_t j = 0; j < sp.count; ++j) {
+        // squeeze: the chunk right behind a permutation was copied out of the LDS staging by the kernel that permuted (CopyOut)
+        const uint32_t todo = (SQUEEZE && first_move_done && q == pass) ? 0 : sp.count;
+        for (uint32_t j = 0; j < todo; ++j) {
             if constexpr (SQUEEZE) {
                 abi_store(row + 8 * j, abi_load(st + 8 * j));
             } else {
@@ -1185,14 +1221,28 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     const uint64_t due_mask = __builtin_amdgcn_ballot_w64(due);       // wave-uniform: the only thing live across the permutation
     {
         Engine e(d, consts);
-        e.load_states(states, n);
+        typename Engine::AbsorbAdjust add{nullptr, p32, 0, 0};
+        if (!SQUEEZE && due) {   // the chunk in front of this sponge's permutation 0 (none if its mode asks for the permutation up front)
+            const SpongePass sp = absorb_pass(mode_tag[gid], mode_index[gid], (uint32_t)len, d.rounds.rate, d.rounds.capacity, 0);
+            add.row = reinterpret_cast<const uint32_t *>(io + (gid * len + sp.first) * 4);
+            add.pos = sp.state_pos;
+            add.count = sp.count;
+        }
+        e.load_states(states, n, add);
         e.permute(0, e.c.rate + e.c.capacity);   // (run-time width: see permute_kernel)
-        e.store_states_where(states, n, due_mask);
+        typename Engine::CopyOut out{nullptr, 0, 0};
+        if (SQUEEZE && ((due_mask >> (threadIdx.x & 63)) & 1)) {   // the chunk right behind permutation 0
+            const SpongePass sp = squeeze_pass(mode_tag[gid], mode_index[gid], (uint32_t)len, d.rounds.rate, d.rounds.capacity, 1);
+            out.row = reinterpret_cast<uint32_t *>(io + (gid * len + sp.first) * 4);
+            out.pos = sp.state_pos;
+            out.count = sp.count;
+        }
+        e.store_states_where(states, n, due_mask, out);
     }
     const bool mine_due = (due_mask >> (threadIdx.x & 63)) & 1;
     // (the wave's span was written by other lanes of the SAME wave after a workgroup barrier: make it visible to this lane's loads)
     __threadfence_block();
-    const bool again = sponge_walk<SQUEEZE>(d.rounds, p32, states, mode_tag, mode_index, io, len, gid, mine_due, 1, last_pass);
+    const bool again = sponge_walk<SQUEEZE>(d.rounds, p32, states, mode_tag, mode_index, io, len, gid, mine_due, 1, last_pass, true);
     sponge_queue(again, gid, list1, count1);
 }
 
@@ -1214,18 +1264,33 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     {
         Engine e(d, consts);
         uint64_t *mine = states + sponge * (size_t)(e.c.rate + e.c.capacity) * 4;
-        e.load_state_at(mine);
+        const uint32_t *p32 = consts + d.io_offset + kIoP32;
+        typename Engine::AbsorbAdjust add{nullptr, p32, 0, 0};
+        if (!SQUEEZE && active) {    // the chunk in front of this sponge's permutation `pass`
+            const SpongePass sp = absorb_pass(mode_tag[sponge], mode_index[sponge], (uint32_t)len, d.rounds.rate, d.rounds.capacity, pass);
+            add.row = reinterpret_cast<const uint32_t *>(io + (sponge * len + sp.first) * 4);
+            add.pos = sp.state_pos;
+            add.count = sp.count;
+        }
+        e.load_state_at(mine, add);
         e.permute(0, e.c.rate + e.c.capacity);   // (run-time width: see permute_kernel)
+        typename Engine::CopyOut out{nullptr, 0, 0};
+        if (SQUEEZE && active) {     // the chunk right behind it
+            const SpongePass sp = squeeze_pass(mode_tag[sponge], mode_index[sponge], (uint32_t)len, d.rounds.rate, d.rounds.capacity, pass + 1);
+            out.row = reinterpret_cast<uint32_t *>(io + (sponge * len + sp.first) * 4);
+            out.pos = sp.state_pos;
+            out.count = sp.count;
+        }
         // a batch in ONE mode lists whole waves of consecutive sponges (the start kernel appends a wave's sponges in lane order)
         const uint32_t lane = threadIdx.x & 63;
         const size_t lead = (size_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sponge) | ((size_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sponge >> 32)) << 32);
         const uint64_t live = __builtin_amdgcn_ballot_w64(active);
         const bool together = __builtin_amdgcn_ballot_w64(!active || sponge == lead + lane) == ~0ull;
-        e.store_state_at(mine, active, together, states + lead * (size_t)(e.c.rate + e.c.capacity) * 4, (uint32_t)__builtin_popcountll(live));
+        e.store_state_at(mine, active, together, states + lead * (size_t)(e.c.rate + e.c.capacity) * 4, (uint32_t)__builtin_popcountll(live), out);
     }
     // (written through the wave's LDS region by the lanes of the SAME wave: make it visible to this lane's loads)
     __threadfence_block();
-    const bool again = sponge_walk<SQUEEZE>(d.rounds, consts + d.io_offset + kIoP32, states, mode_tag, mode_index, io, len, sponge, active, pass + 1, last_pass);
+    const bool again = sponge_walk<SQUEEZE>(d.rounds, consts + d.io_offset + kIoP32, states, mode_tag, mode_index, io, len, sponge, active, pass + 1, last_pass, true);
     sponge_queue(again, sponge, list_next, count_next);
 }
 
