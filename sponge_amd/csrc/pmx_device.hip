@@ -1152,16 +1152,19 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWavesDriver)
 
 // The absorb / squeeze driver of the wide states as PASSES (pmx_sponge_plan.hpp; mod.rs:121-182, 232-254, 321-341).
 // A sponge's call alternates data movement and permutations; pass p is "the sponge's own p-th permutation, then whatever
-// follows it up to the next one".  Every lane WALKS its own sponge between permutations (sponge_walk): chunks are moved in
-// global memory - input elements added into the rate portion (field addition on the ABI residues, mod.rs:128,143) or rate
-// elements copied out (mod.rs:159-170) - until a permutation is due or the call is over (the mode words are rewritten,
-// mod.rs:130-132, 162-164); until then every step re-derives its share from the sponge's ORIGINAL mode words.
+// follows it up to the next one".  Data movement = input elements added into the rate portion (field addition on the ABI
+// residues, mod.rs:128,143) or rate elements copied out (mod.rs:159-170).  It never indexes registers dynamically:
+//   - a chunk IN FRONT of a permutation is added as the state comes into the permuting kernel's registers (AbsorbAdjust);
+//   - a chunk right BEHIND a permutation is copied out of the LDS staging of that kernel's store (CopyOut);
+//   - a chunk no permutation follows is moved in global memory by the lane that owns the sponge (sponge_walk), which also
+//     rewrites the mode words when the call is over for the sponge (mod.rs:130-132, 162-164).
+// Until then every step re-derives its share from the sponge's ORIGINAL mode words.
 //   sponge_first_kernel    pass 0 over the whole batch in place: walk, then the workgroup permutes if any of its sponges is
 //                          due and only those take the result; walk on; sponges due again go onto list 1 (one atomic per wave).
 //   permute_listed_kernel  pass p >= 1: the permutation of the sponges on list p, then walk on -> list p + 1 or finished.
 // Both run the permutation wave-uniform on the permutation engine of the width (the matrix-core one at t = 7..9) with
-// nothing per-sponge live across it but one ballot; the walks hide under the other waves' arithmetic; and from the second
-// permutation on a batch in mixed modes costs the permutations the reference would execute, not max-over-a-wave of them.
+// nothing per-sponge live across it but one ballot; and from the second permutation on a batch in mixed modes costs the
+// permutations the reference would execute, not max-over-a-wave of them.
 template <bool SQUEEZE>
 __device__ __forceinline__ bool sponge_walk(const Rounds &c, const uint32_t *__restrict__ p32, uint64_t *__restrict__ states, uint32_t *__restrict__ mode_tag,
                                             uint32_t *__restrict__ mode_index, uint64_t *__restrict__ io, size_t len, size_t sponge, bool active,

@@ -1,4 +1,5 @@
-// The absorb / squeeze batch driver as a sequence of wave-uniform PASSES (wide states, pmx_device.hip: sponge_pass_kernel).
+// The absorb / squeeze batch driver as a sequence of wave-uniform PASSES (wide states; pmx_device.hip: sponge_first_kernel,
+// permute_listed_kernel, sponge_walk).
 //
 // Reference semantics (file:line in /root/reference):
 //   absorb   src/poseidon/mod.rs:232-254 (mode handling) + absorb_internal :121-150
@@ -9,15 +10,15 @@
 // which elements each chunk holds depend only on the sponge's ORIGINAL mode words and the call's length - so pass p of
 // the launch loop can recompute its share from those two words and its own number, with no per-sponge scratch:
 //
-//   pass p  =  move the chunk in front of the sponge's OWN p-th permutation, in global memory (own lane: dynamic addressing
-//              is free there)  ->  that permutation
+//   pass p  =  move the chunk in front of the sponge's OWN p-th permutation (as the state is loaded, or in global memory by
+//              the owning lane - dynamic addressing is free there)  ->  that permutation
 //
-// and the mode words are rewritten by the last pass only.  Passes are numbered by each sponge's own permutations, not by
+// and a sponge's mode words are rewritten only when the call is over for it.  Passes are numbered by each sponge's own permutations, not by
 // chunk: a sponge whose mode asks for a permutation up front (Squeezing, or an index equal to the rate) and one that
 // absorbs first both run their p-th permutation in pass p, so a call costs max-over-sponges permutation launches (2 for
-// absorb(11) at rate 8 whatever the modes), not one per chunk boundary any sponge happens to have (3).  The permutation then runs wave-uniform on the fast engines
-// (the per-lane state machine of absorb_kernel / squeeze_kernel left no room for the byte operands of the matrix-core rows,
-// DESIGN.md section 8), stored back only for the sponges that need it.
+// absorb(11) at rate 8 whatever the modes), not one per chunk boundary any sponge happens to have (3).
+// The permutation then runs wave-uniform on the fast engines (the per-lane state machine of absorb_kernel / squeeze_kernel
+// left no room for the byte operands of the matrix-core rows) and is kept only by the sponges it is due for.
 #pragma once
 #include <cstddef>
 #include <cstdint>
