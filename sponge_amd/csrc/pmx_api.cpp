@@ -155,7 +155,7 @@ static int ctx_free(pmx_ctx *ctx) {
     // (the caller's streams are the caller's to drain before it destroys the context, as with every *_dev call)
     for (auto &kv : ctx->pass_blocks)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-    for (void *p : ctx->pass_retired) (void)hipFree(p);
+    for (const pmx_ctx::RetiredBlock &r : ctx->pass_retired) (void)hipFree(r.ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->d_consts) (void)hipFree(ctx->d_consts);
     delete ctx;
@@ -506,9 +506,37 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
 }
 
 // ---- duplex sponge driver ------------------------------------------------------------------------
-// PassScratch::get for a context: the block of this caller stream, grown if needed (called with ctx->pass_lock held)
+// PassScratch::get for a context: the block of this caller stream, grown if needed (called with ctx->pass_lock held).
+// Housekeeping on the way: a retired block is freed once its stream has drained, and when a caller has gone through many
+// streams the blocks of the idle (or destroyed) ones are given back - a stream with work in flight keeps its block.
+static bool stream_idle(hipStream_t st) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipErrorNotReady) return false;
+    if (e != hipSuccess) (void)hipGetLastError();   // a stream that no longer exists: nothing of it can be in flight
+    return true;
+}
 static hipError_t ctx_pass_scratch(void *owner, hipStream_t st, size_t bytes, uint32_t **out) {
     pmx_ctx *ctx = static_cast<pmx_ctx *>(owner);
+    for (size_t i = 0; i < ctx->pass_retired.size();) {
+        if (stream_idle(ctx->pass_retired[i].stream)) {
+            (void)hipFree(ctx->pass_retired[i].ptr);
+            ctx->pass_retired[i] = ctx->pass_retired.back();
+            ctx->pass_retired.pop_back();
+        } else {
+            ++i;
+        }
+    }
+    constexpr size_t kMaxStreams = 16;
+    if (ctx->pass_blocks.size() > kMaxStreams) {
+        for (auto it = ctx->pass_blocks.begin(); it != ctx->pass_blocks.end();) {
+            if (it->first != st && stream_idle(it->first)) {
+                if (it->second.ptr) (void)hipFree(it->second.ptr);
+                it = ctx->pass_blocks.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
     pmx_ctx::PassBlock &b = ctx->pass_blocks[st];
     if (b.bytes < bytes) {
         size_t want = b.bytes * 2 > bytes ? b.bytes * 2 : bytes;
@@ -516,7 +544,7 @@ static hipError_t ctx_pass_scratch(void *owner, hipStream_t st, size_t bytes, ui
         void *fresh = nullptr;
         const hipError_t e = hipMalloc(&fresh, want);
         if (e != hipSuccess) return e;
-        if (b.ptr) ctx->pass_retired.push_back(b.ptr);   // work already enqueued on `st` may still read it
+        if (b.ptr) ctx->pass_retired.push_back({b.ptr, st});   // work already enqueued on `st` may still read it
         b.ptr = fresh;
         b.bytes = want;
     }

@@ -31,9 +31,10 @@ struct pmx_ctx {
     // enqueued: it is retired, not freed, until the context goes.  pass_lock is held while a driver call enqueues, which
     // also keeps two threads from interleaving their launches on one stream of this context.
     struct PassBlock { void *ptr = nullptr; size_t bytes = 0; };
+    struct RetiredBlock { void *ptr; hipStream_t stream; };
     std::mutex pass_lock;
     std::unordered_map<hipStream_t, PassBlock> pass_blocks;
-    std::vector<void *> pass_retired;
+    std::vector<RetiredBlock> pass_retired;
     // pmx_ctx_acquire / pmx_ctx_release bookkeeping (0 for contexts made by pmx_ctx_create)
     uint64_t cache_key = 0;
     long cache_refs = 0;

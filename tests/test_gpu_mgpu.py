@@ -384,3 +384,40 @@ def test_wide_driver_dev_calls_from_several_threads_on_their_own_streams():
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+def test_wide_driver_many_short_lived_streams_do_not_pile_up_scratch():
+    """A caller that goes through many streams (one per request, say): the context keeps one pass-list block per stream, gives
+    back the blocks of drained or destroyed streams once more than sixteen have been seen, and frees an outgrown block when its
+    stream has drained.  Forty streams, growing batch sizes on each; results against the C port, and device memory does not
+    grow by forty blocks."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BN254_FR
+    cfg = S.poseidon_config_from_lfsr(f, 8, 5, 8, 57)
+    cr = cref.CRef(O.make_config(O.BN254_FR, 254, 8, 5, 8, 57))
+    ctx = cfg.context(0)
+    t, L, K = 9, 19, 10
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(40):
+        n = 20000 + 5000 * (k % 5)
+        stream = torch.cuda.Stream(device="cuda:0")
+        msgs = synth.random_elements(f, n * L, seed=700 + k).reshape(n, L, 4)
+        with torch.cuda.stream(stream):
+            d_st = torch.zeros((n, t, 4), dtype=torch.int64, device="cuda:0")
+            d_tag, d_idx = torch.zeros(n, dtype=torch.int32, device="cuda:0"), torch.zeros(n, dtype=torch.int32, device="cuda:0")
+            d_in = torch.from_numpy(msgs.view(np.int64).copy()).to("cuda:0")
+            d_out = torch.zeros((n, K, 4), dtype=torch.int64, device="cuda:0")
+        stream.synchronize()
+        ctx.sponge_absorb_batch_dev(d_st.data_ptr(), d_tag.data_ptr(), d_idx.data_ptr(), d_in.data_ptr(), L, n, stream.cuda_stream)
+        ctx.sponge_squeeze_batch_dev(d_st.data_ptr(), d_tag.data_ptr(), d_idx.data_ptr(), d_out.data_ptr(), K, n, stream.cuda_stream)
+        stream.synchronize()
+        if k % 8 == 0:
+            pick = np.arange(0, n, 97)
+            assert np.array_equal(d_out.cpu().numpy().view(np.uint64)[pick], cr.hash_batch(np.ascontiguousarray(msgs[pick]), L, K, threads=0)), k
+        del d_st, d_tag, d_idx, d_in, d_out, stream
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    grown = free0 - torch.cuda.mem_get_info()[0]
+    assert grown < 17 * (2 * 40000 * 4 + 4096) + (64 << 20), grown        # at most ~sixteen blocks of the largest size (+ allocator slack)
