@@ -74,7 +74,8 @@ if has prof; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c2 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_c2.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c3 -- python3 $R/bench.py --workload c3 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_c3.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5 -- python3 $R/bench.py --workload c5 --total-log2 21 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_c5.log 2>&1
-  for w in c2 c3 c5; do f=$(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${w}_kernel_stats.csv; done
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d9 -- python3 $R/bench.py --workload d9 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_d9.log 2>&1
+  for w in c2 c3 c5 d9; do f=$(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${w}_kernel_stats.csv; done
 fi
 cd $R
 if has slots; then
