@@ -266,3 +266,28 @@ def test_c4_whole_batch_2e24_states_through_the_device_group():
                 got = alls[l][first:first + chunk].cpu().numpy().view(np.uint64)
                 assert np.array_equal(got, want), (l, first)
     g.close()
+
+
+def test_forest_of_2e11_trees_is_the_lower_half_of_one_2e21_leaf_tree():
+    """Size-independent property at the per-GPU size of BASELINE configs[4]: 2^11 trees of 2^10 leaves advanced together
+    (pmx_merkle_2to1_forest_dev) produce, level by level, exactly the first ten levels of the ONE tree over the same 2^21
+    leaves (pmx_merkle_2to1_dev) - pairs never straddle trees -, and a sample of the trees against the C port."""
+    name = "bls_t3_a5_8_31"
+    cfg = product_config(name)
+    n_trees, m = 1 << 11, 1 << 10
+    total = n_trees * m
+    leaves = synth.random_elements(cfg.field, total, seed=0x5EED00F5)
+    ctx = cfg.context()
+    stream = torch.cuda.current_stream().cuda_stream
+    one = torch.zeros((2 * total - 1, 4), dtype=torch.int64, device="cuda:0")
+    one[:total] = dev_tensor(leaves)
+    forest = torch.zeros((n_trees * (2 * m - 1), 4), dtype=torch.int64, device="cuda:0")
+    forest[:total] = one[:total]
+    torch.cuda.synchronize()
+    ctx.merkle_2to1_dev(one.data_ptr(), total, stream)
+    ctx.merkle_2to1_forest_dev(forest.data_ptr(), n_trees, m, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(forest, one[:forest.shape[0]])                 # leaves + ten levels, level-major in both
+    roots = to_numpy(forest[-n_trees:])
+    for b in (0, 1, 777, n_trees - 1):
+        assert np.array_equal(roots[b], c_oracle(name).merkle(leaves[b * m:(b + 1) * m], threads=0)[-1]), b
