@@ -181,7 +181,8 @@ int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64
  * Widths 4..9 run a call as PASSES on the permutation engine of the width (one launch per permutation a sponge of the
  * batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would permute it); the pass
  * lists of the _dev variants live in a block the context keeps per caller stream (calls on different streams stay
- * independent; concurrent calls of ONE context serialise while they enqueue).  in_len, out_len < 2^31. */
+ * independent; concurrent calls of ONE context serialise while they enqueue); there a call moves at most 65536 rates of
+ * elements per sponge (PMX_ERR_ARG beyond: split the call - to a duplex sponge two calls are the same as one). */
 int pmx_sponge_absorb_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
                             const uint64_t *in, size_t in_len, size_t n);
 int pmx_sponge_squeeze_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,

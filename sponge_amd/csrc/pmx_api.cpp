@@ -506,6 +506,19 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
 }
 
 // ---- duplex sponge driver ------------------------------------------------------------------------
+// The pass driver of the wide states launches one kernel per permutation a sponge of the call can need: a call is limited to
+// kMaxPasses of them (65536 rates of elements per sponge and call - 16 MiB at rate 8; longer inputs are absorbed in several calls,
+// which is the same thing to a duplex sponge).  The per-lane kernels of t = 3 and of the run-time-width engine loop inside ONE
+// launch and have no such limit.
+static constexpr int kMaxPasses = 65537;
+static int check_pass_count(const pmx_ctx *ctx, int op, size_t n, size_t len, const char *who) {
+    EngineInfo info;
+    if (describe_launch(ctx->dev, ctx->t, op, n, len, &info) == hipSuccess && info.launches > kMaxPasses)
+        return set_error(PMX_ERR_ARG, "%s: %zu elements per sponge is more than 65536 rates (%u) in one call on this width; split the call", who, len,
+                         ctx->dev.rounds.rate);
+    return PMX_OK;
+}
+
 // PassScratch::get for a context: the block of this caller stream, grown if needed (called with ctx->pass_lock held).
 // Housekeeping on the way: a retired block is freed once its stream has drained, and when a caller has gone through many
 // streams the blocks of the idle (or destroyed) ones are given back - a stream with work in flight keeps its block.
@@ -559,6 +572,7 @@ extern "C" int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uin
     if (n == 0 || in_len == 0) return PMX_OK;  // absorbing an empty input changes nothing (mod.rs:234-236)
     if (!aligned16(d_states) || !aligned16(d_in)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
+    if (int rc = check_pass_count(ctx, PMX_OP_ABSORB, n, in_len, "pmx_sponge_absorb_batch_dev")) return rc;
     PMX_ABI_BEGIN("pmx_sponge_absorb_batch_dev")
     PMX_BIND(ctx);
     std::lock_guard<std::mutex> lock(ctx->pass_lock);
@@ -574,6 +588,7 @@ extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, ui
     if (n == 0) return PMX_OK;
     if (!aligned16(d_states) || !aligned16(d_out)) return set_error(PMX_ERR_ARG, "device pointers must be 16-byte aligned");
     if (n > (size_t)0x7fffffff * 64) return set_error(PMX_ERR_ARG, "batch too large");
+    if (int rc = check_pass_count(ctx, PMX_OP_SQUEEZE, n, out_len, "pmx_sponge_squeeze_batch_dev")) return rc;
     PMX_ABI_BEGIN("pmx_sponge_squeeze_batch_dev")
     PMX_BIND(ctx);
     std::lock_guard<std::mutex> lock(ctx->pass_lock);

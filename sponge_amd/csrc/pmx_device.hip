@@ -1489,7 +1489,8 @@ hipError_t PMX_HYB_NAME(describe)(const DevConfig &c, uint32_t t, int op, size_t
     if (!driver || passes) e = fast();
     if (e != hipSuccess) e = plain();
     if (e == hipSuccess && passes) {
-        const int passes = (int)(op == PMX_OP_SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate));
+        const size_t passes_z = op == PMX_OP_SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate);
+        const int passes = passes_z > 0x7fffffff ? 0x7fffffff : (int)passes_z;
         o->launches = passes > 1 ? passes - 1 : passes;  // one launch per permutation a sponge of the batch can need
         std::snprintf(o->engine + std::strlen(o->engine), sizeof o->engine - std::strlen(o->engine), " x passes");
     }

@@ -148,3 +148,17 @@ def test_many_contexts_alive_and_calls_of_every_size_interleaved():
                        timeout=900, cwd=root)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0 and "soak ok: 60 launches-sets" in out, out[-3000:]
+
+
+def test_a_call_longer_than_65536_rates_is_refused_not_launched():
+    """The pass driver launches one kernel per permutation a sponge can need; a call that would need more than 65536 of them is
+    refused with PMX_ERR_ARG before anything is touched (the header says so; splitting the call is equivalent)."""
+    f, cfg, _ = _config("bn254_fr", None, 254, 8, 5, 8, 57)
+    lib = _lib.lib()
+    h = cfg.context()._h
+    dummy = ctypes.c_void_p(4096)                                      # never dereferenced: the length check comes first
+    assert lib.pmx_sponge_squeeze_batch_dev(h, dummy, dummy, dummy, dummy, 8 * 65536 + 1, 1, None) == _lib.PMX_ERR_ARG
+    assert b"65536 rates" in lib.pmx_last_error()
+    assert lib.pmx_sponge_absorb_batch_dev(h, dummy, dummy, dummy, dummy, 8 * 65536 + 9, 1, None) == _lib.PMX_ERR_ARG
+    # the largest legal call shape is accepted by the check (n = 0: nothing is enqueued)
+    assert lib.pmx_sponge_squeeze_batch_dev(h, None, None, None, None, 8 * 65536, 0, None) == _lib.PMX_OK
