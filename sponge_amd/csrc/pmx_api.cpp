@@ -510,7 +510,7 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
 // kMaxPasses of them (65536 rates of elements per sponge and call - 16 MiB at rate 8; longer inputs are absorbed in several calls,
 // which is the same thing to a duplex sponge).  The per-lane kernels of t = 3 and of the run-time-width engine loop inside ONE
 // launch and have no such limit.
-static constexpr int kMaxPasses = 65537;
+static constexpr int kMaxPasses = 65536;  // launches = permutations a sponge of the call can need
 static int check_pass_count(const pmx_ctx *ctx, int op, size_t n, size_t len, const char *who) {
     EngineInfo info;
     if (describe_launch(ctx->dev, ctx->t, op, n, len, &info) == hipSuccess && info.launches > kMaxPasses)
