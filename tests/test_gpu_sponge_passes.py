@@ -45,21 +45,10 @@ def _engine_info(cfg, op, n, length):
     return info
 
 
-@pytest.mark.parametrize("layout", ["random", "blocks"])
-@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-t{c[3] + 1}-a{c[4]}")
-def test_wide_driver_mixed_modes_vs_c_oracle(case, layout):
-    """n sponges (more than two workgroups, the last one ragged) in different modes and positions advance together
-    through absorbs and squeezes of every interesting length: longer than the rate, exactly the rate (the lazy
-    permutation; on the squeeze side the `:175` case), one element, nothing (squeeze(0) of an absorbing sponge
-    permutes), several rates.  `blocks`: whole workgroups in ONE mode, so that some workgroups skip a pass others take."""
-    field_name, modulus, bits, rate, alpha, rf, rp, mfma = case
-    f, cfg, cr = _config(field_name, modulus, bits, rate, alpha, rf, rp)
-    t, r = rate + 1, rate
-    n = 2 * 256 + 77
-    info = _engine_info(cfg, _lib.OP_ABSORB, n, r + 3)
-    assert b"passes" in info.engine and bool(info.mfma_dense) == mfma and info.launches == -(-(r + 3) // r), (info.engine, info.launches)
-    assert _engine_info(cfg, _lib.OP_PERMUTE, n, 0).mfma_dense == int(mfma)
-    rng = np.random.default_rng(1000 * rate + alpha)
+def _run_script(f, cfg, cr, rate, capacity, n, layout, seed):
+    """absorbs and squeezes of every interesting length on n sponges in mixed modes; every sponge against the C restatement"""
+    t, r = rate + capacity, rate
+    rng = np.random.default_rng(seed)
     batch = S.BatchPoseidonSponge.new(cfg, n)
     batch.state = synth.random_elements(f, n * t, seed=7 + rate).reshape(n, t, 4)
     if layout == "random":
@@ -95,6 +84,42 @@ def test_wide_driver_mixed_modes_vs_c_oracle(case, layout):
         assert bad.size == 0, (op, length, step, bad[:8])
         assert [int(x) for x in batch.mode_tag] == [m for _, m, _ in ref], (op, length, step)
         assert [int(x) for x in batch.mode_index] == [i for _, _, i in ref], (op, length, step)
+
+
+@pytest.mark.parametrize("layout", ["random", "blocks"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-t{c[3] + 1}-a{c[4]}")
+def test_wide_driver_mixed_modes_vs_c_oracle(case, layout):
+    """n sponges (more than two workgroups, the last one ragged) in different modes and positions advance together
+    through absorbs and squeezes of every interesting length: longer than the rate, exactly the rate (the lazy
+    permutation; on the squeeze side the `:175` case), one element, nothing (squeeze(0) of an absorbing sponge
+    permutes), several rates.  `blocks`: whole workgroups in ONE mode, so that some workgroups skip a pass others take."""
+    field_name, modulus, bits, rate, alpha, rf, rp, mfma = case
+    f, cfg, cr = _config(field_name, modulus, bits, rate, alpha, rf, rp)
+    t, r = rate + 1, rate
+    n = 2 * 256 + 77
+    info = _engine_info(cfg, _lib.OP_ABSORB, n, r + 3)
+    assert b"passes" in info.engine and bool(info.mfma_dense) == mfma and info.launches == -(-(r + 3) // r), (info.engine, info.launches)
+    assert _engine_info(cfg, _lib.OP_PERMUTE, n, 0).mfma_dense == int(mfma)
+    _run_script(f, cfg, cr, rate, 1, n, layout, 1000 * rate + alpha)
+
+
+@pytest.mark.parametrize("rate,capacity", [(7, 2), (3, 6), (8, 0), (3, 3), (2, 2)])
+def test_wide_driver_other_rate_capacity_splits(rate, capacity):
+    """PoseidonConfig::new takes any split of the width into rate and capacity (mod.rs:187-213; the default tables use
+    capacity 1 only): the rate part starts at `capacity`, which is where the passes add, copy and count.  Constants of the
+    width, another split, mixed modes, every sponge against the C restatement."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f = S.BLS12_381_FR
+    t = rate + capacity
+    rp = 57 if t >= 6 else 56
+    base = S.poseidon_config_from_lfsr(f, t - 1, 5, 8, rp)
+    cfg = S.PoseidonConfig(f, 8, rp, 5, base.mds, base.ark, rate, capacity)
+    ob = O.make_config(O.BLS12_381_FR, 255, t - 1, 5, 8, rp)
+    cr = cref.CRef(O.PoseidonConfig(ob.p, 8, rp, 5, ob.ark, ob.mds, rate, capacity))
+    n = 2 * 256 + 77
+    assert b"passes" in _engine_info(cfg, _lib.OP_SQUEEZE, n, rate + 1).engine
+    _run_script(f, cfg, cr, rate, capacity, n, "random", 77 * rate + capacity)
 
 
 def test_wide_driver_device_resident_modes_out_of_range_are_clamped():
