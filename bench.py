@@ -206,7 +206,16 @@ def main():
     # share the visible GPUs round-robin, torch.distributed runs on gloo and the gathers are staged through the host
     # (RCCL refuses two ranks on one device).  It exercises the sharding, the step functions, the verification of the
     # gathered buffer and the JSON line; its numbers mean nothing and the line says so.
-    rehearsal = os.environ.get("PMX_BENCH_REHEARSAL", "") == "1"
+    # PMX_BENCH_REHEARSAL=group: the same shared-GPU dry run, but through the PRODUCT's multi-rank path - the C ABI's device
+    # group (pmx_mgpu_create_rank, pmx_mgpu_permute_shards_dev, pmx_mgpu_all_gather_dev, pmx_mgpu_merkle_2to1_dev) exactly as
+    # in a real N > 1 run; only torch.distributed's control plane is on gloo.  The collective library then has to accept
+    # several ranks on one device, which RCCL does not: the caller names one that does with PMX_RCCL_LIBRARY
+    # (tools/gpu_group_rehearsal.sh uses the tests' stand-in).  Again: every branch executes, no number means anything.
+    rehearsal_mode = os.environ.get("PMX_BENCH_REHEARSAL", "")
+    if rehearsal_mode not in ("", "1", "group"):
+        raise SystemExit("PMX_BENCH_REHEARSAL is 1 (gathers staged through the host) or group (the C ABI's device group)")
+    rehearsal = rehearsal_mode != ""
+    host_staged = rehearsal_mode == "1"
     if rehearsal:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -259,11 +268,11 @@ def main():
 
     # ---- the engine: one context at N = 1, the C ABI's device group (RCCL) at N > 1 -------------------------------------
     group, group_error, rccl = None, None, None
-    if world > 1 and rehearsal:
+    if world > 1 and host_staged:
         rccl = {"ranks": None, "version": None, "via": "REHEARSAL on gloo, gathers staged through the host - not a measurement"}
     elif world > 1:
         uid = [mgpu.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0, device=dev)
+        dist.broadcast_object_list(uid, src=0, device=ctl)
         try:
             group = mgpu.DeviceGroup.one_rank(cfg, local_rank, rank, world, uid[0])
             info = group.info()
@@ -271,7 +280,9 @@ def main():
                     "via": "pmx_mgpu_create_rank (ncclCommInitRank); gather = pmx_mgpu_all_gather_dev (ncclAllGather)"}
         except S.PmxError as e:
             group_error = str(e)
-        ok = torch.tensor([1 if group is not None else 0], device=dev)
+        if group is not None and rehearsal:
+            rccl["via"] += "; REHEARSAL: the ranks share GPUs, collective library = " + os.environ.get("PMX_RCCL_LIBRARY", "librccl.so.1")
+        ok = torch.tensor([1 if group is not None else 0], device=ctl)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok) == 0:
             # The product's gather is pmx_mgpu_all_gather_dev.  A run that cannot form the device group is a failed run, not a
@@ -302,7 +313,7 @@ def main():
     def torch_all_gather(local, out):
         """The gather through torch.distributed (fallback / rehearsal): rank r's rows at r's span of `out`, ragged or not."""
         from sponge_amd import distributed as D
-        D.all_gather_rows(local, out, host_staged=rehearsal)
+        D.all_gather_rows(local, out, host_staged=host_staged)
 
     def fresh_inputs():
         """this rank's shard of the global seeded input, uploaded (used for the timed buffers and again for the check)"""

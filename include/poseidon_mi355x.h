@@ -239,7 +239,11 @@ int pmx_merkle_verify_paths_dev(pmx_ctx *ctx, const uint64_t *d_leaves, const ui
  * ncclCommInitRank; rank 0 makes the id with pmx_mgpu_unique_id and the launcher carries it to the other ranks).
  * A group holds `n_local` devices with consecutive ranks first_rank .. first_rank + n_local - 1 of `world`.
  * Arrays indexed [local] below have n_local entries.  The *_dev calls enqueue on the group's own per-device
- * streams (pmx_mgpu_stream) and return; pmx_mgpu_synchronize waits for all of them. */
+ * streams (pmx_mgpu_stream) and return; pmx_mgpu_synchronize waits for all of them.
+ *
+ * RCCL is bound when the first group is formed (dlopen of librccl.so.1 by SONAME - a process that already holds a copy
+ * keeps it -, then /opt/rocm/lib/librccl.so.1).  The environment variable PMX_RCCL_LIBRARY=<path>, read at that moment,
+ * names the build to bind instead; nothing else is tried when it is set. */
 #define PMX_UNIQUE_ID_BYTES 128
 #define PMX_MAX_LOCAL_DEVICES 16
 typedef struct pmx_mgpu pmx_mgpu;

@@ -63,13 +63,21 @@ struct Rccl {
 Rccl &rccl_lib() {
     static Rccl *lib = [] {
         Rccl *r = new Rccl();
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r->handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r->handle) break;
+        // PMX_RCCL_LIBRARY=<path>: bind THAT build of the collective library (a site's own RCCL; a process that already
+        // holds another copy - PyTorch's - would otherwise get that one by SONAME).  Nothing else is tried when it is set.
+        const char *chosen = std::getenv("PMX_RCCL_LIBRARY");
+        if (chosen && *chosen) {
+            r->handle = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            chosen = "librccl.so.1";
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r->handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r->handle) break;
+            }
         }
         if (!r->handle) {
             const char *e = dlerror();
-            r->error = std::string("librccl.so.1 could not be loaded: ") + (e ? e : "unknown error");
+            r->error = std::string(chosen) + " could not be loaded: " + (e ? e : "unknown error");
             return r;
         }
         auto sym = [&](const char *name) {

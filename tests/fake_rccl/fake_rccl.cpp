@@ -27,10 +27,24 @@
 //                                      GroupEnd; the k-th queued call of every rank of a communicator is one collective
 //   ncclCommInitAll                    one thread owns all ranks;   ncclCommInitRank   ranks are joined by id, inside ONE
 //                                      process (threads), and the call blocks until all of them have arrived, as RCCL does
+//
+// Ranks in DIFFERENT processes (FAKE_RCCL_XPROC=1 in the process that calls ncclGetUniqueId; the id then names a POSIX
+// shared-memory object): what `bench.py --gpus N` under torch.distributed.run and tests/mgpu_rank_worker.py do.  The ranks
+// meet in the shared object (descriptor table + a sense-reversing barrier, two-minute time-outs instead of hangs), compare
+// what they posted exactly as above, and the payload goes through one shared-memory object per rank: owner's stream
+// drained, device -> object, barrier, object -> every reader's receive buffer on the reader's stream, drained, barrier.
+// Slow and fully synchronous - it is a rehearsal stage, not a transport.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
 #include <atomic>
+#include <cerrno>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -69,9 +83,13 @@ struct Clique {
 
 }  // namespace
 
+namespace {
+struct XComm;
+}
 struct ncclComm {
-    Clique *clique = nullptr;
-    int rank = 0;
+    Clique *clique = nullptr;                // ranks of one process
+    XComm *x = nullptr;                      // ranks of several processes (exactly one of the two is set)
+    int rank = 0, world = 0;
     int device = 0;
     std::vector<Op> pending;                 // queued inside a group by the owning thread
     uint64_t post_epoch = 0;
@@ -255,13 +273,23 @@ ncclResult_t run_round(Clique *c) {
     return ncclSuccess;
 }
 
+ncclResult_t x_perform(ncclComm *c, const std::vector<Op> &ops);   // ranks in different processes, below
+
 thread_local int t_depth = 0;
 thread_local bool t_group_failed = false;         // a call inside the open group was refused: the group is void
 thread_local std::vector<ncclComm *> t_touched;   // communicators with queued calls, in first-use order
 
 ncclResult_t flush_group() {
-    std::vector<ncclComm *> touched;
-    touched.swap(t_touched);
+    std::vector<ncclComm *> all, touched;
+    all.swap(t_touched);
+    ncclResult_t x_result = ncclSuccess;
+    for (ncclComm *comm : all) {
+        if (!comm->x) { touched.push_back(comm); continue; }
+        std::vector<Op> ops;
+        ops.swap(comm->pending);
+        const ncclResult_t rc = x_perform(comm, ops);
+        if (rc != ncclSuccess) x_result = rc;
+    }
     // post everything this thread queued (a thread that owns all ranks of a communicator completes the round itself)
     for (ncclComm *comm : touched) {
         Clique *c = comm->clique;
@@ -277,7 +305,7 @@ ncclResult_t flush_group() {
             c->cv.notify_all();
         }
     }
-    ncclResult_t result = ncclSuccess;
+    ncclResult_t result = x_result;
     for (ncclComm *comm : touched) {
         Clique *c = comm->clique;
         std::unique_lock<std::mutex> l(c->m);
@@ -289,13 +317,242 @@ ncclResult_t flush_group() {
 }
 
 ncclResult_t enqueue(ncclComm *comm, const Op &op) {
-    if (!comm || !comm->clique) return fail(ncclInvalidArgument, "null communicator");
+    if (!comm || (!comm->clique && !comm->x)) return fail(ncclInvalidArgument, "null communicator");
     bool seen = false;
     for (ncclComm *c : t_touched) seen = seen || c == comm;
     if (!seen) t_touched.push_back(comm);
     comm->pending.push_back(op);
     if (t_depth == 0) return flush_group();   // a call outside a group is a group of its own
     return ncclSuccess;
+}
+
+// ---- ranks in different processes ---------------------------------------------------------------------------------------
+constexpr int kXMaxWorld = 64;
+constexpr unsigned kXMagic = 0xFA4ECC17u;
+constexpr double kXTimeout = 120.0;   // seconds a rank waits for the others before it gives up (a hang helps nobody)
+
+struct XDesc {
+    int kind, root, type, rc;
+    unsigned long long count, n_ops;
+};
+struct XShared {
+    std::atomic<unsigned> magic;
+    int world;
+    std::atomic<int> joined, left;
+    std::atomic<int> bar_count, bar_sense;
+    XDesc desc[kXMaxWorld];
+};
+struct XComm {
+    XShared *sh = nullptr;
+    std::string token;                        // the objects are /fake_rccl_<token> and /fake_rccl_<token>_r<rank>
+    int sense = 0;
+    int data_fd = -1;
+    void *data = nullptr;
+    size_t data_bytes = 0;
+};
+
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+ncclResult_t x_barrier(ncclComm *c, const char *where) {
+    XShared *sh = c->x->sh;
+    const int s = (c->x->sense ^= 1);
+    if (sh->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == sh->world) {
+        sh->bar_count.store(0, std::memory_order_relaxed);
+        sh->bar_sense.store(s, std::memory_order_release);
+        return ncclSuccess;
+    }
+    const double t0 = now_s();
+    for (unsigned spin = 0; sh->bar_sense.load(std::memory_order_acquire) != s; ++spin) {
+        if (spin > 1000) usleep(100);
+        if ((spin & 1023) == 1023 && now_s() - t0 > kXTimeout)
+            return fail(ncclSystemError, std::string("rank ") + std::to_string(c->rank) + " waited two minutes for the other ranks at " + where);
+    }
+    return ncclSuccess;
+}
+
+std::string x_data_name(const std::string &token, int rank) { return "/fake_rccl_" + token + "_r" + std::to_string(rank); }
+
+// this rank's staging object, at least `bytes` long
+ncclResult_t x_stage(ncclComm *c, size_t bytes) {
+    XComm *x = c->x;
+    if (x->data_bytes >= bytes) return ncclSuccess;
+    if (x->data) munmap(x->data, x->data_bytes);
+    x->data = nullptr;
+    x->data_bytes = 0;
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    if (ftruncate(x->data_fd, (off_t)want) != 0) return fail(ncclSystemError, std::string("ftruncate of the staging object: ") + std::strerror(errno));
+    void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED, x->data_fd, 0);
+    if (m == MAP_FAILED) return fail(ncclSystemError, std::string("mmap of the staging object: ") + std::strerror(errno));
+    x->data = m;
+    x->data_bytes = want;
+    return ncclSuccess;
+}
+
+// copy `bytes` of rank j's staging object to dst (device) on st
+ncclResult_t x_fetch(ncclComm *c, int j, void *dst, size_t bytes, hipStream_t st) {
+    XComm *x = c->x;
+    if (j == c->rank) {
+        FAKE_HIP(hipMemcpyAsync(dst, x->data, bytes, hipMemcpyHostToDevice, st));
+        FAKE_HIP(hipStreamSynchronize(st));
+        return ncclSuccess;
+    }
+    const int fd = shm_open(x_data_name(x->token, j).c_str(), O_RDONLY, 0);
+    if (fd < 0) return fail(ncclSystemError, "rank " + std::to_string(j) + "'s staging object cannot be opened: " + std::strerror(errno));
+    void *m = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail(ncclSystemError, std::string("mmap of a peer's staging object: ") + std::strerror(errno));
+    hipError_t e = hipMemcpyAsync(dst, m, bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    munmap(m, bytes);
+    if (e != hipSuccess) return fail(ncclUnhandledCudaError, std::string("copy from a peer's staging object: ") + hipGetErrorString(e));
+    return ncclSuccess;
+}
+
+// the calls one rank queued in a group (or one call outside a group); every rank of the communicator is in here with its own
+ncclResult_t x_perform(ncclComm *c, const std::vector<Op> &ops) {
+    XShared *sh = c->x->sh;
+    const int W = c->world, me = c->rank;
+    ncclResult_t rc;
+    sh->desc[me].n_ops = ops.size();
+    if ((rc = x_barrier(c, "the start of a group")) != ncclSuccess) return rc;
+    ncclResult_t verdict = ncclSuccess;
+    for (int r = 0; r < W; ++r)
+        if (sh->desc[r].n_ops != ops.size() && verdict == ncclSuccess) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "rank %d posted %zu collectives in this group, rank %d posted %llu", me, ops.size(), r, sh->desc[r].n_ops);
+            verdict = fail(ncclInvalidArgument, msg);
+        }
+    if ((rc = x_barrier(c, "the group's size check")) != ncclSuccess) return rc;
+    if (verdict != ncclSuccess) return verdict;
+    for (const Op &o : ops) {
+        const size_t esz = type_bytes(o.type);
+        const size_t bytes = o.count * esz;
+        const bool sender = o.kind == kAllGather || me == o.root;
+        ncclResult_t mine = ncclSuccess;
+        if (esz == 0) mine = fail(ncclInvalidArgument, "unsupported datatype");
+        else if (o.kind == kBroadcast && (o.root < 0 || o.root >= W)) mine = fail(ncclInvalidArgument, "broadcast root out of range");
+        else if (o.kind == kAllGather) {
+            mine = check_range(o.send, bytes, "ncclAllGather sendbuff", me);
+            if (mine == ncclSuccess) mine = check_range(o.recv, bytes * (size_t)W, "ncclAllGather recvbuff", me);
+        } else {
+            if (sender) mine = check_range(o.send, bytes, "ncclBroadcast sendbuff (root)", me);
+            if (mine == ncclSuccess) mine = check_range(o.recv, bytes, "ncclBroadcast recvbuff", me);
+        }
+        if (mine == ncclSuccess && bytes) {
+            hipError_t e = hipStreamSynchronize(o.stream);            // everything enqueued before the call has happened
+            if (e == hipSuccess && sender) {
+                mine = x_stage(c, bytes);
+                if (mine == ncclSuccess) e = hipMemcpy(c->x->data, o.send, bytes, hipMemcpyDeviceToHost);
+            }
+            if (e != hipSuccess) mine = fail(ncclUnhandledCudaError, std::string("staging the send buffer: ") + hipGetErrorString(e));
+        }
+        sh->desc[me].kind = (int)o.kind;
+        sh->desc[me].root = o.root;
+        sh->desc[me].type = (int)o.type;
+        sh->desc[me].count = o.count;
+        sh->desc[me].rc = (int)mine;
+        if ((rc = x_barrier(c, "a collective (posted)")) != ncclSuccess) return rc;
+        verdict = mine;
+        for (int r = 0; r < W && verdict == ncclSuccess; ++r) {
+            const XDesc &d = sh->desc[r];
+            if (d.rc != 0) verdict = fail((ncclResult_t)d.rc, "rank " + std::to_string(r) + " refused the call (its process has the reason)");
+            else if (d.kind != (int)o.kind || d.count != o.count || d.type != (int)o.type || d.root != o.root) {
+                char msg[256];
+                std::snprintf(msg, sizeof msg, "ranks %d and %d posted different collectives (kind %d/%d, count %zu/%llu, root %d/%d)", me, r,
+                              (int)o.kind, d.kind, o.count, d.count, o.root, d.root);
+                verdict = fail(ncclInvalidArgument, msg);
+            }
+        }
+        if (verdict == ncclSuccess && bytes) {
+            if (o.kind == kAllGather) {
+                for (int j = 0; j < W && verdict == ncclSuccess; ++j) {
+                    char *dst = (char *)o.recv + (size_t)j * bytes;
+                    if (j == me && (const void *)dst == o.send) { g_stats.inplace_skips++; continue; }
+                    verdict = x_fetch(c, j, dst, bytes, o.stream);
+                    g_stats.copies++;
+                    g_stats.bytes += (long long)bytes;
+                }
+            } else if (me == o.root && o.recv == o.send) {
+                g_stats.inplace_skips++;
+            } else {
+                verdict = x_fetch(c, o.root, o.recv, bytes, o.stream);
+                g_stats.copies++;
+                g_stats.bytes += (long long)bytes;
+            }
+        }
+        if ((rc = x_barrier(c, "a collective (delivered)")) != ncclSuccess) return rc;   // the staging objects may be reused
+        if (verdict != ncclSuccess) return verdict;
+        (o.kind == kAllGather ? g_stats.all_gathers : g_stats.broadcasts)++;
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t x_join(ncclComm *m, int nranks, const std::string &token) {
+    if (nranks > kXMaxWorld) return fail(ncclInvalidArgument, "the cross-process stand-in holds at most 64 ranks");
+    XComm *x = new XComm();
+    x->token = token;
+    m->x = x;
+    const std::string name = "/fake_rccl_" + token;
+    bool creator = true;
+    int fd = shm_open(name.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd < 0 && errno == EEXIST) {
+        creator = false;
+        fd = shm_open(name.c_str(), O_RDWR, 0600);
+    }
+    if (fd < 0) return fail(ncclSystemError, "shm_open(" + name + "): " + std::strerror(errno));
+    if (creator && ftruncate(fd, (off_t)sizeof(XShared)) != 0) {
+        close(fd);
+        return fail(ncclSystemError, std::string("ftruncate of the rendezvous object: ") + std::strerror(errno));
+    }
+    const double t0 = now_s();
+    if (!creator) {   // the creator may not have sized it yet
+        struct stat st;
+        while (fstat(fd, &st) == 0 && (size_t)st.st_size < sizeof(XShared)) {
+            if (now_s() - t0 > kXTimeout) { close(fd); return fail(ncclSystemError, "the rendezvous object was never sized"); }
+            usleep(1000);
+        }
+    }
+    void *mem = mmap(nullptr, sizeof(XShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) return fail(ncclSystemError, std::string("mmap of the rendezvous object: ") + std::strerror(errno));
+    XShared *sh = static_cast<XShared *>(mem);
+    x->sh = sh;
+    if (creator) {   // a fresh object is all zeros: the atomics start at 0
+        sh->world = nranks;
+        sh->magic.store(kXMagic, std::memory_order_release);
+    } else {
+        while (sh->magic.load(std::memory_order_acquire) != kXMagic) {
+            if (now_s() - t0 > kXTimeout) return fail(ncclSystemError, "the rendezvous object was never initialised");
+            usleep(1000);
+        }
+    }
+    if (sh->world != nranks) return fail(ncclInvalidArgument, "ncclCommInitRank: the ranks disagree about the world size");
+    x->data_fd = shm_open(x_data_name(token, m->rank).c_str(), O_RDWR | O_CREAT, 0600);
+    if (x->data_fd < 0) return fail(ncclSystemError, std::string("shm_open of the staging object: ") + std::strerror(errno));
+    sh->joined.fetch_add(1, std::memory_order_acq_rel);
+    while (sh->joined.load(std::memory_order_acquire) < nranks) {   // RCCL blocks here until every rank has arrived, too
+        if (now_s() - t0 > kXTimeout) return fail(ncclSystemError, "ncclCommInitRank: not every rank arrived within two minutes");
+        usleep(200);
+    }
+    return ncclSuccess;
+}
+
+void x_leave(ncclComm *m) {
+    XComm *x = m->x;
+    if (x->data) munmap(x->data, x->data_bytes);
+    if (x->data_fd >= 0) {
+        close(x->data_fd);
+        shm_unlink(x_data_name(x->token, m->rank).c_str());
+    }
+    if (x->sh) {
+        if (x->sh->left.fetch_add(1, std::memory_order_acq_rel) + 1 >= x->sh->world) shm_unlink(("/fake_rccl_" + x->token).c_str());
+        munmap(x->sh, sizeof(XShared));
+    }
+    delete x;
 }
 
 std::mutex g_registry_lock;
@@ -316,7 +573,12 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
     if (!id) return ncclInvalidArgument;
     if (injected(6)) return fail(ncclSystemError, "injected failure (ncclGetUniqueId)");
     std::memset(id->internal, 0, sizeof id->internal);
-    std::snprintf(id->internal, sizeof id->internal, "fake_rccl:%u", g_next_id.fetch_add(1));
+    const char *xproc = std::getenv("FAKE_RCCL_XPROC");
+    if (xproc && xproc[0] == '1')   // the ranks will be processes: the id names the shared-memory object they meet in
+        std::snprintf(id->internal, sizeof id->internal, "fake_rccl_x:%d_%u_%llx", (int)getpid(), g_next_id.fetch_add(1),
+                      (unsigned long long)(now_s() * 1e6));
+    else
+        std::snprintf(id->internal, sizeof id->internal, "fake_rccl:%u", g_next_id.fetch_add(1));
     return ncclSuccess;
 }
 
@@ -332,6 +594,7 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist) {
         ncclComm *m = new ncclComm();
         m->clique = c;
         m->rank = r;
+        m->world = ndev;
         m->device = devlist ? devlist[r] : r;   // (the same device may appear several times: that is the point)
         c->member[(size_t)r] = m;
         comms[r] = m;
@@ -343,6 +606,21 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist) {
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank) {
     if (!comm || nranks <= 0 || rank < 0 || rank >= nranks) return fail(ncclInvalidArgument, "ncclCommInitRank: bad argument");
     if (injected(5)) return fail(ncclSystemError, "injected failure (ncclCommInitRank)");
+    if (std::strncmp(id.internal, "fake_rccl_x:", 12) == 0) {
+        ncclComm *m = new ncclComm();
+        m->rank = rank;
+        m->world = nranks;
+        if (hipGetDevice(&m->device) != hipSuccess) m->device = 0;
+        const ncclResult_t rc = x_join(m, nranks, std::string(id.internal + 12, strnlen(id.internal + 12, sizeof id.internal - 12)));
+        if (rc != ncclSuccess) {
+            if (m->x) x_leave(m);
+            delete m;
+            return rc;
+        }
+        *comm = m;
+        g_stats.comms_created++;
+        return ncclSuccess;
+    }
     const std::string key(id.internal, sizeof id.internal);
     Clique *c = nullptr;
     {
@@ -361,6 +639,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
     ncclComm *m = new ncclComm();
     m->clique = c;
     m->rank = rank;
+    m->world = nranks;
     if (hipGetDevice(&m->device) != hipSuccess) m->device = 0;
     std::unique_lock<std::mutex> l(c->m);
     if (c->world != nranks || c->member[(size_t)rank]) {
@@ -384,6 +663,12 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     if (!comm) return ncclSuccess;
+    if (comm->x) {
+        x_leave(comm);
+        delete comm;
+        g_stats.comms_destroyed++;
+        return ncclSuccess;
+    }
     Clique *c = comm->clique;
     bool last = false;
     {
@@ -402,7 +687,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
 
 ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
     if (!comm || !count) return ncclInvalidArgument;
-    *count = comm->clique->world;
+    *count = comm->world;
     return ncclSuccess;
 }
 

@@ -50,7 +50,8 @@ def main():
         assert lib.pmx_test_hooks_enabled() == 1, "run with PMX_TEST_HOOKS=1"
         cfg = product_config(NAME)
         cr = c_oracle(NAME)
-        fake = ctypes.CDLL("librccl.so.1")                  # the copy the product binds (same SONAME, same search path)
+        # the copy the product binds: the one PMX_RCCL_LIBRARY names, else the same SONAME on the same search path
+        fake = ctypes.CDLL(os.environ.get("PMX_RCCL_LIBRARY") or "librccl.so.1")
         assert fake.fake_rccl_marker() == 0x5EED, "the real RCCL is on the path, not tests/fake_rccl"
         fake.fake_rccl_stats.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
         fake.fake_rccl_stats.restype = None

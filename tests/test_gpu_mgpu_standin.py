@@ -86,3 +86,87 @@ assert np.array_equal(cfg.context(0).permute_batch(st), c_oracle("bls_t3_a5_8_31
     p = subprocess.run([sys.executable, "-c", code], env=_child_env(os.path.join(FAKE_DIR, "broken")), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+
+
+def _xproc_env():
+    """ranks in different processes: the product is told WHICH collective library to bind (PMX_RCCL_LIBRARY, a product
+    feature: a site's own RCCL build) and the stand-in is told that its ranks are processes"""
+    return dict(os.environ, PMX_RCCL_LIBRARY=os.path.join(FAKE_DIR, "librccl.so.1"), FAKE_RCCL_XPROC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+
+@pytest.mark.parametrize("world,shape", [(2, "equal"), (2, "ragged"), (3, "ragged"), (4, "equal"), (8, "ragged")])
+def test_one_process_per_rank_on_one_gpu(world, shape, tmp_path):
+    """The multi-PROCESS form - what `bench.py --gpus N` and a Rust job with one process per GPU use, and what
+    tests/test_gpu_mgpu.py::test_one_process_per_gpu_with_create_rank runs with ONE rank on a one-GPU box: W fresh child
+    processes, all on cuda:0, the id made by rank 0 (pmx_mgpu_unique_id) and handed over through a file,
+    pmx_mgpu_create_rank in every child, sharded permutation, equal (one ncclAllGather) or ragged (W grouped in-place
+    ncclBroadcasts, the last shards shorter) gather, the sharded tree with its roots all-gather; every rank checks the WHOLE
+    of its gathered copy and its tree top against the C restatement (tests/mgpu_rank_worker.py, unchanged)."""
+    _ensure_fake()
+    n_total = (1 << 12) * world + (3 if shape == "ragged" else 0)
+    uid_file = str(tmp_path / "uid.bin")
+    procs = []
+    for r in range(world):
+        out = str(tmp_path / f"rank{r}.json")
+        procs.append((out, subprocess.Popen([sys.executable, os.path.join(HERE, "mgpu_rank_worker.py"), str(r), str(world), "0", uid_file,
+                                             str(n_total), "8", out], env=_xproc_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    results = []
+    for out, p in procs:
+        try:
+            log, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for _, q in procs:
+                q.kill()
+            raise
+        assert os.path.exists(out), log.decode(errors="replace")[-3000:]
+        results.append(json.load(open(out)))
+    for res in results:
+        assert res["ok"], res
+        assert res["info"]["comm_ranks"] == world and res["gather_bad_spans"] == []
+        if world & (world - 1) == 0:
+            assert res["tree_ok"] is True
+    assert sorted(r["info"]["comm_first_rank"] for r in results) == list(range(world))
+    leftovers = [f for f in os.listdir("/dev/shm") if f.startswith("fake_rccl_")]
+    assert not leftovers, leftovers
+
+
+def test_a_named_collective_library_that_does_not_exist_is_reported(tmp_path):
+    """PMX_RCCL_LIBRARY names the build to bind; a path that cannot be loaded is PMX_ERR_RCCL with the loader's reason at
+    the first device-group call (nothing else is tried: a caller who names a library wants THAT library)."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import sponge_amd as S
+from sponge_amd import _lib, mgpu
+try:
+    mgpu.unique_id()
+    sys.exit(2)
+except S.PmxError as e:
+    assert e.code == _lib.PMX_ERR_RCCL and "/nonexistent/librccl.so could not be loaded" in str(e), str(e)
+''' % os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PMX_RCCL_LIBRARY="/nonexistent/librccl.so"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+
+
+@pytest.mark.parametrize("world,extra", [(2, ["--workload", "c2", "--total-units", "50001", "--gather", "step"]),
+                                         (4, ["--workload", "c5", "--total-log2", "14"])])
+def test_bench_multi_rank_path_runs_through_the_device_group(world, extra, tmp_path):
+    """`bench.py --gpus N` under torch.distributed.run, N > 1, on one GPU (PMX_BENCH_REHEARSAL=group): the ranks share
+    cuda:0, torch.distributed's control plane is gloo, and the data path is the product's - pmx_mgpu_create_rank with the id
+    broadcast by rank 0, pmx_mgpu_permute_shards_dev, the (ragged) pmx_mgpu_all_gather_dev per step, the sharded tree with its
+    roots all-gather - followed by bench.py's own verification of every rank's gathered copy.  The JSON line must say
+    rccl.ranks = N and verified = true; the numbers are a rehearsal's (tools/gpu_group_rehearsal.sh runs more shapes)."""
+    _ensure_fake()
+    root = os.path.dirname(HERE)
+    env = dict(_xproc_env(), PMX_BENCH_REHEARSAL="group", MASTER_ADDR="127.0.0.1")
+    port = 29500 + (os.getpid() * 7 + world) % 400
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--spinup-seconds", "0.05"] + extra, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = p.stdout.decode(errors="replace")
+    lines = [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, text[-3000:]
+    d = lines[0]
+    assert d["verified"] is True and d["n_gpus"] == world and d["rccl"]["ranks"] == world, d
+    assert "pmx_mgpu_create_rank" in d["rccl"]["via"] and "REHEARSAL" in d["config"]

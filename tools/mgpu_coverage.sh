@@ -2,7 +2,8 @@
 # Line coverage of sponge_amd/csrc/pmx_mgpu.cpp (host code) under the stand-in tests, on a ONE-GPU box:
 #   tools/mgpu_coverage.sh [OUT_DIR]        (default gpurun_out/mgpu_cov)
 # builds tests/cov/libposeidon_mi355x_cov.so (the product's objects + a gcov-instrumented pmx_mgpu.o), runs
-# tests/mgpu_standin_worker.py for W = 2, 3, 8 behind tests/fake_rccl and once behind the library that lacks a symbol,
+# tests/mgpu_standin_worker.py for W = 2, 3, 8 behind tests/fake_rccl, once behind the library that lacks a symbol, once with
+# the library named by PMX_RCCL_LIBRARY and once with a name that cannot be loaded,
 # then gcov.  Writes pmx_mgpu.cpp.gcov (annotated source) and coverage_summary.txt.
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -38,6 +39,23 @@ try:
     sys.exit(2)
 except S.PmxError as e:
     assert "librccl has no symbol ncclBroadcast" in str(e), str(e)
+    print("ok:", e)
+PY
+# PMX_RCCL_LIBRARY: a named library that loads (the stand-in, by path instead of by search order) and one that does not
+PMX_RCCL_LIBRARY="$ROOT/tests/fake_rccl/librccl.so.1" python3 tests/mgpu_standin_worker.py 2 "$OUT/standin_named_w2.json" "$COV" \
+    > "$OUT/standin_named_w2.log" 2>&1 || status=1
+PMX_RCCL_LIBRARY=/nonexistent/librccl.so python3 - "$COV" > "$OUT/unloadable.log" 2>&1 <<'PY' || status=1
+import sys
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from sponge_amd import _lib
+_lib.LIB_PATH = sys.argv[1]
+import sponge_amd as S
+from sponge_amd import mgpu
+try:
+    mgpu.unique_id()
+    sys.exit(2)
+except S.PmxError as e:
+    assert "/nonexistent/librccl.so could not be loaded" in str(e), str(e)
     print("ok:", e)
 PY
 (cd tests/cov && gcov -o . pmx_mgpu_cov.o > "$OUT/gcov_stdout.txt" 2>&1)
