@@ -126,6 +126,7 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.tab_bdense_offset = (uint32_t)pp.tab_bdense_offset;
     d.mfma_offset = (uint32_t)pp.mfma_offset;
     d.mfma_dense = pp.mfma_dense ? 1u : 0u;
+    d.win_offset = (uint32_t)pp.win_offset;
     d.io_offset = (uint32_t)pp.io_offset;
     d.has_opt = pp.has_opt ? 1u : 0u;
     {

@@ -311,6 +311,7 @@ struct HybridEngine {
         tb.tab_sparse = consts + d.tab_sparse_offset;
         tb.tab_bdense = consts + d.tab_bdense_offset;
         tb.mfma = consts + d.mfma_offset;
+        tb.win = consts + d.win_offset;
         lane = threadIdx.x & 63;
         region = pmx_lds + (threadIdx.x >> 6) * (kWaveBytes / 16);
         sc.base = reinterpret_cast<uint32_t *>(region) + lane;
@@ -544,7 +545,8 @@ struct HybridEngine {
     }
 
     static void describe(EngineInfo &o) {
-        std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,%s>", T, ALPHA, MFMA ? "mfma" : "valu");
+        if (MFMA && mfma_window_for(T) > 0) std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,mfma,windows of %d>", T, ALPHA, mfma_window_for(T));
+        else std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,%s>", T, ALPHA, MFMA ? "mfma" : "valu");
         o.threads = kThreads;
         o.optimised = 1;
         o.row_tables = T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB;
@@ -568,7 +570,8 @@ struct HybridEngine {
     }
 
     __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T) {
-        permute_hybrid<T, ALPHA, Scratch, MFMA ? kThreads : 0, kTileSteps>(s, sc, tb, c, one, f, want_lo, want_hi, pmx_lds + kWaves * (kWaveBytes / 16));
+        permute_hybrid<T, ALPHA, Scratch, MFMA ? kThreads : 0, kTileSteps, MFMA ? mfma_window_for(T) : 0>(s, sc, tb, c, one, f, want_lo, want_hi,
+                                                                                                          pmx_lds + kWaves * (kWaveBytes / 16));
     }
 };
 

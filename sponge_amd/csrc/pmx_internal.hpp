@@ -41,6 +41,7 @@ struct DevConfig {
     uint32_t tab_full_offset, tab_sparse_offset, tab_bdense_offset;   // shifted tables (pmx_field.hpp: tab_dot)
     uint32_t mfma_offset;     // int8 tables of the dense layers (pmx_mfma.hpp); valid when mfma_dense
     uint32_t mfma_dense;      // 1: those tables exist (t and modulus qualify: pmx_prepare.hpp)
+    uint32_t win_offset;      // window tables of the partial section (pmx_mfma.hpp); valid when mfma_dense and the width takes windows
     uint32_t io_offset;       // FieldRt::io block; `field.io` itself holds a HOST address and is re-pointed by the engines
     uint32_t has_opt;         // optimised schedule tables present (and, for t = 3, the cooperative table)
     uint32_t max_lds_bytes;   // LDS one workgroup may ask for on this device (launcher-side engine choice only)

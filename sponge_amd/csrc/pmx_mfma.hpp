@@ -41,10 +41,32 @@ constexpr int kMfmaElemBytes = 36;   // K bytes per element (33 used)
 PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32; }
 PMX_FN constexpr int mfma_row_words(int t) { return mfma_k_steps(t) * 64 * 4; }             // A operand of one output row
 PMX_FN constexpr int mfma_layer_words(int t) { return t * mfma_row_words(t) + t * 16; }     // t rows, then t x 8 int64 corrections
+// a layer with n_in input elements and n_out rows (mfma_k_steps / mfma_row_words count INPUT elements)
+PMX_FN constexpr int mfma_layer_words_io(int n_in, int n_out) { return n_out * mfma_row_words(n_in) + n_out * 16; }
+
+// Windows of partial rounds (round 4).  A partial round applies its S-box to lane 0 only, so over K of them everything but the K
+// S-box outputs is LINEAR: with the carried lanes u in a basis chosen by the host (pmx_prepare.hpp: derive_window_layers) the
+// S-box inputs are   x_1 (carried),  x_{k+1} = z_k + u_k + sum_{i<k} h_{k,i} z_i   - additions and (K-1)(K-2)/2 products by
+// constants - and the whole linear part of the K rounds (2t-1 products by constants each on the VALU) is ONE layer on the
+// matrix cores: inputs (u_1 .. u_{t-1}, z_1 .. z_K), outputs (x_1, u_1 .. u_{t-1}) of the next window, or the state the full
+// rounds after the partial section expect.  The first window is the short one when K does not divide the number of partial rounds.
+#ifndef PMX_MFMA_WINDOW
+#define PMX_MFMA_WINDOW 3
+#endif
+#ifndef PMX_MFMA_WINDOW_MIN_T
+#define PMX_MFMA_WINDOW_MIN_T 7
+#endif
+// window size of a width (0: its partial rounds keep their sparse layers on the VALU)
+PMX_FN constexpr int mfma_window_for(int t) { return (t >= PMX_MFMA_WINDOW_MIN_T && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T) ? PMX_MFMA_WINDOW : 0; }
+PMX_FN constexpr int mfma_window_hist(int k) { return (k - 1) * (k - 2) / 2; }   // history constants per window
+// words of the window tables of a config: the entry layer (t -> t), then per window its layer (t - 1 + K -> t) and its history constants
+PMX_FN constexpr size_t mfma_window_words(int t, int k, size_t windows) {
+    return (size_t)mfma_layer_words(t) + windows * ((size_t)mfma_layer_words_io(t - 1 + k, t) + (size_t)mfma_window_hist(k) * kFeStride);
+}
 
 // the state's K bytes: nine 32-bit words per element (u - 128 in every byte), padded with zero digits to whole k-steps
 template <int T>
-PMX_FN void mfma_state_words(const Fe (&s)[T], uint32_t (&W)[8 * mfma_k_steps(T)]) {
+PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
     static_for<0, T>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
 #pragma unroll
@@ -111,14 +133,15 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
 
 #if !defined(__HIPCC__)
 // Host form for tests/hostcheck (g++, no matrix cores): the same tables, bytes and finish, the GEMM as plain integer sums.
-template <int T, int THREADS, int TILE_STEPS, class Scratch>
-inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, void * /*tile*/, const FieldRt &f, uint32_t lo, uint32_t hi) {
-    constexpr int NQ = mfma_k_steps(T);
+// NIN input elements -> rows [lo, hi) of NOUT into out (NOUT - 1 <= the scratch's slots).
+template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
+inline void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, void * /*tile*/, const FieldRt &f, uint32_t lo, uint32_t hi) {
+    constexpr int NQ = mfma_k_steps(NIN);
     uint32_t W[8 * NQ];
-    mfma_state_words<T>(s, W);
+    mfma_state_words<NIN>(in, W);
     const int8_t *bytes = reinterpret_cast<const int8_t *>(layer);
-    const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(T));
-    Fe last = s[T - 1];
+    const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)NOUT * mfma_row_words(NIN));
+    Fe last = out[NOUT - 1];
     for (uint32_t i = lo; i < hi; ++i) {
         int32_t R[8][4];
         for (int e = 0; e < 32; ++e) {
@@ -131,11 +154,15 @@ inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, voi
             R[e / 4][e % 4] = (int32_t)sum;
         }
         const Fe row = mfma_row_finish(R, corr + (size_t)i * 8, f);
-        if (i + 1 < (uint32_t)T) sc.set(i, row);
+        if (i + 1 < (uint32_t)NOUT) sc.set(i, row);
         else last = row;
     }
-    static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
-    s[T - 1] = last;
+    static_for<0, NOUT - 1>([&](auto i) { out[i] = sc.get(i); });
+    out[NOUT - 1] = last;
+}
+template <int T, int THREADS, int TILE_STEPS, class Scratch>
+inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi) {
+    matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi);
 }
 #endif
 
@@ -154,21 +181,23 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
 // Rows [lo, hi) of the layer whose tables start at `layer` (global memory; mfma_layer_words(T) words); the other rows of s
 // come back unspecified, like matrix_rows_rolled.  s norm.  `tile`: TILE_STEPS KiB of LDS shared by the workgroup's THREADS
 // threads, all of which must arrive here together (two barriers per stage of a row) with every lane active.
-template <int T, int THREADS, int TILE_STEPS, class Scratch>
-__device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f, uint32_t lo,
-                                                 uint32_t hi) {
-    constexpr int NQ = mfma_k_steps(T), NW = 8 * NQ;
+// General form: NIN input elements at `in`, rows [lo, hi) of NOUT into out (which may alias in: the inputs are consumed first).
+template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
+__device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
+                                                    uint32_t lo, uint32_t hi) {
+    constexpr int T = NOUT;
+    constexpr int NQ = mfma_k_steps(NIN), NW = 8 * NQ;
     constexpr int NS = (NQ + TILE_STEPS - 1) / TILE_STEPS;   // the tile holds TILE_STEPS k-steps: a row passes through it in NS stages
     const uint32_t lane = threadIdx.x & 63;
     uint32_t W[NW];
-    mfma_state_words<T>(s, W);
+    mfma_state_words<NIN>(in, W);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) lane32_swap(W[8 * q + u], W[8 * q + 4 + u]);
     }
-    const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(T));
-    Fe last = s[T - 1];
+    const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(NIN));
+    Fe last = out[T - 1];
     // this thread's share of a stage of the table: fetched from global memory one stage ahead, so that the fetch runs behind
     // the multiplications of the stage before instead of between the two barriers
     constexpr int kPer = (TILE_STEPS * 64 + THREADS - 1) / THREADS;
@@ -222,8 +251,13 @@ __device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const 
         if (i + 1 < (uint32_t)T) sc.set(i, row);
         else last = row;
     }
-    static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
-    s[T - 1] = last;
+    static_for<0, T - 1>([&](auto i) { out[i] = sc.get(i); });
+    out[T - 1] = last;
+}
+template <int T, int THREADS, int TILE_STEPS, class Scratch>
+__device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f, uint32_t lo,
+                                                 uint32_t hi) {
+    matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi);
 }
 
 #endif  // __HIPCC__

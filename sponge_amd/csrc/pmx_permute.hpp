@@ -67,6 +67,7 @@ struct OptTables {
     const uint32_t *ark, *mds, *full, *sparse, *bdense;   // elements (mds: the reference matrix, dense schedule only)
     const uint32_t *tab_full, *tab_sparse, *tab_bdense;   // shifted tables (pmx_prepare.hpp layout)
     const uint32_t *mfma;                                 // int8 tables of the dense layers (pmx_mfma.hpp), or null
+    const uint32_t *win;                                  // window tables of the partial rounds (pmx_mfma.hpp: mfma_window_words), or null
 };
 
 PMX_FN uint32_t full_ordinal(uint32_t r, const Rounds &c) { return r < c.half_full ? r : r - c.partial_rounds - 1; }
@@ -343,12 +344,51 @@ PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, con
 // copies would not fit the instruction cache at t = 9).
 // MFMA_THREADS > 0: the dense layers run on the matrix cores (pmx_mfma.hpp) - the workgroup has that many threads, all of them
 // here together, and `tile` is its shared LDS tile.
-template <int T, int ALPHA, class Scratch, int MFMA_THREADS = 0, int MFMA_TILE_STEPS = 0>
+// MFMA_WINDOW = K > 0 (with MFMA_THREADS > 0): the partial rounds run as windows of K (pmx_mfma.hpp) - the layer after the entrance
+// round is the windows' entry layer on the matrix cores, and the sparse layers are not in the kernel at all.
+template <int T, int ALPHA, class Scratch, int MFMA_THREADS = 0, int MFMA_TILE_STEPS = 0, int MFMA_WINDOW = 0>
 PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
                            const FieldRt &f, uint32_t want_lo = 0, uint32_t want_hi = T, void *tile = nullptr) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
     uint32_t guard = 0;   // keeps table_touch's loads alive (see the end of the function)
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
+        if constexpr (MFMA_THREADS > 0 && MFMA_WINDOW > 0) {
+            if (r == first_partial) {   // the whole partial section: windows, each closed by one layer on the matrix cores
+                constexpr int K = MFMA_WINDOW, NIN = T - 1 + K;
+                constexpr size_t kLayer = (size_t)mfma_layer_words_io(NIN, T), kPer = kLayer + (size_t)mfma_window_hist(K) * kFeStride;
+                const uint32_t n_win = (c.partial_rounds + K - 1) / K;
+                uint32_t kw = c.partial_rounds - (n_win - 1) * K;   // the first window is the short one
+                const uint32_t *wt = tb.win + mfma_layer_words(T);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (uint32_t w = 0; w < n_win; ++w, wt += kPer, kw = K) {
+                    Fe in[NIN];
+                    static_for<1, T>([&](auto i) { in[i - 1] = s[i]; });
+                    const uint32_t *hist = wt + kLayer;
+                    in[T - 1] = fe_sbox<ALPHA>(s[0], c.alpha, one, f);               // z_1 = x_1^alpha: x_1 came whole out of the layer before
+                    static_for<1, K>([&](auto kk) {
+                        constexpr int k = decltype(kk)::value;                        // z_{k+1} from x_{k+1} = z_k + u_k + sum_{i<k} h_{k,i} z_i
+                        if ((uint32_t)k < kw) {
+                            Fe x = s[k];
+                            if constexpr (k >= 2) {
+                                Fe hc[k - 1];
+                                static_for<0, k - 1>([&](auto i) { hc[i] = fe_const(hist + (size_t)(mfma_window_hist(k) + i) * kFeStride); });
+                                x = mont_dot_add<k - 1>(&in[T - 1], hc, x, f);
+                            }
+                            in[T - 1 + k] = fe_sbox<ALPHA>(fe_add_lazy(x, in[T - 2 + k]), c.alpha, one, f);
+                        } else {
+                            in[T - 1 + k] = fe_zero();
+                        }
+                    });
+#if defined(__HIPCC__)
+                    matrix_rows_mfma_io<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(in, s, sc, wt, static_cast<mfma_v4i *>(tile), f, 0u, (uint32_t)T);
+#else
+                    matrix_rows_mfma_io<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(in, s, sc, wt, tile, f, 0u, (uint32_t)T);
+#endif
+                }
+                r = last_partial;
+                continue;
+            }
+        }
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
         const bool full = r < first_partial || r > last_partial;
         const bool sparse_layer = r + 1 >= first_partial && r < last_partial;   // entrance round and all partial rounds but the last
@@ -360,7 +400,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                 sc.set(i, fe_sbox<ALPHA>(fe_add_lazy(sc.get(i), fe_const(rk + i * kFeStride)), c.alpha, one, f));
             s[T - 1] = fe_sbox<ALPHA>(fe_add_lazy(s[T - 1], fe_const(rk + (T - 1) * kFeStride)), c.alpha, one, f);
             static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
-        } else {               // partial round: S-box on lane 0; lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom)
+        } else if constexpr (!(MFMA_THREADS > 0 && MFMA_WINDOW > 0)) {   // partial round: S-box on lane 0; lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom)
             if constexpr (PMX_HYBRID_TOUCH) {
                 if (sparse_layer) {
                     const uint32_t *rt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
@@ -372,7 +412,17 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             }
             s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         }
-        if (sparse_layer) {
+        if constexpr (MFMA_THREADS > 0 && MFMA_WINDOW > 0) {
+            if (sparse_layer) {   // only the entrance round comes here: its layer leads into the first window
+#if defined(__HIPCC__)
+                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, tb.win, static_cast<mfma_v4i *>(tile), f, 0u, (uint32_t)T);
+#else
+                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, tb.win, tile, f, 0u, (uint32_t)T);
+#endif
+                continue;
+            }
+        }
+        if (sparse_layer && !(MFMA_THREADS > 0 && MFMA_WINDOW > 0)) {
             const uint32_t *spt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
             const Fe z0 = s[0];
             if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {

@@ -59,6 +59,9 @@ struct Prepared {
     //   mfma_offset                [RF][mfma_layer_words(t)]
     size_t mfma_offset;
     bool mfma_dense;
+    //   -- only when mfma_dense and mfma_window_for(t) > 0: the partial section as windows (pmx_mfma.hpp: mfma_window_words) --
+    size_t win_offset;
+    uint32_t mfma_window;   // K, or 0: no windows (the sparse layers run on the VALU)
     size_t io_offset;   // kIoWords words behind FieldRt::io
 };
 
@@ -66,14 +69,15 @@ struct Prepared {
 // Row i, k-step q, lane l: 16 bytes = bytes e = l & 31 of the residues  Y = c_ij * 2^(8 b + 58) mod p  for the 16 positions
 // k = 32 q + 16 (l >> 5) + 0..15 of the state's byte string (k = 36 j + b), as balanced signed bytes; then per row the eight
 // word sums of 128 * sum_k Y_k (the state's bytes enter as u - 128).
-inline void put_mfma_layer(const HostField &hf, const U256 *rows, size_t t, uint32_t *dst) {
-    const size_t nq = (size_t)mfma_k_steps((int)t), row_words = (size_t)mfma_row_words((int)t);
+// General form: n_out rows of n_in constants; aff (may be null): one constant per row added to the row's value.
+inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in, size_t n_out, const U256 *aff, uint32_t *dst) {
+    const size_t nq = (size_t)mfma_k_steps((int)n_in), row_words = (size_t)mfma_row_words((int)n_in);
     int8_t *bytes = reinterpret_cast<int8_t *>(dst);
-    long long *corr = reinterpret_cast<long long *>(dst + t * row_words);
-    for (size_t i = 0; i < t; ++i) {
+    long long *corr = reinterpret_cast<long long *>(dst + n_out * row_words);
+    for (size_t i = 0; i < n_out; ++i) {
         long long colsum[32] = {0};
-        for (size_t j = 0; j < t; ++j) {
-            U256 y = times_pow2(hf, hf.from_mont(rows[i * t + j]), 58);
+        for (size_t j = 0; j < n_in; ++j) {
+            U256 y = times_pow2(hf, hf.from_mont(rows[i * n_in + j]), 58);
             for (size_t b = 0; b < 33; ++b) {
                 // balanced bytes of y: digit e in [-128, 127], carry into the next
                 unsigned carry = 0;
@@ -92,13 +96,17 @@ inline void put_mfma_layer(const HostField &hf, const U256 *rows, size_t t, uint
                 y = times_pow2(hf, y, 8);
             }
         }
+        // the row's constant in the units of V: its internal form (x 2^261) times the 2^58 the finish divides by
+        U256 add = {{0, 0, 0, 0}};
+        if (aff) add = times_pow2(hf, hf.from_mont(aff[i]), 261 + 58);
         for (size_t w = 0; w < 8; ++w) {
             long long v = 0;
             for (size_t tt = 0; tt < 4; ++tt) v += (128 * colsum[4 * w + tt]) * (1ll << (8 * tt));
-            corr[i * 8 + w] = v;
+            corr[i * 8 + w] = v + (long long)((add.l[w / 2] >> (32 * (w % 2))) & 0xffffffffull);
         }
     }
 }
+inline void put_mfma_layer(const HostField &hf, const U256 *rows, size_t t, uint32_t *dst) { put_mfma_layer_io(hf, rows, t, t, nullptr, dst); }
 
 // shifted table of a ROW of n constants (given as ABI Montgomery residues C_i * 2^256) in the chunked layout of
 // pmx_field.hpp (tab_index): limb k of C_i * 2^(29 j + 58) mod p; tab_row_words(n) words, padding left 0
@@ -223,7 +231,8 @@ inline size_t full_matrix_ordinal(uint32_t r, uint32_t half_full, uint32_t rp) {
 // schedule 351); t = 9, 8 + 57: 1497 (5265).
 inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full, uint32_t rp, uint32_t rounds, uint64_t alpha,
                               const std::vector<U256> &ark, const HostMat &M, std::vector<U256> &ark_opt,
-                              std::vector<U256> &fullmat, std::vector<U256> &sparse, std::vector<U256> &bdense) {
+                              std::vector<U256> &fullmat, std::vector<U256> &sparse, std::vector<U256> &bdense,
+                              std::vector<U256> *entrance_scale = nullptr, std::vector<U256> *exit_scale = nullptr) {
     if (rp == 0 || half_full == 0 || t < 2 || half_full + rp >= rounds) return false;
     const size_t n = t - 1, per = 2 * (size_t)t - 1;
     const uint32_t rf_total = rounds - rp, entrance = half_full - 1, last_partial = half_full + rp - 1;
@@ -294,6 +303,8 @@ inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full
             if (u256_is_zero(e[i])) return false;
             inv_e[i] = f.inverse(e[i]);
         }
+        if (r == entrance && entrance_scale) *entrance_scale = e;       // what multiplies the S-box outputs of the entrance round
+        if (r == last_partial + 1 && exit_scale) *exit_scale = d;       // what multiplies the state that enters the first full round after the partial section
         if (r == entrance || (!full && r < last_partial)) {            // sparse layer
             U256 *sp = &sparse[(size_t)(r - entrance) * per];
             if (u256_is_zero(sp[0])) return false;
@@ -319,6 +330,172 @@ inline bool derive_opt_tables(const HostField &f, uint32_t t, uint32_t half_full
             }
         }
         d = dn;
+    }
+    return true;
+}
+
+// ---- the partial section as windows (pmx_mfma.hpp, pmx_permute.hpp: MFMA_WINDOW) ----------------------------------------------
+// Exact algebra on the reference's rounds (s <- M (s + c_r with lane 0 raised to alpha)), per window of kw <= K partial rounds:
+// with sigma = lanes 1.. of the true state at the window's start and z_1 .. z_kw its S-box outputs, every later S-box input and the
+// state at the window's end are affine in (sigma, z).  The window carries  x^_1 = x_1  and  u^ = Psi sigma + psi  where the first
+// kw - 1 rows of Psi are the sigma-parts (and constants) of x_2 .. x_kw, scaled by delta_{k+1} = delta_k^alpha / M_00 so that
+//     x^_{k+1} = delta_{k+1} x_{k+1} = z^_k + u^_k + sum_{i<k} h_{k,i} z^_i,      z^_k = x^_k^alpha = delta_k^alpha z_k,
+// and the other rows are unit rows that keep Psi invertible.  Layer w maps (u^, z^) of window w to (x^_1, u^) of window w + 1 (the
+// last one to what the first full round after the section expects: D (s + c) minus the constant the kernel adds there), the entry
+// layer maps the scaled S-box outputs of the entrance round to window 0.
+struct WindowPlan {
+    size_t n_win = 0;
+    std::vector<U256> entry_rows, entry_aff;                 // t x t, t
+    std::vector<std::vector<U256>> rows, aff;                // per window: t x (t - 1 + K), t
+    std::vector<U256> hist;                                  // per window mfma_window_hist(K) constants
+};
+
+inline size_t mat_rank(const HostField &f, HostMat a) {
+    size_t rank = 0;
+    const size_t n = a.size(), m = n ? a[0].size() : 0;
+    for (size_t col = 0; col < m && rank < n; ++col) {
+        size_t piv = rank;
+        while (piv < n && u256_is_zero(a[piv][col])) ++piv;
+        if (piv == n) continue;
+        std::swap(a[piv], a[rank]);
+        const U256 d = f.inverse(a[rank][col]);
+        for (size_t i = rank + 1; i < n; ++i) {
+            if (u256_is_zero(a[i][col])) continue;
+            const U256 k = f.mul(a[i][col], d);
+            for (size_t j = col; j < m; ++j) a[i][j] = f.sub(a[i][j], f.mul(k, a[rank][j]));
+        }
+        ++rank;
+    }
+    return rank;
+}
+
+inline bool derive_window_layers(const HostField &f, uint32_t t, uint32_t half, uint32_t rp, uint64_t alpha, uint32_t K,
+                                 const std::vector<U256> &ark, const HostMat &M, const std::vector<U256> &entrance_scale,
+                                 const std::vector<U256> &exit_scale, const U256 *arkopt_exit, WindowPlan &plan) {
+    if (K < 1 || K > t || rp == 0 || half == 0 || entrance_scale.size() != t || exit_scale.size() != t) return false;
+    const U256 zero = {{0, 0, 0, 0}};
+    const size_t n = t - 1, G = n + K;                       // generators: sigma (n), z_1..z_K; index G = the constant
+    const size_t n_win = (rp + K - 1) / K;
+    typedef std::vector<U256> Form;                          // G + 1 coefficients
+    auto unit = [&](size_t g) { Form v(G + 1, zero); v[g] = f.r; return v; };
+    plan = WindowPlan();
+    plan.n_win = n_win;
+    plan.rows.resize(n_win);
+    plan.aff.resize(n_win);
+    plan.hist.assign(n_win * (size_t)mfma_window_hist((int)K), zero);
+    // what the layer BEFORE window w has to produce, from the true state at the window's start: x^_1 = s_0 + c, u^ = Psi s_1.. + psi
+    std::vector<HostMat> Psi(n_win), PsiInv(n_win);
+    std::vector<std::vector<U256>> psi(n_win);
+    std::vector<std::vector<Form>> Send(n_win);              // true state after the window, over (sigma, z, 1)
+    std::vector<std::vector<U256>> zscale(n_win);            // delta_j^-alpha: z_j = zscale_j z^_j
+    uint32_t r1 = half;
+    for (size_t w = 0; w < n_win; ++w) {
+        const uint32_t kw = w == 0 ? rp - (uint32_t)(n_win - 1) * K : K;
+        std::vector<Form> S(t, Form(G + 1, zero)), X(kw + 1);
+        for (size_t i = 1; i < t; ++i) S[i] = unit(i - 1);
+        for (uint32_t j = 1; j <= kw; ++j) {
+            const U256 *c = &ark[(size_t)(r1 + j - 1) * t];
+            std::vector<Form> y = S;
+            for (size_t i = 0; i < t; ++i) y[i][G] = f.add(y[i][G], c[i]);
+            if (j >= 2) X[j] = y[0];
+            y[0] = unit(n + j - 1);
+            for (size_t i = 0; i < t; ++i) {
+                Form acc(G + 1, zero);
+                for (size_t l = 0; l < t; ++l)
+                    for (size_t g = 0; g <= G; ++g)
+                        if (!u256_is_zero(y[l][g])) acc[g] = f.add(acc[g], f.mul(M[i][l], y[l][g]));
+                S[i] = acc;
+            }
+        }
+        Send[w] = S;
+        std::vector<U256> delta(kw + 1, f.r), dpow(kw + 1, f.r);   // delta_j, delta_j^alpha (delta_1 = 1)
+        zscale[w].assign(K, zero);
+        zscale[w][0] = f.r;
+        Psi[w].assign(n, std::vector<U256>(n, zero));
+        psi[w].assign(n, zero);
+        for (uint32_t j = 2; j <= kw; ++j) {
+            const U256 a = X[j][n + j - 2];                  // coefficient of z_{j-1} in x_j
+            if (u256_is_zero(a)) return false;
+            delta[j] = f.mul(dpow[j - 1], f.inverse(a));
+            dpow[j] = host_pow(f, delta[j], alpha);
+            if (u256_is_zero(dpow[j])) return false;
+            zscale[w][j - 1] = f.inverse(dpow[j]);
+            const size_t k = j - 1;                          // x_{k+1}: coordinate u^_k, history h_{k,i}
+            for (size_t g = 0; g < n; ++g) Psi[w][k - 1][g] = f.mul(delta[j], X[j][g]);
+            psi[w][k - 1] = f.mul(delta[j], X[j][G]);
+            for (size_t i = 1; i < k; ++i)
+                plan.hist[w * (size_t)mfma_window_hist((int)K) + (size_t)mfma_window_hist((int)k) + (i - 1)] =
+                    f.mul(f.mul(delta[j], X[j][n + i - 1]), zscale[w][i - 1]);
+        }
+        // the other coordinates: lanes of sigma themselves, chosen so that Psi stays invertible
+        size_t have = kw - 1, cand = 0;
+        while (have < n) {
+            if (cand >= n) return false;
+            HostMat trial(Psi[w].begin(), Psi[w].begin() + (long)have);
+            trial.push_back(std::vector<U256>(n, zero));
+            trial.back()[cand] = f.r;
+            if (mat_rank(f, trial) == have + 1) {
+                Psi[w][have] = trial.back();
+                ++have;
+            }
+            ++cand;
+        }
+        if (!mat_inverse(f, Psi[w], PsiInv[w])) return false;
+        r1 += kw;
+    }
+    // rows of a producing layer: P[i] = true lane i at the start of window w over the producer's inputs (n_in + 1 coefficients)
+    auto emit = [&](const std::vector<Form> &P, size_t n_in, size_t w, uint32_t first_round, std::vector<U256> &rows, std::vector<U256> &aff) {
+        rows.assign((size_t)t * n_in, zero);
+        aff.assign(t, zero);
+        for (size_t g = 0; g < n_in; ++g) rows[g] = P[0][g];
+        aff[0] = f.add(P[0][n_in], ark[(size_t)first_round * t]);
+        for (size_t k = 0; k < n; ++k) {
+            for (size_t g = 0; g <= n_in; ++g) {
+                U256 acc = zero;
+                for (size_t l = 0; l < n; ++l) acc = f.add(acc, f.mul(Psi[w][k][l], P[1 + l][g]));
+                if (g < n_in) rows[(1 + k) * n_in + g] = acc;
+                else aff[1 + k] = f.add(acc, psi[w][k]);
+            }
+        }
+    };
+    {   // entry layer: inputs = scaled S-box outputs of the entrance round, true z_j = in_j / e_j, state = M z
+        std::vector<Form> P(t, Form(t + 1, zero));
+        for (size_t j = 0; j < t; ++j) {
+            if (u256_is_zero(entrance_scale[j])) return false;
+            const U256 inv = f.inverse(entrance_scale[j]);
+            for (size_t i = 0; i < t; ++i) P[i][j] = f.mul(M[i][j], inv);
+        }
+        emit(P, t, 0, half, plan.entry_rows, plan.entry_aff);
+    }
+    r1 = half;
+    for (size_t w = 0; w < n_win; ++w) {
+        const uint32_t kw = w == 0 ? rp - (uint32_t)(n_win - 1) * K : K;
+        r1 += kw;                                            // first round after this window
+        // the window's end state over its own inputs (u^, z^): sigma = PsiInv (u^ - psi), z_j = zscale_j z^_j
+        std::vector<U256> shift = mat_vec(f, PsiInv[w], psi[w]);   // PsiInv psi
+        std::vector<Form> P(t, Form(G + 1, zero));
+        for (size_t i = 0; i < t; ++i) {
+            const Form &S = Send[w][i];
+            for (size_t m = 0; m < n; ++m) {
+                U256 acc = zero;
+                for (size_t l = 0; l < n; ++l) acc = f.add(acc, f.mul(S[l], PsiInv[w][l][m]));
+                P[i][m] = acc;
+            }
+            for (size_t j = 0; j < K; ++j) P[i][n + j] = f.mul(S[n + j], zscale[w][j]);   // (zero columns for the rounds a short window lacks)
+            U256 cst = S[G];
+            for (size_t l = 0; l < n; ++l) cst = f.sub(cst, f.mul(S[l], shift[l]));
+            P[i][G] = cst;
+        }
+        if (w + 1 < n_win) {
+            emit(P, G, w + 1, r1, plan.rows[w], plan.aff[w]);
+        } else {   // into the full rounds: D (s + c) - (the constant the kernel adds at that round)
+            plan.rows[w].assign((size_t)t * G, zero);
+            plan.aff[w].assign(t, zero);
+            for (size_t i = 0; i < t; ++i) {
+                for (size_t g = 0; g < G; ++g) plan.rows[w][i * G + g] = f.mul(exit_scale[i], P[i][g]);
+                plan.aff[w][i] = f.sub(f.mul(exit_scale[i], f.add(P[i][G], ark[(size_t)r1 * t + i])), arkopt_exit[i]);
+            }
+        }
     }
     return true;
 }
@@ -351,7 +528,8 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         to_limbs29(times_pow2(hf, v, 5), &out.consts[k * kFeStride]);   // x*2^256 -> x*2^261
     }
     // optimised schedule
-    std::vector<U256> src_full, src_sparse, src_bdense;
+    std::vector<U256> src_full, src_sparse, src_bdense, entrance_scale, exit_scale, arkopt_exit, ark_true;
+    HostMat M_true;
     const uint32_t half = cfg->full_rounds / 2, rp = cfg->partial_rounds;
     const size_t n_full = cfg->full_rounds ? (size_t)cfg->full_rounds - 1 : 0;   // matrices in `full`
     {
@@ -365,7 +543,13 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         long double two_261 = 1;
         for (int i = 0; i < 261; ++i) two_261 *= 2;
         out.has_opt = opt_schedule_lane_headroom(two_261 / pv, rp, cfg->alpha) &&
-                      derive_opt_tables(hf, t, half, rp, (uint32_t)rounds, cfg->alpha, ark, M, ark_opt, src_full, src_sparse, src_bdense);
+                      derive_opt_tables(hf, t, half, rp, (uint32_t)rounds, cfg->alpha, ark, M, ark_opt, src_full, src_sparse, src_bdense,
+                                        &entrance_scale, &exit_scale);
+        if (out.has_opt) {
+            arkopt_exit.assign(ark_opt.begin() + (long)((size_t)(half + rp) * t), ark_opt.begin() + (long)((size_t)(half + rp) * t + t));
+            ark_true = ark;
+            M_true = M;
+        }
         out.opt_offset = out.consts.size();
         out.opt_full_offset = out.opt_sparse_offset = out.opt_bdense_offset = out.opt_offset;
         if (out.has_opt) {
@@ -452,6 +636,32 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         out.consts.resize(out.mfma_offset + (n_full + 1) * lw, 0u);
         for (size_t o = 0; o < n_full; ++o) put_mfma_layer(hf, &src_full[o * t * t], t, &out.consts[out.mfma_offset + o * lw]);
         put_mfma_layer(hf, src_bdense.data(), t, &out.consts[out.mfma_offset + n_full * lw]);
+    }
+    // ... and the partial section as windows closed by one such layer each.  A width that takes windows has no sparse layers in
+    // its matrix-core kernels: if the windows cannot be derived (a zero where the algebra divides) the config runs on the VALU rows.
+    out.win_offset = out.consts.size();
+    out.mfma_window = 0;
+    if (out.mfma_dense && mfma_window_for((int)t) > 0) {
+        const uint32_t K = (uint32_t)mfma_window_for((int)t);
+        WindowPlan plan;
+        if (K <= t && derive_window_layers(hf, t, half, rp, cfg->alpha, K, ark_true, M_true, entrance_scale, exit_scale, arkopt_exit.data(), plan)) {
+            const size_t lw_in = (size_t)mfma_layer_words_io((int)(t - 1 + K), (int)t), nh = (size_t)mfma_window_hist((int)K);
+            out.consts.resize(out.win_offset + mfma_window_words((int)t, (int)K, plan.n_win), 0u);
+            uint32_t *dst = &out.consts[out.win_offset];
+            put_mfma_layer_io(hf, plan.entry_rows.data(), t, t, plan.entry_aff.data(), dst);
+            dst += mfma_layer_words((int)t);
+            for (size_t w = 0; w < plan.n_win; ++w) {
+                put_mfma_layer_io(hf, plan.rows[w].data(), t - 1 + K, t, plan.aff[w].data(), dst);
+                dst += lw_in;
+                for (size_t h = 0; h < nh; ++h) to_limbs29(times_pow2(hf, plan.hist[w * nh + h], 5), dst + h * kFeStride);
+                dst += nh * kFeStride;
+            }
+            out.mfma_window = K;
+        } else {
+            out.mfma_dense = false;
+            out.consts.resize(out.mfma_offset);
+            out.win_offset = out.consts.size();
+        }
     }
     FieldRt &f = out.f;
     f.unit = 1;

@@ -132,6 +132,7 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
     tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
     tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     tb.mfma = nullptr;
+    tb.win = nullptr;
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
         HostScratch<T> sc;
@@ -162,12 +163,15 @@ extern "C" int hc_permute_hybrid_mfma(const pmx_config *cfg, uint64_t *states, s
     tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
     tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     tb.mfma = pp.consts.data() + pp.mfma_offset;
+    tb.win = pp.consts.data() + pp.win_offset;
+    constexpr int KW = mfma_window_for(T);   // the partial section as windows when the width takes them (pmx_mfma.hpp)
+    if ((int)pp.mfma_window != KW) return PMX_ERR_UNSUPPORTED;
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
         HostScratch<T> sc;
         for (int i = 0; i < T; ++i) s[i] = fe_from_abi_scaled(load_abi(states + (k * T + i) * 4));
-        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, 256, 6>(s, sc, tb, pp.c, pp.one, pp.f);
-        else permute_hybrid<T, 0, HostScratch<T>, 256, 6>(s, sc, tb, pp.c, pp.one, pp.f);
+        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, 256, 6, KW>(s, sc, tb, pp.c, pp.one, pp.f);
+        else permute_hybrid<T, 0, HostScratch<T>, 256, 6, KW>(s, sc, tb, pp.c, pp.one, pp.f);
         for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
     }
     return PMX_OK;

@@ -22,7 +22,7 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck")
 @pytest.fixture(scope="module")
 def hc():
     subprocess.check_call(["make", "-C", HERE, "all"], stdout=subprocess.DEVNULL)
-    lib = ctypes.CDLL(os.path.join(HERE, "libpmx_hostcheck.so"))
+    lib = ctypes.CDLL(os.environ.get("PMX_HOSTCHECK_LIB") or os.path.join(HERE, "libpmx_hostcheck.so"))
     lib.hc_permute.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_rt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_opt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
