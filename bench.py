@@ -68,13 +68,17 @@ BASELINE_CONFIG = {("c2", False): "BASELINE.json configs[1] (C2)", ("c2", True):
                    ("c5", True): "BASELINE.json configs[4] (C5)"}
 
 
-def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tables=False, mfma_dense=False):
+def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tables=False, mfma_dense=False, window=0):
     """v_mad_u64_u32 count of one permutation as implemented (pmx_field.hpp): product 81, square 45, reduction 81 limb
     products; one reduction per S-box step and per matrix row.  With shifted tables (tab_dot) a row of N constants
     costs 81 N + 18 instead of 81 N + 81 (`row_tables`) and an identity-lane update 81 + 18 + 9 instead of 162 + 9
     (`lane_tables`).  The optimised schedule carries the state scaled lane by lane so that one entry per row of every
     matrix but the last round's is exactly one (pmx_prepare.hpp: derive_opt_tables).  `mfma_dense`: the rows of the DENSE
-    layers come from the matrix cores (pmx_mfma.hpp) - 20 multiplies each, the two Montgomery steps of the row's finish."""
+    layers come from the matrix cores (pmx_mfma.hpp) - 20 multiplies each, the two Montgomery steps of the row's finish.
+    `window` = K > 0: the partial rounds as windows of K S-boxes (the first window takes the remainder), each closed by one
+    matrix-core layer of t rows; on the VALU a window keeps its S-boxes and the history products of its later S-box inputs
+    (x_{k+1} = z_k + u_k + sum_{i<k} h_{k,i} z_i: a (k-1)-term dot product with an addend, element form); the layer after the
+    entrance round is a matrix-core layer as well."""
     sqr, mul = 45 + 81, 81 + 81
     chain = {5: 2 * sqr + mul, 17: 4 * sqr + mul}.get(alpha)
     if chain is None:
@@ -89,6 +93,11 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
         dot = norm_dense = 20
     else:
         norm_dense = norm
+    if optimised and mfma_dense and window > 0:
+        n_win = -(-rp // window)
+        sizes = [rp - (n_win - 1) * window] + [window] * (n_win - 1)
+        hist = sum(81 * (k - 1) + 81 + 9 for kw in sizes for k in range(2, kw))
+        return (rf * t + rp) * chain + (rf + n_win) * t * 20 + hist
     if optimised:
         # S-box layers: RF full, RP partial.  Linear layers: RF - 2 normalised dense (every full round but the entrance and the
         # last one) + 1 dense (last round) + RP sparse (after the entrance round and after every partial round but the last)
@@ -465,7 +474,7 @@ def main():
         _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, op, (n // 2 if merkle else n), (in_len if duplex else 0), info))
         mfma_dense = bool(info.mfma_dense)
         mads = mads_per_permutation(t, alpha, rf, rp, optimised=bool(info.optimised), row_tables=bool(info.row_tables),
-                                    lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense)
+                                    lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense, window=int(info.partial_window))
         # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
         # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
         last_row = 20 if mfma_dense else 81 * t + (18 if info.row_tables else 81)
@@ -493,6 +502,7 @@ def main():
             "engine": {"name": info.engine.decode(), "threads_per_workgroup": info.threads, "waves_per_simd": info.waves_per_simd,
                        "lds_bytes_per_workgroup": info.lds_bytes, "optimised_schedule": bool(info.optimised),
                        "row_tables": bool(info.row_tables), "lane_tables": bool(info.lane_tables), "mfma_dense": mfma_dense,
+                       "partial_window": int(info.partial_window),
                        "source": "pmx_ctx_engine_info (the launchers' own dispatch conditions)" + (", widest level of the tree" if merkle else "")},
             "rccl": rccl,
             "verified": (verify["ok"] if verify else None), "verify": verify,

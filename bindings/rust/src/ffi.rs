@@ -54,6 +54,7 @@ pub struct pmx_engine_info {
     pub lane_tables: c_int,
     pub mfma_dense: c_int,
     pub launches: c_int,
+    pub partial_window: c_int,
 }
 #[repr(C)]
 pub struct pmx_issue_slot {

@@ -143,7 +143,7 @@ int pmx_ctx_width(const pmx_ctx *ctx);
 #define PMX_OP_ABSORB 3
 #define PMX_OP_SQUEEZE 4
 typedef struct pmx_engine_info {
-    char engine[64];     /* e.g. "RegEngine<3,5,opt,tab>", "HybridEngine<9,5,mfma>", "HybridEngine<9,5,mfma> x passes", "QuadEngine<5>" */
+    char engine[64];     /* e.g. "RegEngine<3,5,opt,tab>", "HybridEngine<9,5,mfma,windows of 6>", "... x passes", "QuadEngine<5>" */
     int width;           /* t */
     int threads;         /* per workgroup */
     int waves_per_simd;  /* the kernel's launch bound (what its register allocation is held to) */
@@ -153,6 +153,8 @@ typedef struct pmx_engine_info {
     int lane_tables;     /* 1: identity-lane updates of the sparse layers consume shifted tables */
     int mfma_dense;      /* 1: rows of the dense layers come from the matrix cores (int8 GEMM, pmx_mfma.hpp) */
     int launches;        /* kernel launches of the call: 1, or the passes of an absorb / squeeze call on wide states */
+    int partial_window;  /* K > 0: the partial rounds run as windows of K S-boxes, each closed by ONE layer on the matrix cores
+                            (no sparse layers on the VALU); 0: one sparse layer per partial round */
 } pmx_engine_info;
 int pmx_ctx_engine_info(const pmx_ctx *ctx, int op, size_t n, size_t len, pmx_engine_info *out);
 

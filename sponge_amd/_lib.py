@@ -58,7 +58,7 @@ class PmxEngineInfo(ctypes.Structure):
     _fields_ = [
         ("engine", ctypes.c_char * 64), ("width", ctypes.c_int), ("threads", ctypes.c_int), ("waves_per_simd", ctypes.c_int),
         ("lds_bytes", ctypes.c_int), ("optimised", ctypes.c_int), ("row_tables", ctypes.c_int), ("lane_tables", ctypes.c_int),
-        ("mfma_dense", ctypes.c_int), ("launches", ctypes.c_int),
+        ("mfma_dense", ctypes.c_int), ("launches", ctypes.c_int), ("partial_window", ctypes.c_int),
     ]
 
 

@@ -552,6 +552,7 @@ struct HybridEngine {
         o.row_tables = T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB;
         o.lane_tables = T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB;
         o.mfma_dense = MFMA;
+        o.partial_window = MFMA ? mfma_window_for(T) : 0;
     }
 
     __device__ __forceinline__ Fe get(uint32_t i) const {

@@ -51,13 +51,15 @@ PMX_FN constexpr int mfma_layer_words_io(int n_in, int n_out) { return n_out * m
 // matrix cores: inputs (u_1 .. u_{t-1}, z_1 .. z_K), outputs (x_1, u_1 .. u_{t-1}) of the next window, or the state the full
 // rounds after the partial section expect.  The first window is the short one when K does not divide the number of partial rounds.
 #ifndef PMX_MFMA_WINDOW
-#define PMX_MFMA_WINDOW 3
+#define PMX_MFMA_WINDOW 6
 #endif
 #ifndef PMX_MFMA_WINDOW_MIN_T
 #define PMX_MFMA_WINDOW_MIN_T 7
 #endif
 // window size of a width (0: its partial rounds keep their sparse layers on the VALU)
-PMX_FN constexpr int mfma_window_for(int t) { return (t >= PMX_MFMA_WINDOW_MIN_T && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T) ? PMX_MFMA_WINDOW : 0; }
+PMX_FN constexpr int mfma_window_for(int t) {
+    return (t >= PMX_MFMA_WINDOW_MIN_T && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T) ? (PMX_MFMA_WINDOW < t ? PMX_MFMA_WINDOW : t) : 0;
+}
 PMX_FN constexpr int mfma_window_hist(int k) { return (k - 1) * (k - 2) / 2; }   // history constants per window
 // words of the window tables of a config: the entry layer (t -> t), then per window its layer (t - 1 + K -> t) and its history constants
 PMX_FN constexpr size_t mfma_window_words(int t, int k, size_t windows) {

@@ -412,17 +412,8 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             }
             s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         }
-        if constexpr (MFMA_THREADS > 0 && MFMA_WINDOW > 0) {
-            if (sparse_layer) {   // only the entrance round comes here: its layer leads into the first window
-#if defined(__HIPCC__)
-                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, tb.win, static_cast<mfma_v4i *>(tile), f, 0u, (uint32_t)T);
-#else
-                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, tb.win, tile, f, 0u, (uint32_t)T);
-#endif
-                continue;
-            }
-        }
-        if (sparse_layer && !(MFMA_THREADS > 0 && MFMA_WINDOW > 0)) {
+        constexpr bool kWindows = MFMA_THREADS > 0 && MFMA_WINDOW > 0;
+        if (sparse_layer && !kWindows) {
             const uint32_t *spt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
             const Fe z0 = s[0];
             if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
@@ -474,6 +465,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             if constexpr (MFMA_THREADS > 0) {
                 const uint32_t n_full = c.total_rounds - c.partial_rounds - 1;   // the layer after the last partial round follows the full rounds' own
                 const uint32_t *lay = tb.mfma + (size_t)(full ? o : n_full) * mfma_layer_words(T);
+                if (kWindows && sparse_layer) lay = tb.win;   // the entrance round's layer leads into the first window (same code, other table)
 #if defined(__HIPCC__)
                 matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, static_cast<mfma_v4i *>(tile), f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
 #else

@@ -144,15 +144,11 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
     }
 }
 
-// The matrix-core form of the widest hybrid (HybridEngine<9, 5, true>): the same round loop with its dense layers through
-// pmx_mfma.hpp's tables, byte strings and row finish - the GEMM itself as plain integer sums (no matrix cores on the host).
-extern "C" int hc_permute_hybrid_mfma(const pmx_config *cfg, uint64_t *states, size_t n) {
-    Prepared pp;
-    std::string err;
-    int rc = prepare(cfg, pp, err);
-    if (rc) return rc;
-    if (!pp.has_opt || !pp.mfma_dense || pp.t != 9) return PMX_ERR_UNSUPPORTED;
-    constexpr int T = 9;
+// The matrix-core form of the wide hybrids (HybridEngine<7..9, alpha, true>): the same round loop with its dense layers - and the
+// partial section as windows closed by one layer each (pmx_mfma.hpp: PMX_MFMA_WINDOW) - through pmx_mfma.hpp's tables, byte
+// strings and row finish; the GEMM itself as plain integer sums (no matrix cores on the host).
+template <int T>
+static int permute_hybrid_mfma_t(const Prepared &pp, uint64_t *states, size_t n) {
     OptTables tb;
     tb.ark = pp.consts.data() + pp.opt_offset;
     tb.mds = pp.consts.data() + pp.mds_offset;
@@ -164,7 +160,7 @@ extern "C" int hc_permute_hybrid_mfma(const pmx_config *cfg, uint64_t *states, s
     tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     tb.mfma = pp.consts.data() + pp.mfma_offset;
     tb.win = pp.consts.data() + pp.win_offset;
-    constexpr int KW = mfma_window_for(T);   // the partial section as windows when the width takes them (pmx_mfma.hpp)
+    constexpr int KW = mfma_window_for(T);   // the partial section as windows when the width takes them
     if ((int)pp.mfma_window != KW) return PMX_ERR_UNSUPPORTED;
     for (size_t k = 0; k < n; ++k) {
         Fe s[T];
@@ -176,6 +172,21 @@ extern "C" int hc_permute_hybrid_mfma(const pmx_config *cfg, uint64_t *states, s
     }
     return PMX_OK;
 }
+extern "C" int hc_permute_hybrid_mfma(const pmx_config *cfg, uint64_t *states, size_t n) {
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);
+    if (rc) return rc;
+    if (!pp.has_opt || !pp.mfma_dense) return PMX_ERR_UNSUPPORTED;
+    switch (pp.t) {
+        case 7: return permute_hybrid_mfma_t<7>(pp, states, n);
+        case 8: return permute_hybrid_mfma_t<8>(pp, states, n);
+        case 9: return permute_hybrid_mfma_t<9>(pp, states, n);
+        default: return PMX_ERR_UNSUPPORTED;
+    }
+}
+// the window size this library was compiled with (tests build one library per size)
+extern "C" int hc_mfma_window(int t) { return mfma_window_for(t); }
 
 // register + scratch hybrid on the optimised schedule (what HybridEngine runs)
 extern "C" int hc_permute_hybrid(const pmx_config *cfg, uint64_t *states, size_t n) {

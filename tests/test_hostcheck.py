@@ -358,6 +358,41 @@ def test_matrix_core_tables_only_for_moduli_whose_residues_fit_32_balanced_bytes
             assert cref.limbs_to_elems(out, p) == want
 
 
+@pytest.mark.parametrize("K", [6, 1, 4, 9])
+def test_partial_rounds_as_windows_every_size_and_width(K):
+    """pmx_mfma.hpp / pmx_prepare.hpp (derive_window_layers): the matrix-core engines of t = 7..9 run their partial rounds as windows
+    of K S-boxes closed by ONE layer each - an exact rewrite derived on the host (basis of the carried lanes chosen so that later
+    S-box inputs are sums of an earlier output, a carried coordinate and K - 2 products at most; the first window takes RP mod K).
+    Host build of the same templates and tables against the big-integer oracle: the shipped size 6 (57 = 3 + 9 x 6), 1 (every
+    round its own window), 4 (first window of ONE round), 9 = t (first window of 3; at t = 7, 8 clamped to t); t = 7, 8, 9;
+    RP = 57, 56, 5, 1; alpha = 5 and the generic-exponent build; both fields of BASELINE."""
+    name = "libpmx_hostcheck.so" if K == 6 else "libpmx_hostcheck_k%d.so" % K
+    subprocess.check_call(["make", "-C", HERE, name], stdout=subprocess.DEVNULL)
+    hc = ctypes.CDLL(os.path.join(HERE, name))
+    hc.hc_permute_hybrid_mfma.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    assert hc.hc_mfma_window(9) == K and hc.hc_mfma_window(7) == min(K, 7) and hc.hc_mfma_window(6) == 0
+    cases = [(O.BN254_FR, 254, 8, 5, 8, 57), (O.BLS12_381_FR, 255, 8, 5, 8, 57), (O.BLS12_381_FR, 255, 7, 5, 8, 57),
+             (O.BLS12_381_FR, 255, 6, 5, 8, 57), (O.BLS12_381_FR, 255, 8, 17, 8, 56), (O.BN254_FR, 254, 6, 3, 6, 5),
+             (O.BLS12_381_FR, 255, 7, 5, 3, 1)]
+    for p, bits, rate, alpha, rf, rp in cases:
+        t = rate + 1
+        cfg = O.make_config(p, bits, rate, alpha, rf, rp)
+        rng = random.Random(K * 1000 + t * 10 + rp)
+        states = [[rng.randrange(p) for _ in range(t)] for _ in range(3)] + [[p - 1] * t, [0] * t]
+        want = [x for st in states for x in O.permute(cfg, st)]
+        limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), t, 4)
+        ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+        mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+        c = PmxConfig()
+        c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = rf, rp, alpha, rate, 1
+        for i, l in enumerate(O.to_limbs(p)):
+            c.modulus[i] = l
+        c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+        out = limbs.copy()
+        assert hc.hc_permute_hybrid_mfma(ctypes.byref(c), out.ctypes.data, len(states)) == 0, (K, t, alpha, rf, rp)
+        assert cref.limbs_to_elems(out, p) == want, (K, t, alpha, rf, rp)
+
+
 @pytest.mark.parametrize("rate", [2, 4])
 @pytest.mark.parametrize("rf,rp", [(1, 0), (1, 5), (3, 0), (3, 5), (7, 0), (7, 5), (3, 1), (3, 2)])
 def test_odd_full_rounds_follow_the_reference_split(hc, rate, rf, rp):
