@@ -74,7 +74,7 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     costs 81 N + 18 instead of 81 N + 81 (`row_tables`) and an identity-lane update 81 + 18 + 9 instead of 162 + 9
     (`lane_tables`).  The optimised schedule carries the state scaled lane by lane so that one entry per row of every
     matrix but the last round's is exactly one (pmx_prepare.hpp: derive_opt_tables).  `mfma_dense`: the rows of the DENSE
-    layers come from the matrix cores (pmx_mfma.hpp) - 20 multiplies each, the two Montgomery steps of the row's finish.
+    layers come from the matrix cores (pmx_mfma.hpp) - 9 multiplies each, the Montgomery step of the row's finish.
     `window` = K > 0: the partial rounds as windows of K S-boxes (the first window takes the remainder), each closed by one
     matrix-core layer of t rows; on the VALU a window keeps its S-boxes and the history products of its later S-box inputs
     (x_{k+1} = z_k + u_k + sum_{i<k} h_{k,i} z_i: a (k-1)-term dot product with an addend, element form); the layer after the
@@ -90,14 +90,14 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     lane = (81 + 18 + 9) if lane_tables else (mul + 9)
     sparse = norm + (t - 1) * lane                          # a sparse layer: row 0 and the identity lanes
     if mfma_dense:
-        dot = norm_dense = 20
+        dot = norm_dense = 9
     else:
         norm_dense = norm
     if optimised and mfma_dense and window > 0:
         n_win = -(-rp // window)
         sizes = [rp - (n_win - 1) * window] + [window] * (n_win - 1)
         hist = sum(81 * (k - 1) + 81 + 9 for kw in sizes for k in range(2, kw))
-        return (rf * t + rp) * chain + (rf + n_win) * t * 20 + hist
+        return (rf * t + rp) * chain + (rf + n_win) * t * 9 + hist
     if optimised:
         # S-box layers: RF full, RP partial.  Linear layers: RF - 2 normalised dense (every full round but the entrance and the
         # last one) + 1 dense (last round) + RP sparse (after the entrance round and after every partial round but the last)
@@ -477,7 +477,7 @@ def main():
                                     lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense, window=int(info.partial_window))
         # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
         # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
-        last_row = 20 if mfma_dense else 81 * t + (18 if info.row_tables else 81)
+        last_row = 9 if mfma_dense else 81 * t + (18 if info.row_tables else 81)
         if merkle:
             mads -= (t - 1) * last_row
         elif hashing:

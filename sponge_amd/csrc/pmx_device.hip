@@ -238,6 +238,12 @@ struct RegEngine {
 #define PMX_HYB_3WAVE_MAX_T 6   // widths up to this one must fit three waves per SIMD: t = 4, 5 do so on their own; t = 6 (176 VGPRs
                                 // when left alone) is +6 % when held to 168; t = 7, 8, 9 spill and lose 23 / 46 / 68 % (round 3 A/B)
 #endif
+#ifndef PMX_MFMA_4WAVE_MAX_T   // the same bounds for the matrix-core engines of the narrow widths (their byte strings and sums want registers)
+#define PMX_MFMA_4WAVE_MAX_T 3
+#endif
+#ifndef PMX_MFMA_3WAVE_MAX_T
+#define PMX_MFMA_3WAVE_MAX_T 5
+#endif
 #ifndef PMX_HYB_4WAVE_MAX_T
 #define PMX_HYB_4WAVE_MAX_T 4   // t = 4 (133 VGPRs when left alone) held to 128: four waves per SIMD, +3.8 % (round 3 A/B)
 #endif
@@ -258,7 +264,8 @@ struct HybridEngine {
     static constexpr int kWaves = MFMA ? PMX_MFMA_WAVES : PMX_HYB_WAVES;
     static constexpr int kThreads = 64 * kWaves;
     // waves per SIMD the register allocation must allow (4: <= 128 VGPRs, 3: <= 168, 2: <= 256)
-    static constexpr int kMinWaves = T <= PMX_HYB_4WAVE_MAX_T ? 4 : T <= PMX_HYB_3WAVE_MAX_T ? 3 : 2;
+    static constexpr int kMinWaves = MFMA ? (T <= PMX_MFMA_4WAVE_MAX_T ? 4 : T <= PMX_MFMA_3WAVE_MAX_T ? 3 : 2)
+                                          : (T <= PMX_HYB_4WAVE_MAX_T ? 4 : T <= PMX_HYB_3WAVE_MAX_T ? 3 : 2);
     static constexpr int kMinWavesDriver = 2;   // absorb / squeeze kernels (per-lane modes: more live state) spill under the tighter bounds
     // the matrix-core rows exchange operands between the lanes of a pair (l, l + 32) and share an LDS tile behind workgroup
     // barriers: permute() must be reached by every lane of the workgroup - never from a per-lane loop (absorb_kernel /
@@ -1418,9 +1425,21 @@ static bool lds_fits_engine(const DevConfig &c, uint32_t t) { return Engine::lds
 #define PMX_HYB_MFMA_CASE(W, CALL)                                                                      \
     if (t == W && W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T && lds_fits_engine<HybridEngine<W, PMX_HYB_ALPHA, true>>(c, t)) \
         return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::CALL;
+#if PMX_MFMA_MIN_T <= 3 && PMX_TU == 1   // t = 3, alpha = 5: large batches of permute / hash / compress (t3_mfma below)
+#define PMX_HYB_MFMA_NARROW(CALL) PMX_HYB_MFMA_CASE(3, CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
+#elif PMX_MFMA_MIN_T <= 4
+#define PMX_HYB_MFMA_NARROW(CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
+#elif PMX_MFMA_MIN_T <= 5
+#define PMX_HYB_MFMA_NARROW(CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
+#elif PMX_MFMA_MIN_T <= 6
+#define PMX_HYB_MFMA_NARROW(CALL) PMX_HYB_MFMA_CASE(6, CALL)
+#else
+#define PMX_HYB_MFMA_NARROW(CALL)
+#endif
 #define PMX_HYB_MFMA(CALL)               \
     do {                                 \
         if (c.mfma_dense) {              \
+            PMX_HYB_MFMA_NARROW(CALL)    \
             PMX_HYB_MFMA_CASE(7, CALL)   \
             PMX_HYB_MFMA_CASE(8, CALL)   \
             PMX_HYB_MFMA_CASE(9, CALL)   \
@@ -1464,8 +1483,15 @@ static hipError_t hyb_driver(const DevConfig &c, uint32_t t, uint64_t *states, u
         else return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::absorb(c, t, states, tag, index, io, len, n, st);
     }
 }
+#if PMX_MFMA_MIN_T <= 3 && PMX_TU == 1   // t = 3, alpha = 5, device-filling calls (t3_mfma): passes on the matrix-core engine
+#define PMX_HYB_DRIVER_T3(SQ, IO) \
+        case 3: return Launch<HybridEngine<3, PMX_HYB_ALPHA, true>>::template sponge_passes<SQ>(c, t, states, tag, index, IO, len, n, st, scratch);
+#else
+#define PMX_HYB_DRIVER_T3(SQ, IO)
+#endif
 #define PMX_HYB_DRIVER(SQ, IO)                                                     \
     switch (t) {                                                                   \
+        PMX_HYB_DRIVER_T3(SQ, IO)                                                  \
         case 4: return hyb_driver<4, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
         case 5: return hyb_driver<5, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
         case 6: return hyb_driver<6, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
@@ -1485,7 +1511,7 @@ hipError_t PMX_HYB_NAME(squeeze)(const DevConfig &c, uint32_t t, uint64_t *state
 // pmx_ctx_engine_info for the hybrid family: the very conditions of the launchers above
 hipError_t PMX_HYB_NAME(describe)(const DevConfig &c, uint32_t t, int op, size_t len, EngineInfo *o) {
     const bool driver = op == PMX_OP_ABSORB || op == PMX_OP_SQUEEZE;
-    const bool passes = driver && (int)t >= PMX_HYB_PASS_MIN_T;
+    const bool passes = driver && ((int)t >= PMX_HYB_PASS_MIN_T || t == 3);   // (t = 3 comes here only for its pass driver: t3_mfma)
     hipError_t e = hipErrorInvalidValue;
     const int op_engine = passes ? PMX_OP_PERMUTE : op;        // a pass is the permutation engine's launch
     auto plain = [&]() -> hipError_t { PMX_HYB_DISPATCH(describe(c, t, op_engine, len, o)); };
@@ -1586,14 +1612,27 @@ static bool quad_shape(const DevConfig &c, uint32_t t) { return quad_table(c, t)
         return hipGetLastError();                                                                                           \
     } while (0)
 
+// t = 3 on the matrix cores as well (round 4): HybridEngine<3, 5, mfma, windows of 3> - the dense layers and the partial rounds'
+// linear part as int8 GEMM layers, 40,9xx instead of 53 k VALU instructions per permutation - for alpha = 5, configs that have the
+// tables (modulus rule of pmx_mfma.hpp) and launches that fill the device (the engine runs four-wave workgroups with a shared
+// table tile; below PMX_T3_MFMA_MIN units the register engine's lower latency wins).  permute, hash, compress, and the absorb /
+// squeeze drivers as passes on that engine (like the wider states); smaller calls keep the register engine's kernels.
+#ifndef PMX_T3_MFMA_MIN
+#define PMX_T3_MFMA_MIN ((size_t)1 << 17)
+#endif
+static bool t3_mfma(const DevConfig &c, uint32_t t, size_t n) {
+    return PMX_MFMA_MIN_T <= 3 && t == 3 && c.has_opt && c.mfma_dense && c.rounds.alpha == 5 && n >= PMX_T3_MFMA_MIN;
+}
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
     if (quad_table(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(permute_quad_kernel, states, n);
+    if (t3_mfma(c, t, n)) return hybrid5_permute(c, t, states, n, st);
     PMX_SMALL_BATCH(kTabMinPermute, permute(c, t, states, n, st));
     PMX_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                        size_t n, hipStream_t st) {
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(hash_quad_kernel, in, in_len, out, out_len, n);
+    if (t3_mfma(c, t, n)) return hybrid5_hash(c, t, in, in_len, out, out_len, n, st);
     PMX_SMALL_BATCH(kTabMinPermute, hash(c, t, in, in_len, out, out_len, n, st));
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
@@ -1620,6 +1659,7 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
         if (c.rounds.alpha == 17) return launch_compress_coop<17>(c, in, out, n, st);
         return launch_compress_coop<0>(c, in, out, n, st);
     }
+    if (t3_mfma(c, t, n)) return hybrid5_compress(c, t, in, out, n, st);
     PMX_SMALL_BATCH(kTabMinCompress, compress(c, t, in, out, n, st));
     PMX_DISPATCH(compress(c, t, in, out, n, st));
 }
@@ -1627,12 +1667,14 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st, const PassScratch &scratch) {
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(absorb_quad_kernel, states, tag, index, in, in_len, n);
+    if (t3_mfma(c, t, n)) return hybrid5_absorb(c, t, states, tag, index, in, in_len, n, st, scratch);
     PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
     PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
 }
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st, const PassScratch &scratch) {
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
+    if (t3_mfma(c, t, n)) return hybrid5_squeeze(c, t, states, tag, index, out, out_len, n, st, scratch);
     PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
 }
@@ -1653,16 +1695,19 @@ hipError_t describe_launch(const DevConfig &c, uint32_t t, int op, size_t n, siz
     switch (op) {
         case PMX_OP_PERMUTE:
             if (quad_table(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) return describe_quad(c, o);
+            if (t3_mfma(c, t, n)) return hybrid5_describe(c, t, op, len, o);
             PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
             break;
         case PMX_OP_HASH:
         case PMX_OP_ABSORB:
         case PMX_OP_SQUEEZE:
             if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) return describe_quad(c, o);
+            if (t3_mfma(c, t, n)) return hybrid5_describe(c, t, op, len, o);
             PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
             break;
         case PMX_OP_COMPRESS:
             if (quad_shape(c, t) && n <= kCoopMaxUnits) return describe_quad(c, o);
+            if (t3_mfma(c, t, n)) return hybrid5_describe(c, t, op, len, o);
             PMX_SMALL_BATCH(kTabMinCompress, describe(c, t, op, len, o));
             break;
         default:

@@ -6,7 +6,7 @@
 //
 //   * every element z_j (nine 29-bit limbs, value < 2^261 < 2^264) is re-cut into 33 bytes u_{j,b}; an element takes 36
 //     bytes of K (9 words, the top three bytes zero), the state t * 36, in k-steps of 32;
-//   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 58) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
+//   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 29) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
 //     (pmx_prepare.hpp: put_mfma_layer; the modulus' top byte must be <= 126 for 32 of them to do), laid out as the A
 //     operand: 16 bytes per lane and k-step, lane l = row e (l & 31) and half (l >> 5) of the k-step;
 //   * MFMA bytes are signed, state bytes are not: they enter as u - 128 (one v_xor per register) and the host adds the
@@ -16,8 +16,8 @@
 //     half of its byte registers its partner lane (+-32) must feed to that partner (v_permlane32_swap, once per layer);
 //     afterwards the 32 sums of a state sit half on its own lane and half on the partner: sixteen more swaps per row;
 //   * the 32 sums S_e (|S_e| < 2^25) are the integer V = sum_e S_e 2^(8e) = sum u Y < 2^272: eight 64-bit word sums, a
-//     carry pass, a re-cut into ten 29-bit limbs and two Montgomery steps (division by 2^58, which the table carries)
-//     give the row as a norm element below (1 + 2^-40) p - 20 multiplies instead of 810.
+//     carry pass, a re-cut into ten 29-bit limbs and ONE Montgomery step (division by 2^29, which the table carries: round 3
+//     took two, but V / 2^29 + p already fits nine limbs) give the row below 2^243 + p - 9 multiplies instead of 810.
 //
 // The 11 KiB of table one row of t = 9 needs pass through an LDS tile once per WORKGROUP, in stages (read per wave from L2 they
 // are 101 KiB per wave and layer and the L2 -> L1 path sets the time), which is why the engines that use this run several waves
@@ -32,12 +32,13 @@ namespace pmx {
 // Widths whose dense layers go to the matrix cores.  A row costs ~155 VALU instructions of finish plus its share of the state's
 // re-cut (26 per element) and 2 x ceil(36 t / 32) MFMA issue slots, against 81 t + 81 multiplies and their carries on the VALU.
 #ifndef PMX_MFMA_MIN_T
-#define PMX_MFMA_MIN_T 7
+#define PMX_MFMA_MIN_T 3
 #endif
 #ifndef PMX_MFMA_MAX_T
 #define PMX_MFMA_MAX_T 9
 #endif
 constexpr int kMfmaElemBytes = 36;   // K bytes per element (33 used)
+constexpr int kMfmaShift = 29;       // the tables hold c 2^(8 b + kMfmaShift): the row finish divides by 2^29 (one Montgomery step)
 PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32; }
 PMX_FN constexpr int mfma_row_words(int t) { return mfma_k_steps(t) * 64 * 4; }             // A operand of one output row
 PMX_FN constexpr int mfma_layer_words(int t) { return t * mfma_row_words(t) + t * 16; }     // t rows, then t x 8 int64 corrections
@@ -54,7 +55,7 @@ PMX_FN constexpr int mfma_layer_words_io(int n_in, int n_out) { return n_out * m
 #define PMX_MFMA_WINDOW 6
 #endif
 #ifndef PMX_MFMA_WINDOW_MIN_T
-#define PMX_MFMA_WINDOW_MIN_T 7
+#define PMX_MFMA_WINDOW_MIN_T 3
 #endif
 // window size of a width (0: its partial rounds keep their sparse layers on the VALU)
 PMX_FN constexpr int mfma_window_for(int t) {
@@ -85,7 +86,7 @@ PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
 }
 
 // One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's
-// correction, as eight 64-bit word sums with carries, re-cut into ten 29-bit limbs, two Montgomery steps: V 2^-58 mod p, norm.
+// correction, as eight 64-bit word sums with carries, re-cut into ten 29-bit limbs, one Montgomery step: V 2^-29 mod p, below 2^243 + p.
 PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
     uint32_t wd[9];
     // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from a
@@ -112,22 +113,17 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
         if (wi + 1 < 9) pair |= (uint64_t)wd[wi + 1] << 32;
         L[k] = (uint32_t)(pair >> sh) & kMask;
     }
+    // ONE Montgomery step: V < 2^272, so (V + m p) / 2^29 < 2^243 + p already fits nine limbs (the table carries the 2^29)
     uint64_t acc = L[0];
     const uint32_t m0 = ((uint32_t)acc * f.pinv) & kMask;
     acc += (uint64_t)m0 * f.p[0];
     acc >>= kW;
-    acc += L[1];
-    acc += (uint64_t)m0 * f.p[1];
-    const uint32_t m1 = ((uint32_t)acc * f.pinv) & kMask;
-    acc += (uint64_t)m1 * f.p[0];
-    acc >>= kW;
     Fe row;
 #pragma unroll
-    for (int k = 2; k <= 10; ++k) {
-        if (k < 10) acc += L[k];
+    for (int k = 1; k <= 9; ++k) {
+        acc += L[k];
         if (k <= 8) acc += (uint64_t)m0 * f.p[k];
-        if (k - 1 <= 8) acc += (uint64_t)m1 * f.p[k - 1];
-        row.l[k - 2] = k < 10 ? ((uint32_t)acc & kMask) : (uint32_t)acc;
+        row.l[k - 1] = k < 9 ? ((uint32_t)acc & kMask) : (uint32_t)acc;
         acc >>= kW;
     }
     return row;

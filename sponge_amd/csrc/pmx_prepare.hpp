@@ -66,7 +66,7 @@ struct Prepared {
 };
 
 // One dense layer as the A operands of pmx_mfma.hpp: `rows` = t rows of t constants (ABI Montgomery residues, row-major).
-// Row i, k-step q, lane l: 16 bytes = bytes e = l & 31 of the residues  Y = c_ij * 2^(8 b + 58) mod p  for the 16 positions
+// Row i, k-step q, lane l: 16 bytes = bytes e = l & 31 of the residues  Y = c_ij * 2^(8 b + 29) mod p  for the 16 positions
 // k = 32 q + 16 (l >> 5) + 0..15 of the state's byte string (k = 36 j + b), as balanced signed bytes; then per row the eight
 // word sums of 128 * sum_k Y_k (the state's bytes enter as u - 128).
 // General form: n_out rows of n_in constants; aff (may be null): one constant per row added to the row's value.
@@ -77,7 +77,7 @@ inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in
     for (size_t i = 0; i < n_out; ++i) {
         long long colsum[32] = {0};
         for (size_t j = 0; j < n_in; ++j) {
-            U256 y = times_pow2(hf, hf.from_mont(rows[i * n_in + j]), 58);
+            U256 y = times_pow2(hf, hf.from_mont(rows[i * n_in + j]), kMfmaShift);
             for (size_t b = 0; b < 33; ++b) {
                 // balanced bytes of y: digit e in [-128, 127], carry into the next
                 unsigned carry = 0;
@@ -96,9 +96,9 @@ inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in
                 y = times_pow2(hf, y, 8);
             }
         }
-        // the row's constant in the units of V: its internal form (x 2^261) times the 2^58 the finish divides by
+        // the row's constant in the units of V: its internal form (x 2^261) times the 2^kMfmaShift the finish divides by
         U256 add = {{0, 0, 0, 0}};
-        if (aff) add = times_pow2(hf, hf.from_mont(aff[i]), 261 + 58);
+        if (aff) add = times_pow2(hf, hf.from_mont(aff[i]), 261 + kMfmaShift);
         for (size_t w = 0; w < 8; ++w) {
             long long v = 0;
             for (size_t tt = 0; tt < 4; ++tt) v += (128 * colsum[4 * w + tt]) * (1ll << (8 * tt));

@@ -144,7 +144,7 @@ static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
     }
 }
 
-// The matrix-core form of the wide hybrids (HybridEngine<7..9, alpha, true>): the same round loop with its dense layers - and the
+// The matrix-core form of the wide hybrids (HybridEngine<3..9, alpha, true>): the same round loop with its dense layers - and the
 // partial section as windows closed by one layer each (pmx_mfma.hpp: PMX_MFMA_WINDOW) - through pmx_mfma.hpp's tables, byte
 // strings and row finish; the GEMM itself as plain integer sums (no matrix cores on the host).
 template <int T>
@@ -179,6 +179,10 @@ extern "C" int hc_permute_hybrid_mfma(const pmx_config *cfg, uint64_t *states, s
     if (rc) return rc;
     if (!pp.has_opt || !pp.mfma_dense) return PMX_ERR_UNSUPPORTED;
     switch (pp.t) {
+        case 3: return permute_hybrid_mfma_t<3>(pp, states, n);
+        case 4: return permute_hybrid_mfma_t<4>(pp, states, n);
+        case 5: return permute_hybrid_mfma_t<5>(pp, states, n);
+        case 6: return permute_hybrid_mfma_t<6>(pp, states, n);
         case 7: return permute_hybrid_mfma_t<7>(pp, states, n);
         case 8: return permute_hybrid_mfma_t<8>(pp, states, n);
         case 9: return permute_hybrid_mfma_t<9>(pp, states, n);

@@ -25,9 +25,9 @@ CASES = [
     ("bls12_381_fr", None, 255, 6, 5, 8, 57, True),
     ("pallas_fp", PALLAS, 255, 8, 5, 8, 57, True),       # a third field on the matrix-core side of the modulus rule ...
     ("p25519", P25519, 255, 8, 5, 8, 57, False),         # ... and one on the other (top byte 127: VALU rows)
-    ("bls12_381_fr", None, 255, 5, 5, 8, 57, False),     # t = 6, 5, 4: passes on the VALU-row engines
-    ("bls12_381_fr", None, 255, 4, 5, 8, 56, False),
-    ("bls12_381_fr", None, 255, 3, 3, 8, 56, False),
+    ("bls12_381_fr", None, 255, 5, 5, 8, 57, True),      # t = 6, 5, 4: the matrix-core engines of the narrower hybrids
+    ("bls12_381_fr", None, 255, 4, 5, 8, 56, True),
+    ("bls12_381_fr", None, 255, 3, 3, 8, 56, True),
 ]
 
 
@@ -187,3 +187,77 @@ def test_a_call_longer_than_65536_rates_is_refused_not_launched():
     assert lib.pmx_sponge_absorb_batch_dev(h, dummy, dummy, dummy, dummy, 8 * 65536 + 9, 1, None) == _lib.PMX_ERR_ARG
     # the largest legal call shape is accepted by the check (n = 0: nothing is enqueued)
     assert lib.pmx_sponge_squeeze_batch_dev(h, None, None, None, None, 8 * 65536, 0, None) == _lib.PMX_OK
+
+
+def test_t3_device_filling_calls_run_on_the_matrix_core_engine_and_agree_with_the_register_engine():
+    """t = 3, alpha = 5 (BASELINE configs[1]'s shape): calls of at least 2^17 units run on HybridEngine<3,5,mfma,windows of 3> -
+    permute, hash, compress, and absorb / squeeze as passes -, smaller ones on the register engine (pmx_device.hip: t3_mfma).
+    pmx_ctx_engine_info says which; the SAME sponges through both sides of the threshold must agree limb for limb (the first
+    2^17 - 1 of them in a second call), and a sample of the large call - the first and the last workgroup in full, 1500 at
+    random - is checked against the C restatement sponge by sponge, in mixed modes, through absorbs and squeezes that take
+    zero, one, two and three permutations."""
+    from gpu_helpers import c_oracle, product_config
+    name = "bls_t3_a5_8_31"
+    cfg, cr = product_config(name), c_oracle(name)
+    f, t, r = cfg.field, 3, 2
+    big, small = (1 << 17) + 333, (1 << 17) - 1
+    for op in (_lib.OP_PERMUTE, _lib.OP_HASH, _lib.OP_COMPRESS, _lib.OP_ABSORB, _lib.OP_SQUEEZE):
+        hi, lo = _engine_info(cfg, op, big, 4), _engine_info(cfg, op, small, 4)
+        assert hi.engine.startswith(b"HybridEngine<3,5,mfma,windows of 3>") and hi.mfma_dense == 1 and hi.partial_window == 3, hi.engine
+        assert lo.engine.startswith(b"RegEngine<3,5") and lo.mfma_dense == 0 and lo.partial_window == 0, lo.engine
+        assert (b"passes" in hi.engine) == (op in (_lib.OP_ABSORB, _lib.OP_SQUEEZE))
+    rng = np.random.default_rng(33)
+    state0 = synth.random_elements(f, big * t, seed=91).reshape(big, t, 4)
+    tag0 = rng.integers(0, 2, big).astype(np.uint32)
+    idx0 = rng.integers(0, r + 1, big).astype(np.uint32)
+    sample = np.unique(np.concatenate([np.arange(256), np.arange(big - 333 - 256, big), rng.integers(0, big, 1500)]))
+
+    def run(n):
+        b = S.BatchPoseidonSponge.new(cfg, n)
+        b.state, b.mode_tag, b.mode_index = state0[:n].copy(), tag0[:n].copy(), idx0[:n].copy()
+        outs = []
+        for step, (op, length) in enumerate([("absorb", 3), ("squeeze", 2), ("absorb", 5), ("squeeze", 3), ("squeeze", 0), ("absorb", 2), ("squeeze", 1)]):
+            if op == "absorb":
+                elems = synth.random_elements(f, big * length, seed=200 + step).reshape(big, length, 4)[:n]
+                b.absorb(np.ascontiguousarray(elems))
+                outs.append(None)
+            else:
+                outs.append(b.squeeze_native_field_elements(length))
+        return b, outs
+
+    b_big, o_big = run(big)
+    b_small, o_small = run(small)
+    assert np.array_equal(b_big.state[:small], b_small.state) and np.array_equal(b_big.mode_tag[:small], b_small.mode_tag)
+    assert np.array_equal(b_big.mode_index[:small], b_small.mode_index)
+    for a, b in zip(o_big, o_small):
+        assert (a is None and b is None) or np.array_equal(a[:small], b)
+    # ... and the sample against the C restatement
+    ops = [("absorb", 3), ("squeeze", 2), ("absorb", 5), ("squeeze", 3), ("squeeze", 0), ("absorb", 2), ("squeeze", 1)]
+    for j in sample:
+        s, m, i = state0[j].copy(), int(tag0[j]), int(idx0[j])
+        for step, (op, length) in enumerate(ops):
+            if op == "absorb":
+                s, m, i = cr.sponge_absorb(s, m, i, _t3_elems(f, big, length, step)[j])
+            else:
+                s, m, i, o = cr.sponge_squeeze(s, m, i, length)
+                assert np.array_equal(o_big[step][j], o), (int(j), step)
+        assert np.array_equal(b_big.state[j], s) and int(b_big.mode_tag[j]) == m and int(b_big.mode_index[j]) == i, int(j)
+    # permute and hash across the threshold: the same rows through both engines
+    st = synth.random_elements(f, big * t, seed=92).reshape(big, t, 4)
+    ctx = cfg.context(0)
+    p_big, p_small = ctx.permute_batch(st), ctx.permute_batch(st[:small])
+    assert np.array_equal(p_big[:small], p_small)
+    assert np.array_equal(p_big[sample], cr.permute_batch(np.ascontiguousarray(st[sample]), threads=0))
+    msgs = synth.random_elements(f, big * 4, seed=93).reshape(big, 4, 4)
+    h_big, h_small = ctx.hash_batch(msgs, 4, 2), ctx.hash_batch(msgs[:small], 4, 2)
+    assert np.array_equal(h_big[:small], h_small)
+    assert np.array_equal(h_big[sample], cr.hash_batch(np.ascontiguousarray(msgs[sample]), 4, 2, threads=0))
+
+
+_T3_CACHE = {}
+
+
+def _t3_elems(f, big, length, step):
+    if step not in _T3_CACHE:
+        _T3_CACHE[step] = synth.random_elements(f, big * length, seed=200 + step).reshape(big, length, 4)
+    return _T3_CACHE[step]

@@ -182,7 +182,7 @@ def test_permutation_templates_match_golden(hc, name):
     if cfg.t == 3:
         out = run_permute(hc, name, states, coop=True)  # three-lanes-per-state schedule (small Merkle levels)
         assert cref.limbs_to_elems(out, cfg.p) == want, "coop"
-    if cfg.t == 9:
+    if cfg.t in (3, 4, 9) and cfg.alpha in (5, 17):
         out = run_permute(hc, name, states, mfma=True)  # dense layers as the matrix-core engine computes them (pmx_mfma.hpp)
         assert cref.limbs_to_elems(out, cfg.p) == want, "hybrid, dense layers on the int8 tables"
 
@@ -360,20 +360,22 @@ def test_matrix_core_tables_only_for_moduli_whose_residues_fit_32_balanced_bytes
 
 @pytest.mark.parametrize("K", [6, 1, 4, 9])
 def test_partial_rounds_as_windows_every_size_and_width(K):
-    """pmx_mfma.hpp / pmx_prepare.hpp (derive_window_layers): the matrix-core engines of t = 7..9 run their partial rounds as windows
+    """pmx_mfma.hpp / pmx_prepare.hpp (derive_window_layers): the matrix-core engines of t = 3..9 run their partial rounds as windows
     of K S-boxes closed by ONE layer each - an exact rewrite derived on the host (basis of the carried lanes chosen so that later
     S-box inputs are sums of an earlier output, a carried coordinate and K - 2 products at most; the first window takes RP mod K).
     Host build of the same templates and tables against the big-integer oracle: the shipped size 6 (57 = 3 + 9 x 6), 1 (every
-    round its own window), 4 (first window of ONE round), 9 = t (first window of 3; at t = 7, 8 clamped to t); t = 7, 8, 9;
+    round its own window), 4 (first window of ONE round), 9 = t (first window of 3; at t = 7, 8 clamped to t); t = 3 .. 9;
     RP = 57, 56, 5, 1; alpha = 5 and the generic-exponent build; both fields of BASELINE."""
     name = "libpmx_hostcheck.so" if K == 6 else "libpmx_hostcheck_k%d.so" % K
     subprocess.check_call(["make", "-C", HERE, name], stdout=subprocess.DEVNULL)
     hc = ctypes.CDLL(os.path.join(HERE, name))
     hc.hc_permute_hybrid_mfma.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
-    assert hc.hc_mfma_window(9) == K and hc.hc_mfma_window(7) == min(K, 7) and hc.hc_mfma_window(6) == 0
+    assert hc.hc_mfma_window(9) == K and hc.hc_mfma_window(7) == min(K, 7) and hc.hc_mfma_window(4) == min(K, 4) and hc.hc_mfma_window(3) == min(K, 3) and hc.hc_mfma_window(2) == 0
     cases = [(O.BN254_FR, 254, 8, 5, 8, 57), (O.BLS12_381_FR, 255, 8, 5, 8, 57), (O.BLS12_381_FR, 255, 7, 5, 8, 57),
              (O.BLS12_381_FR, 255, 6, 5, 8, 57), (O.BLS12_381_FR, 255, 8, 17, 8, 56), (O.BN254_FR, 254, 6, 3, 6, 5),
-             (O.BLS12_381_FR, 255, 7, 5, 3, 1)]
+             (O.BLS12_381_FR, 255, 7, 5, 3, 1), (O.BLS12_381_FR, 255, 5, 5, 8, 57), (O.BLS12_381_FR, 255, 4, 5, 8, 56),
+             (O.BLS12_381_FR, 255, 3, 5, 8, 56), (O.BN254_FR, 254, 3, 17, 8, 5), (O.BLS12_381_FR, 255, 2, 5, 8, 31),
+             (O.BN254_FR, 254, 2, 5, 8, 57), (O.BLS12_381_FR, 255, 2, 5, 3, 2)]
     for p, bits, rate, alpha, rf, rp in cases:
         t = rate + 1
         cfg = O.make_config(p, bits, rate, alpha, rf, rp)

@@ -11,7 +11,12 @@ mkdir -p $B
 HIPCC=/opt/rocm/bin/hipcc
 FLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter --offload-arch=gfx950 -DPMX_MFMA_WINDOW=$K $EXTRA"
 $HIPCC $FLAGS -mllvm -opt-disable=reassociate -DPMX_TU=1 -c $C/pmx_device.hip -o $B/pmx_device_1.o &
+TU0=$C/build/pmx_device.o
+if [ "${WITH_TU0:-0}" = "1" ]; then   # the public launchers as well (routing experiments)
+  $HIPCC $FLAGS -mllvm -opt-disable=reassociate -DPMX_TU=0 -c $C/pmx_device.hip -o $B/pmx_device_0.o &
+  TU0=$B/pmx_device_0.o
+fi
 $HIPCC $FLAGS -x hip -c $C/pmx_api.cpp -o $B/pmx_api.o &
 wait
-$HIPCC -shared -fPIC --offload-arch=gfx950 $C/build/pmx_device.o $B/pmx_device_1.o $C/build/pmx_device_hybg.o $B/pmx_api.o $C/build/pmx_mgpu.o $C/build/pmx_diag.o $C/build/pmx_params.o -ldl -o $R/tools/ab/libposeidon_$NAME.so
+$HIPCC -shared -fPIC --offload-arch=gfx950 $TU0 $B/pmx_device_1.o $C/build/pmx_device_hybg.o $B/pmx_api.o $C/build/pmx_mgpu.o $C/build/pmx_diag.o $C/build/pmx_params.o -ldl -o $R/tools/ab/libposeidon_$NAME.so
 ls -la $R/tools/ab/libposeidon_$NAME.so
