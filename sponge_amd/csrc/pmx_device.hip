@@ -239,7 +239,7 @@ struct RegEngine {
                                 // when left alone) is +6 % when held to 168; t = 7, 8, 9 spill and lose 23 / 46 / 68 % (round 3 A/B)
 #endif
 #ifndef PMX_MFMA_4WAVE_MAX_T   // the same bounds for the matrix-core engines of the narrow widths (their byte strings and sums want registers)
-#define PMX_MFMA_4WAVE_MAX_T 3
+#define PMX_MFMA_4WAVE_MAX_T 2
 #endif
 #ifndef PMX_MFMA_3WAVE_MAX_T
 #define PMX_MFMA_3WAVE_MAX_T 5

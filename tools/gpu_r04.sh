@@ -80,15 +80,15 @@ fi
 cd $R
 if has slots; then
   J=$OUT/valu_instructions.json; rm -f $J
-  python tools/valu_count.py $OUT/slots_c2 permute_kernel c2 1048576 "RegEngine<3,5,opt,tab>" 4 $J "profiles/r04" > $OUT/valu_count.log 2>&1
-  python tools/valu_count.py $OUT/slots_c3 permute_kernel c3 262144 "HybridEngine<9,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
-  python tools/valu_count.py $OUT/slots_w4 permute_kernel w4 524288 "HybridEngine<4,5,valu>" 4 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
-  python tools/valu_count.py $OUT/slots_w5 permute_kernel w5 524288 "HybridEngine<5,5,valu>" 3 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
-  python tools/valu_count.py $OUT/slots_w6 permute_kernel w6 262144 "HybridEngine<6,5,valu>" 3 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
-  python tools/valu_count.py $OUT/slots_w7 permute_kernel w7 262144 "HybridEngine<7,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
-  python tools/valu_count.py $OUT/slots_w8 permute_kernel w8 262144 "HybridEngine<8,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
-  python tools/valu_count.py $OUT/slots_h3 hash_kernel h3 2097152 "RegEngine<3,5,opt,tab>" 4 $J "profiles/r04" 2 >> $OUT/valu_count.log 2>&1
-  python tools/valu_count.py $OUT/slots_h9 hash_kernel h9 262144 "HybridEngine<9,5,mfma>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_c2 permute_kernel c2 1048576 "HybridEngine<3,5,mfma,windows of 3>" 3 $J "profiles/r04" > $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_c3 permute_kernel c3 262144 "HybridEngine<9,5,mfma,windows of 6>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w4 permute_kernel w4 524288 "HybridEngine<4,5,mfma,windows of 4>" 3 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w5 permute_kernel w5 524288 "HybridEngine<5,5,mfma,windows of 5>" 3 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w6 permute_kernel w6 262144 "HybridEngine<6,5,mfma,windows of 6>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w7 permute_kernel w7 262144 "HybridEngine<7,5,mfma,windows of 6>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_w8 permute_kernel w8 262144 "HybridEngine<8,5,mfma,windows of 6>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_h3 hash_kernel h3 2097152 "HybridEngine<3,5,mfma,windows of 3>" 3 $J "profiles/r04" 2 >> $OUT/valu_count.log 2>&1
+  python tools/valu_count.py $OUT/slots_h9 hash_kernel h9 262144 "HybridEngine<9,5,mfma,windows of 6>" 2 $J "profiles/r04" >> $OUT/valu_count.log 2>&1
   cat $OUT/valu_count.log
 fi
 if has pmc; then
