@@ -152,7 +152,7 @@ typedef struct pmx_engine_info {
     int row_tables;      /* 1: t-term matrix rows consume shifted tables (81 t + 18 multiplies), 0: element form (81 t + 81) */
     int lane_tables;     /* 1: identity-lane updates of the sparse layers consume shifted tables */
     int mfma_dense;      /* 1: rows of the dense layers come from the matrix cores (int8 GEMM, pmx_mfma.hpp) */
-    int launches;        /* kernel launches of the call: 1, or the passes of an absorb / squeeze call on wide states */
+    int launches;        /* kernel launches of the call: 1, or the passes of an absorb / squeeze call on wide states (and on device-filling t = 3 calls) */
     int partial_window;  /* K > 0: the partial rounds run as windows of K S-boxes, each closed by ONE layer on the matrix cores
                             (no sparse layers on the VALU); 0: one sparse layer per partial round */
 } pmx_engine_info;
@@ -180,7 +180,7 @@ int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64
  * absorb: CryptographicSponge::absorb for in_len native elements per sponge (mod.rs:232-254, 121-150).
  * squeeze: FieldBasedCryptographicSponge::squeeze_native_field_elements(out_len) (mod.rs:321-341,
  * 153-182, including the `!= rate` test of :175).  Sponges in one call may be in different modes.
- * Widths 4..9 run a call as PASSES on the permutation engine of the width (one launch per permutation a sponge of the
+ * Widths 4..9 (and width 3 from 2^17 sponges up, alpha = 5) run a call as PASSES on the permutation engine of the width (one launch per permutation a sponge of the
  * batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would permute it); the pass
  * lists of the _dev variants live in a block the context keeps per caller stream (calls on different streams stay
  * independent; concurrent calls of ONE context serialise while they enqueue); there a call moves at most 65536 rates of
