@@ -32,9 +32,9 @@
 #include "pmx_permute.hpp"
 #include "pmx_sponge_plan.hpp"
 
-// The file is compiled three times (Makefile, in parallel): PMX_TU = 0 holds the t = 3 engine, the run-time-width
-// engine, the cooperative kernel and the public launchers; PMX_TU = 1 / 2 hold the hybrid engines for alpha = 5 and
-// for the generic S-box (6 widths x 5 kernels each - by far the longest compile).
+// The file is compiled five times (Makefile, in parallel): PMX_TU = 0 holds the t = 3 register engine, the run-time-width
+// engine, the cooperative kernel and the public launchers; PMX_TU = 1 / 3 hold the hybrid engines for alpha = 5 (widths up to 6 /
+// from 7), PMX_TU = 2 / 4 the same for the generic S-box (each width x {VALU rows, matrix cores} x 7 kernels - by far the longest compile).
 #ifndef PMX_TU
 #define PMX_TU 0
 #endif
@@ -253,6 +253,9 @@ struct RegEngine {
 #ifndef PMX_MFMA_WAVES
 #define PMX_MFMA_WAVES 4        // waves per workgroup of the matrix-core engines, and
 #endif
+#ifndef PMX_MFMA_TILE_WINDOWS
+#define PMX_MFMA_TILE_WINDOWS 0
+#endif
 #ifndef PMX_MFMA_TILE_STEPS
 #define PMX_MFMA_TILE_STEPS 6   // k-steps (KiB) of a row's table in LDS at a time.  At t = 9 (8 x 18 KiB of scratch per CU) that
                                 // is two workgroups of four waves per CU with a 6 KiB tile each - their phases drift apart, so one's
@@ -303,7 +306,10 @@ struct HybridEngine {
     // the stage of a row's table the workgroup shares, behind the waves' regions
     // (a whole row where two workgroups per CU still fit - t = 7: 8 KiB, t = 8: 9 KiB -, PMX_MFMA_TILE_STEPS at t = 9)
     static constexpr int kTileFit = (int)((80 * 1024 - PMX_MFMA_WAVES * kWaveBytes) / 1024);
-    static constexpr int kTileSteps = mfma_k_steps(T) <= kTileFit ? mfma_k_steps(T) : PMX_MFMA_TILE_STEPS;
+    // (PMX_MFMA_TILE_WINDOWS: sized for the window layers' longer rows - t - 1 + K elements - as well, and as large as still fits)
+    static constexpr int kWinSteps = (MFMA && mfma_window_for(T) > 0) ? mfma_k_steps(T - 1 + mfma_window_for(T)) : 0;
+    static constexpr int kNeedSteps = (PMX_MFMA_TILE_WINDOWS && kWinSteps > mfma_k_steps(T)) ? kWinSteps : mfma_k_steps(T);
+    static constexpr int kTileSteps = kNeedSteps <= kTileFit ? kNeedSteps : ((PMX_MFMA_TILE_WINDOWS && kTileFit > PMX_MFMA_TILE_STEPS) ? kTileFit : PMX_MFMA_TILE_STEPS);
     static constexpr size_t kTileBytes = MFMA ? (size_t)kTileSteps * 1024 : 0;
     static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes + kTileBytes; }
 
@@ -1401,23 +1407,44 @@ struct Launch {
 
 #if PMX_TU != 0
 // ---- hybrid family of this translation unit -------------------------------------------------------------------------
-#if PMX_TU == 1
+// four translation units (they dominate the build time, so they compile in parallel): the exponent (1, 3: alpha = 5; 2, 4: any other) x the
+// widths (1, 2: t <= 6; 3, 4: t = 7..9).  The public launchers of TU 0 pick the half by t.
+#if PMX_TU == 1 || PMX_TU == 3
 #define PMX_HYB_ALPHA 5
-#define PMX_HYB_NAME(op) hybrid5_##op
 #else
 #define PMX_HYB_ALPHA 0
-#define PMX_HYB_NAME(op) hybridg_##op
 #endif
+#if PMX_TU == 1 || PMX_TU == 2
+#define PMX_HYB_NARROW 1
+#else
+#define PMX_HYB_NARROW 0
+#endif
+#if PMX_TU == 1
+#define PMX_HYB_NAME(op) hybrid5n_##op
+#elif PMX_TU == 3
+#define PMX_HYB_NAME(op) hybrid5w_##op
+#elif PMX_TU == 2
+#define PMX_HYB_NAME(op) hybridgn_##op
+#else
+#define PMX_HYB_NAME(op) hybridgw_##op
+#endif
+#if PMX_HYB_NARROW
 #define PMX_HYB_DISPATCH(CALL)                                             \
     switch (t) {                                                           \
         case 4: return Launch<HybridEngine<4, PMX_HYB_ALPHA>>::CALL;       \
         case 5: return Launch<HybridEngine<5, PMX_HYB_ALPHA>>::CALL;       \
         case 6: return Launch<HybridEngine<6, PMX_HYB_ALPHA>>::CALL;       \
+        default: return hipErrorInvalidValue;                              \
+    }
+#else
+#define PMX_HYB_DISPATCH(CALL)                                             \
+    switch (t) {                                                           \
         case 7: return Launch<HybridEngine<7, PMX_HYB_ALPHA>>::CALL;       \
         case 8: return Launch<HybridEngine<8, PMX_HYB_ALPHA>>::CALL;       \
         case 9: return Launch<HybridEngine<9, PMX_HYB_ALPHA>>::CALL;       \
         default: return hipErrorInvalidValue;                              \
     }
+#endif
 
 template <class Engine>
 static bool lds_fits_engine(const DevConfig &c, uint32_t t) { return Engine::lds_bytes(c, t) <= (size_t)c.max_lds_bytes; }
@@ -1425,24 +1452,23 @@ static bool lds_fits_engine(const DevConfig &c, uint32_t t) { return Engine::lds
 #define PMX_HYB_MFMA_CASE(W, CALL)                                                                      \
     if (t == W && W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T && lds_fits_engine<HybridEngine<W, PMX_HYB_ALPHA, true>>(c, t)) \
         return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::CALL;
-#if PMX_MFMA_MIN_T <= 3 && PMX_TU == 1   // t = 3, alpha = 5: large batches of permute / hash / compress (t3_mfma below)
-#define PMX_HYB_MFMA_NARROW(CALL) PMX_HYB_MFMA_CASE(3, CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
+#if !PMX_HYB_NARROW
+#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(7, CALL) PMX_HYB_MFMA_CASE(8, CALL) PMX_HYB_MFMA_CASE(9, CALL)
+#elif PMX_MFMA_MIN_T <= 3 && PMX_TU == 1   // t = 3, alpha = 5: device-filling launches (t3_mfma below)
+#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(3, CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
 #elif PMX_MFMA_MIN_T <= 4
-#define PMX_HYB_MFMA_NARROW(CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
+#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
 #elif PMX_MFMA_MIN_T <= 5
-#define PMX_HYB_MFMA_NARROW(CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
+#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
 #elif PMX_MFMA_MIN_T <= 6
-#define PMX_HYB_MFMA_NARROW(CALL) PMX_HYB_MFMA_CASE(6, CALL)
+#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(6, CALL)
 #else
-#define PMX_HYB_MFMA_NARROW(CALL)
+#define PMX_HYB_MFMA_WIDTHS(CALL)
 #endif
 #define PMX_HYB_MFMA(CALL)               \
     do {                                 \
         if (c.mfma_dense) {              \
-            PMX_HYB_MFMA_NARROW(CALL)    \
-            PMX_HYB_MFMA_CASE(7, CALL)   \
-            PMX_HYB_MFMA_CASE(8, CALL)   \
-            PMX_HYB_MFMA_CASE(9, CALL)   \
+            PMX_HYB_MFMA_WIDTHS(CALL)    \
         }                                \
     } while (0)
 hipError_t PMX_HYB_NAME(permute)(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
@@ -1489,17 +1515,24 @@ static hipError_t hyb_driver(const DevConfig &c, uint32_t t, uint64_t *states, u
 #else
 #define PMX_HYB_DRIVER_T3(SQ, IO)
 #endif
+#if PMX_HYB_NARROW
 #define PMX_HYB_DRIVER(SQ, IO)                                                     \
     switch (t) {                                                                   \
         PMX_HYB_DRIVER_T3(SQ, IO)                                                  \
         case 4: return hyb_driver<4, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
         case 5: return hyb_driver<5, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
         case 6: return hyb_driver<6, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
+        default: return hipErrorInvalidValue;                                      \
+    }
+#else
+#define PMX_HYB_DRIVER(SQ, IO)                                                     \
+    switch (t) {                                                                   \
         case 7: return hyb_driver<7, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
         case 8: return hyb_driver<8, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
         case 9: return hyb_driver<9, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
         default: return hipErrorInvalidValue;                                      \
     }
+#endif
 hipError_t PMX_HYB_NAME(absorb)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                                 const uint64_t *in, size_t len, size_t n, hipStream_t st, const PassScratch &scratch) {
     PMX_HYB_DRIVER(false, const_cast<uint64_t *>(in));   // (the absorb form of the pass kernel only reads `io`)
@@ -1536,8 +1569,34 @@ hipError_t PMX_HYB_NAME(describe)(const DevConfig &c, uint32_t t, int op, size_t
     hipError_t P##absorb(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, const uint64_t *, size_t, size_t, hipStream_t, const PassScratch &); \
     hipError_t P##squeeze(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint64_t *, size_t, size_t, hipStream_t, const PassScratch &); \
     hipError_t P##describe(const DevConfig &, uint32_t, int, size_t, EngineInfo *);
-PMX_HYB_DECL(hybrid5_)
-PMX_HYB_DECL(hybridg_)
+PMX_HYB_DECL(hybrid5n_)
+PMX_HYB_DECL(hybrid5w_)
+PMX_HYB_DECL(hybridgn_)
+PMX_HYB_DECL(hybridgw_)
+// the half of the hybrid family a width lives in (t <= 6 / t >= 7)
+#define PMX_HYB_HALVES(P)                                                                                                                    \
+    static hipError_t P##_permute(const DevConfig &c, uint32_t t, uint64_t *s, size_t n, hipStream_t st) {                                    \
+        return t <= 6 ? P##n_permute(c, t, s, n, st) : P##w_permute(c, t, s, n, st);                                                          \
+    }                                                                                                                                        \
+    static hipError_t P##_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t il, uint64_t *out, size_t ol, size_t n, hipStream_t st) { \
+        return t <= 6 ? P##n_hash(c, t, in, il, out, ol, n, st) : P##w_hash(c, t, in, il, out, ol, n, st);                                    \
+    }                                                                                                                                        \
+    static hipError_t P##_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {             \
+        return t <= 6 ? P##n_compress(c, t, in, out, n, st) : P##w_compress(c, t, in, out, n, st);                                            \
+    }                                                                                                                                        \
+    static hipError_t P##_absorb(const DevConfig &c, uint32_t t, uint64_t *s, uint32_t *tag, uint32_t *idx, const uint64_t *in, size_t len,   \
+                                 size_t n, hipStream_t st, const PassScratch &sc) {                                                           \
+        return t <= 6 ? P##n_absorb(c, t, s, tag, idx, in, len, n, st, sc) : P##w_absorb(c, t, s, tag, idx, in, len, n, st, sc);              \
+    }                                                                                                                                        \
+    static hipError_t P##_squeeze(const DevConfig &c, uint32_t t, uint64_t *s, uint32_t *tag, uint32_t *idx, uint64_t *out, size_t len,       \
+                                  size_t n, hipStream_t st, const PassScratch &sc) {                                                          \
+        return t <= 6 ? P##n_squeeze(c, t, s, tag, idx, out, len, n, st, sc) : P##w_squeeze(c, t, s, tag, idx, out, len, n, st, sc);          \
+    }                                                                                                                                        \
+    static hipError_t P##_describe(const DevConfig &c, uint32_t t, int op, size_t len, EngineInfo *o) {                                       \
+        return t <= 6 ? P##n_describe(c, t, op, len, o) : P##w_describe(c, t, op, len, o);                                                    \
+    }
+PMX_HYB_HALVES(hybrid5)
+PMX_HYB_HALVES(hybridg)
 
 // Engine choice: width 3 runs from registers, on the optimised schedule whenever its tables exist - with the matrices
 // as shifted tables (permute_opt_tab) for the two exponents that have a dedicated chain - (the dense schedule
