@@ -254,7 +254,7 @@ struct RegEngine {
 #define PMX_MFMA_WAVES 4        // waves per workgroup of the matrix-core engines, and
 #endif
 #ifndef PMX_MFMA_TILE_WINDOWS
-#define PMX_MFMA_TILE_WINDOWS 0
+#define PMX_MFMA_TILE_WINDOWS 1
 #endif
 #ifndef PMX_MFMA_TILE_STEPS
 #define PMX_MFMA_TILE_STEPS 6   // k-steps (KiB) of a row's table in LDS at a time.  At t = 9 (8 x 18 KiB of scratch per CU) that
