@@ -1237,8 +1237,18 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     const size_t gid = (size_t)blockIdx.x * Engine::kThreads + threadIdx.x;
     const uint32_t *p32 = consts + d.io_offset + kIoP32;   // the modulus as 8 x 32-bit limbs (wave-uniform: scalar loads)
     const bool due = sponge_walk<SQUEEZE>(d.rounds, p32, states, mode_tag, mode_index, io, len, gid, gid < n, 0, last_pass);
-    if (!__syncthreads_or(due ? 1 : 0)) return;
     const uint64_t due_mask = __builtin_amdgcn_ballot_w64(due);       // wave-uniform: the only thing live across the permutation
+    {   // workgroup vote through the first word of the DYNAMIC LDS (free until the engine is built): __syncthreads_or keeps a static
+        // word of its own, and at t = 9 the engine's 80 KiB are exactly half a CU - one word more and one workgroup fits instead of two
+        uint32_t *flag = reinterpret_cast<uint32_t *>(pmx_lds);
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        if (due_mask != 0 && (threadIdx.x & 63) == 0) *flag = 1;   // (every writer writes the same value)
+        __syncthreads();
+        const bool any = *flag != 0;
+        __syncthreads();
+        if (!any) return;
+    }
     {
         Engine e(d, consts);
         typename Engine::AbsorbAdjust add{nullptr, p32, 0, 0};
