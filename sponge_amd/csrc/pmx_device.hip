@@ -247,14 +247,16 @@ struct RegEngine {
 #ifndef PMX_HYB_4WAVE_MAX_T
 #define PMX_HYB_4WAVE_MAX_T 4   // t = 4 (133 VGPRs when left alone) held to 128: four waves per SIMD, +3.8 % (round 3 A/B)
 #endif
-// MFMA: the dense layers run on the matrix cores (pmx_mfma.hpp); the PMX_MFMA_WAVES waves of a workgroup share one LDS tile of the
-// layer's table rows - the wave-uniform kernels only (permute, hash, compress: inside the per-lane loops of absorb / squeeze not every
-// lane is active, and the lane exchange of that path needs both lanes of a pair).
+// MFMA: every product by a constant runs on the matrix cores (pmx_mfma.hpp) - the dense layers and, as windows of up to six S-boxes
+// per layer, the linear part of the partial rounds; the PMX_MFMA_WAVES waves of a workgroup share one LDS tile of the layer's table
+// rows.  Wave-uniform kernels only (permute, hash, compress, and the passes of the absorb / squeeze driver, which ARE permutation
+// launches: inside a per-lane loop not every lane is active, and the lane exchange of this path needs both lanes of a pair).
 #ifndef PMX_MFMA_WAVES
 #define PMX_MFMA_WAVES 4        // waves per workgroup of the matrix-core engines, and
 #endif
 #ifndef PMX_MFMA_TILE_WINDOWS
-#define PMX_MFMA_TILE_WINDOWS 1
+#define PMX_MFMA_TILE_WINDOWS 1   // the tile holds a whole row of the WINDOW layers (t - 1 + K elements) where two workgroups per CU still fit
+                                  // (t <= 8), as much as fits at t = 9 (8 KiB: two stages per row): +0.4 ... +2 % (profiles/r04)
 #endif
 #ifndef PMX_MFMA_TILE_STEPS
 #define PMX_MFMA_TILE_STEPS 6   // k-steps (KiB) of a row's table in LDS at a time.  At t = 9 (8 x 18 KiB of scratch per CU) that

@@ -1,4 +1,5 @@
-// Dense layers of a wide state on the matrix cores (gfx950: v_mfma_i32_32x32x32_i8).
+// Layers of products by CONSTANTS on the matrix cores (gfx950: v_mfma_i32_32x32x32_i8): the dense layers of the full rounds (round 3,
+// t = 7..9) and - round 4 - the linear part of the partial rounds gathered into windows (below: PMX_MFMA_WINDOW), at every width from 3.
 //
 // A dense layer multiplies the state by a matrix of CONSTANTS: out_i = sum_j c_ij z_j.  On the VALU that is t rows of
 // 81 t + 81 limb products (pmx_permute.hpp: matrix_rows_rolled); here it is an int8 GEMM whose N dimension is the 64 states
