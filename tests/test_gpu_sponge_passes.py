@@ -244,6 +244,10 @@ def test_t3_device_filling_calls_run_on_the_matrix_core_engine_and_agree_with_th
         assert np.array_equal(b_big.state[j], s) and int(b_big.mode_tag[j]) == m and int(b_big.mode_index[j]) == i, int(j)
     # permute and hash across the threshold: the same rows through both engines
     st = synth.random_elements(f, big * t, seed=92).reshape(big, t, 4)
+    pm = f.modulus
+    edges = [[0, 0, 0], [pm - 1] * 3, [1, 0, 0], [0, 0, 1], [pm - 1, 0, 1], [(1 << 254) % pm, (1 << 253) % pm, pm - 2], [2, pm - 1, 0]]
+    for k, e in enumerate(edges):            # the states the reference's arithmetic has edges at, inside the big launch (rows 0..6 are in `sample`)
+        st[k] = f.from_ints(e).reshape(t, 4)
     ctx = cfg.context(0)
     p_big, p_small = ctx.permute_batch(st), ctx.permute_batch(st[:small])
     assert np.array_equal(p_big[:small], p_small)
