@@ -1684,7 +1684,7 @@ static bool quad_shape(const DevConfig &c, uint32_t t) { return quad_table(c, t)
     } while (0)
 
 // t = 3 on the matrix cores as well (round 4): HybridEngine<3, 5, mfma, windows of 3> - the dense layers and the partial rounds'
-// linear part as int8 GEMM layers, 40,9xx instead of 53 k VALU instructions per permutation - for alpha = 5, configs that have the
+// linear part as int8 GEMM layers, 46.1 k instead of 53.0 k VALU instructions per permutation - for alpha = 5, configs that have the
 // tables (modulus rule of pmx_mfma.hpp) and launches that fill the device (the engine runs four-wave workgroups with a shared
 // table tile; below PMX_T3_MFMA_MIN units the register engine's lower latency wins).  permute, hash, compress, and the absorb /
 // squeeze drivers as passes on that engine (like the wider states); smaller calls keep the register engine's kernels.
