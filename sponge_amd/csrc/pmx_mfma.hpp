@@ -63,9 +63,23 @@ PMX_FN constexpr int mfma_window_for(int t) {
     return (t >= PMX_MFMA_WINDOW_MIN_T && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T) ? (PMX_MFMA_WINDOW < t ? PMX_MFMA_WINDOW : t) : 0;
 }
 PMX_FN constexpr int mfma_window_hist(int k) { return (k - 1) * (k - 2) / 2; }   // history constants per window
+// The history constants as stored: elements (kFeStride words each), or - widths up to PMX_MFMA_HIST_TAB_MAX_T - shifted tables
+// (pmx_field.hpp: tab_dot), one row of k - 1 constants per S-box input x_{k+1}, k = 2 .. K - 1: 63 multiplies fewer per input
+// (81 (k-1) + 27 instead of 81 (k-1) + 90) for a constant stream that needs a third wave on the SIMD to hide behind - measured
+// (profiles/r04/q_ab_history_tables.txt): t = 3 +1.4 %, t = 5 +0.7 %, t = 6 -2.9 %, t = 8 -3.3 %, t = 9 -1.8 %.
+#ifndef PMX_MFMA_HIST_TAB_MAX_T
+#define PMX_MFMA_HIST_TAB_MAX_T 5
+#endif
+PMX_FN constexpr bool mfma_hist_tab(int t) { return t <= PMX_MFMA_HIST_TAB_MAX_T; }
+PMX_FN constexpr int mfma_hist_tab_offset(int k) {   // words in front of the row of x_{k+1}
+    int w = 0;
+    for (int j = 2; j < k; ++j) w += tab_row_words(j - 1);
+    return w;
+}
+PMX_FN constexpr int mfma_window_hist_words(int t, int k) { return mfma_hist_tab(t) ? mfma_hist_tab_offset(k) : mfma_window_hist(k) * kFeStride; }
 // words of the window tables of a config: the entry layer (t -> t), then per window its layer (t - 1 + K -> t) and its history constants
 PMX_FN constexpr size_t mfma_window_words(int t, int k, size_t windows) {
-    return (size_t)mfma_layer_words(t) + windows * ((size_t)mfma_layer_words_io(t - 1 + k, t) + (size_t)mfma_window_hist(k) * kFeStride);
+    return (size_t)mfma_layer_words(t) + windows * ((size_t)mfma_layer_words_io(t - 1 + k, t) + (size_t)mfma_window_hist_words(t, k));
 }
 
 // the state's K bytes: nine 32-bit words per element (u - 128 in every byte), padded with zero digits to whole k-steps

@@ -355,7 +355,8 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
         if constexpr (MFMA_THREADS > 0 && MFMA_WINDOW > 0) {
             if (r == first_partial) {   // the whole partial section: windows, each closed by one layer on the matrix cores
                 constexpr int K = MFMA_WINDOW, NIN = T - 1 + K;
-                constexpr size_t kLayer = (size_t)mfma_layer_words_io(NIN, T), kPer = kLayer + (size_t)mfma_window_hist(K) * kFeStride;
+                constexpr size_t kLayer = (size_t)mfma_layer_words_io(NIN, T), kPer = kLayer + (size_t)mfma_window_hist_words(T, K);
+                constexpr bool kHistTab = mfma_hist_tab(T);
                 const uint32_t n_win = (c.partial_rounds + K - 1) / K;
                 uint32_t kw = c.partial_rounds - (n_win - 1) * K;   // the first window is the short one
                 const uint32_t *wt = tb.win + mfma_layer_words(T);
@@ -369,7 +370,16 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                         constexpr int k = decltype(kk)::value;                        // z_{k+1} from x_{k+1} = z_k + u_k + sum_{i<k} h_{k,i} z_i
                         if ((uint32_t)k < kw) {
                             Fe x = s[k];
-                            if constexpr (k >= 2) {
+                            if constexpr (k == 2 && kHistTab) {        // one constant: the compact single-constant table
+                                PMX_SCHED_FENCE();
+                                tab_lanes_stream<1>(in[T - 1], hist, &x, f);
+                                PMX_SCHED_FENCE();
+                            } else if constexpr (k >= 3 && kHistTab) {
+                                const Fe x0 = x;
+                                PMX_SCHED_FENCE();
+                                x = tab_dot_stream<k - 1, true>(&in[T - 1], hist + mfma_hist_tab_offset(k), f, &x0);
+                                PMX_SCHED_FENCE();
+                            } else if constexpr (k >= 2) {
                                 Fe hc[k - 1];
                                 static_for<0, k - 1>([&](auto i) { hc[i] = fe_const(hist + (size_t)(mfma_window_hist(k) + i) * kFeStride); });
                                 x = mont_dot_add<k - 1>(&in[T - 1], hc, x, f);

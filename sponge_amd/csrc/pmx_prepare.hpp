@@ -653,8 +653,13 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
             for (size_t w = 0; w < plan.n_win; ++w) {
                 put_mfma_layer_io(hf, plan.rows[w].data(), t - 1 + K, t, plan.aff[w].data(), dst);
                 dst += lw_in;
-                for (size_t h = 0; h < nh; ++h) to_limbs29(times_pow2(hf, plan.hist[w * nh + h], 5), dst + h * kFeStride);
-                dst += nh * kFeStride;
+                if (mfma_hist_tab((int)t)) {
+                    for (uint32_t k = 2; k < K; ++k)
+                        put_shifted_row(hf, &plan.hist[w * nh + (size_t)mfma_window_hist((int)k)], k - 1, dst + mfma_hist_tab_offset((int)k));
+                } else {
+                    for (size_t h = 0; h < nh; ++h) to_limbs29(times_pow2(hf, plan.hist[w * nh + h], 5), dst + h * kFeStride);
+                }
+                dst += (size_t)mfma_window_hist_words((int)t, (int)K);
             }
             out.mfma_window = K;
         } else {
