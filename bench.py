@@ -96,7 +96,7 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     if optimised and mfma_dense and window > 0:
         n_win = -(-rp // window)
         sizes = [rp - (n_win - 1) * window] + [window] * (n_win - 1)
-        hist = sum(81 * (k - 1) + 81 + 9 for kw in sizes for k in range(2, kw))
+        hist = sum(81 * (k - 1) + red + 9 for kw in sizes for k in range(2, kw))     # (`row_tables`: their constants as shifted tables)
         return (rf * t + rp) * chain + (rf + n_win) * t * 9 + hist
     if optimised:
         # S-box layers: RF full, RP partial.  Linear layers: RF - 2 normalised dense (every full round but the entrance and the

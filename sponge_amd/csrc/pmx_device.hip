@@ -564,7 +564,8 @@ struct HybridEngine {
         else std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,%s>", T, ALPHA, MFMA ? "mfma" : "valu");
         o.threads = kThreads;
         o.optimised = 1;
-        o.row_tables = T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB;
+        // (window engines: the only rows left on the VALU are the history products of the S-box inputs - pmx_mfma.hpp: mfma_hist_tab)
+        o.row_tables = (MFMA && mfma_window_for(T) > 0) ? (mfma_hist_tab(T) ? 1 : 0) : (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB);
         o.lane_tables = T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB;
         o.mfma_dense = MFMA;
         o.partial_window = MFMA ? mfma_window_for(T) : 0;
