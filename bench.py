@@ -52,6 +52,8 @@ WORKLOADS = {
     # every step absorbs L elements into every sponge and squeezes K out of it, the sponges carried from step to step
     "d3": ("bls12_381_fr", 2, 5, 8, 31, 20, None, 0x5EED0008, "bls12_381_fr t=3 alpha=5 duplex driver: absorb(4) + squeeze(3) per sponge and step (4 permutations)"),
     "d9": ("bn254_fr", 8, 5, 8, 57, 18, None, 0x5EED0009, "bn254_fr t=9 alpha=5 duplex driver: absorb(11) + squeeze(9) per sponge and step (4 permutations)"),
+    # the reference's own rate-2 default and the config of its only permutation KAT (src/test.rs:15, src/poseidon/mod.rs:376-399): alpha = 17
+    "k3": ("bls12_381_fr", 2, 17, 8, 31, 20, None, 0x5EED0011, "bls12_381_fr t=3 alpha=17 RF=8 RP=31 permutation batch (the reference's default rate-2 parameters)"),
     # the other widths of the reference's default table (src/test.rs:14-31), for tuning the wide-state engines
     "w4": ("bls12_381_fr", 3, 5, 8, 56, 19, None, 0x5EED0014, "bls12_381_fr t=4 alpha=5 RF=8 RP=56 permutation batch"),
     "w5": ("bls12_381_fr", 4, 5, 8, 56, 19, None, 0x5EED0015, "bls12_381_fr t=5 alpha=5 RF=8 RP=56 permutation batch"),

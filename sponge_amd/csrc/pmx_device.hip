@@ -1418,7 +1418,16 @@ struct Launch {
     }
 };
 
-#if PMX_TU != 0
+#if PMX_TU == 99
+// ---- tuning aid (Makefile target asm1): ONE kernel of one hybrid engine, for reading its ISA and register report in seconds -------
+#ifndef PMX_ONE_T
+#define PMX_ONE_T 9
+#endif
+#ifndef PMX_ONE_ALPHA
+#define PMX_ONE_ALPHA 5
+#endif
+template __global__ void permute_kernel<HybridEngine<PMX_ONE_T, PMX_ONE_ALPHA, true>>(const DevConfig, const uint32_t *__restrict__, uint64_t *__restrict__, size_t);
+#elif PMX_TU != 0
 // ---- hybrid family of this translation unit -------------------------------------------------------------------------
 // four translation units (they dominate the build time, so they compile in parallel): the exponent (1, 3: alpha = 5; 2, 4: any other) x the
 // widths (1, 2: t <= 6; 3, 4: t = 7..9).  The public launchers of TU 0 pick the half by t.
@@ -1467,7 +1476,7 @@ static bool lds_fits_engine(const DevConfig &c, uint32_t t) { return Engine::lds
         return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::CALL;
 #if !PMX_HYB_NARROW
 #define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(7, CALL) PMX_HYB_MFMA_CASE(8, CALL) PMX_HYB_MFMA_CASE(9, CALL)
-#elif PMX_MFMA_MIN_T <= 3 && PMX_TU == 1   // t = 3, alpha = 5: device-filling launches (t3_mfma below)
+#elif PMX_MFMA_MIN_T <= 3   // t = 3 as well: device-filling launches (t3_mfma below), every exponent
 #define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(3, CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
 #elif PMX_MFMA_MIN_T <= 4
 #define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
@@ -1522,7 +1531,7 @@ static hipError_t hyb_driver(const DevConfig &c, uint32_t t, uint64_t *states, u
         else return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::absorb(c, t, states, tag, index, io, len, n, st);
     }
 }
-#if PMX_MFMA_MIN_T <= 3 && PMX_TU == 1   // t = 3, alpha = 5, device-filling calls (t3_mfma): passes on the matrix-core engine
+#if PMX_MFMA_MIN_T <= 3 && PMX_HYB_NARROW   // t = 3, device-filling calls (t3_mfma, which has checked the tables and the LDS): passes on the matrix-core engine
 #define PMX_HYB_DRIVER_T3(SQ, IO) \
         case 3: return Launch<HybridEngine<3, PMX_HYB_ALPHA, true>>::template sponge_passes<SQ>(c, t, states, tag, index, IO, len, n, st, scratch);
 #else
@@ -1684,27 +1693,32 @@ static bool quad_shape(const DevConfig &c, uint32_t t) { return quad_table(c, t)
         return hipGetLastError();                                                                                           \
     } while (0)
 
-// t = 3 on the matrix cores as well (round 4): HybridEngine<3, 5, mfma, windows of 3> - the dense layers and the partial rounds'
-// linear part as int8 GEMM layers, 46.1 k instead of 53.0 k VALU instructions per permutation - for alpha = 5, configs that have the
+// t = 3 on the matrix cores as well (round 4): HybridEngine<3, alpha, mfma, windows of 3> - the dense layers and the partial rounds'
+// linear part as int8 GEMM layers, 46.1 k instead of 53.0 k VALU instructions per permutation at alpha = 5 - for configs that have the
 // tables (modulus rule of pmx_mfma.hpp) and launches that fill the device (the engine runs four-wave workgroups with a shared
 // table tile; below PMX_T3_MFMA_MIN units the register engine's lower latency wins).  permute, hash, compress, and the absorb /
 // squeeze drivers as passes on that engine (like the wider states); smaller calls keep the register engine's kernels.
+// Every exponent (round 5): the window rewrite does not depend on alpha, only the S-box does - alpha = 5 on its dedicated chain,
+// anything else (17: the reference's own rate-2 default, src/test.rs:15; 257: its weights table, :23-31) on the generic S-box,
+// like the wider states.  If the engine's LDS does not fit the device the register engine keeps the call (launch and describe alike).
 #ifndef PMX_T3_MFMA_MIN
 #define PMX_T3_MFMA_MIN ((size_t)1 << 17)
 #endif
 static bool t3_mfma(const DevConfig &c, uint32_t t, size_t n) {
-    return PMX_MFMA_MIN_T <= 3 && t == 3 && c.has_opt && c.mfma_dense && c.rounds.alpha == 5 && n >= PMX_T3_MFMA_MIN;
+    return PMX_MFMA_MIN_T <= 3 && t == 3 && c.has_opt && c.mfma_dense && n >= PMX_T3_MFMA_MIN && lds_fits<HybridEngine<3, 5, true>>(c, t);
 }
+// the hybrid family's half by exponent, as PMX_DISPATCH picks it for the wider states
+#define PMX_T3_MFMA(CALL) (c.rounds.alpha == 5 ? hybrid5_##CALL : hybridg_##CALL)
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
     if (quad_table(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(permute_quad_kernel, states, n);
-    if (t3_mfma(c, t, n)) return hybrid5_permute(c, t, states, n, st);
+    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(permute(c, t, states, n, st));
     PMX_SMALL_BATCH(kTabMinPermute, permute(c, t, states, n, st));
     PMX_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                        size_t n, hipStream_t st) {
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(hash_quad_kernel, in, in_len, out, out_len, n);
-    if (t3_mfma(c, t, n)) return hybrid5_hash(c, t, in, in_len, out, out_len, n, st);
+    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(hash(c, t, in, in_len, out, out_len, n, st));
     PMX_SMALL_BATCH(kTabMinPermute, hash(c, t, in, in_len, out, out_len, n, st));
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
@@ -1731,7 +1745,7 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
         if (c.rounds.alpha == 17) return launch_compress_coop<17>(c, in, out, n, st);
         return launch_compress_coop<0>(c, in, out, n, st);
     }
-    if (t3_mfma(c, t, n)) return hybrid5_compress(c, t, in, out, n, st);
+    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(compress(c, t, in, out, n, st));
     PMX_SMALL_BATCH(kTabMinCompress, compress(c, t, in, out, n, st));
     PMX_DISPATCH(compress(c, t, in, out, n, st));
 }
@@ -1739,14 +1753,14 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st, const PassScratch &scratch) {
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(absorb_quad_kernel, states, tag, index, in, in_len, n);
-    if (t3_mfma(c, t, n)) return hybrid5_absorb(c, t, states, tag, index, in, in_len, n, st, scratch);
+    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
     PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
     PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
 }
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st, const PassScratch &scratch) {
     if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
-    if (t3_mfma(c, t, n)) return hybrid5_squeeze(c, t, states, tag, index, out, out_len, n, st, scratch);
+    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
     PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
 }
@@ -1767,19 +1781,19 @@ hipError_t describe_launch(const DevConfig &c, uint32_t t, int op, size_t n, siz
     switch (op) {
         case PMX_OP_PERMUTE:
             if (quad_table(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) return describe_quad(c, o);
-            if (t3_mfma(c, t, n)) return hybrid5_describe(c, t, op, len, o);
+            if (t3_mfma(c, t, n)) return PMX_T3_MFMA(describe(c, t, op, len, o));
             PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
             break;
         case PMX_OP_HASH:
         case PMX_OP_ABSORB:
         case PMX_OP_SQUEEZE:
             if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) return describe_quad(c, o);
-            if (t3_mfma(c, t, n)) return hybrid5_describe(c, t, op, len, o);
+            if (t3_mfma(c, t, n)) return PMX_T3_MFMA(describe(c, t, op, len, o));
             PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
             break;
         case PMX_OP_COMPRESS:
             if (quad_shape(c, t) && n <= kCoopMaxUnits) return describe_quad(c, o);
-            if (t3_mfma(c, t, n)) return hybrid5_describe(c, t, op, len, o);
+            if (t3_mfma(c, t, n)) return PMX_T3_MFMA(describe(c, t, op, len, o));
             PMX_SMALL_BATCH(kTabMinCompress, describe(c, t, op, len, o));
             break;
         default:
