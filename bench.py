@@ -124,6 +124,9 @@ def parse_args():
     ap.add_argument("--allow-torch-gather", action="store_true",
                     help="N>1: if the C ABI's device group (RCCL through pmx_mgpu_*) cannot be formed, gather through torch.distributed "
                          "instead of exiting non-zero (a second code path: off by default, and the line says so when taken)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N>1 without a launcher: ONE process drives all N GPUs through the C ABI's single-process device group "
+                         "(pmx_mgpu_create = ncclCommInitAll; what a Rust caller uses) instead of starting one rank per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the all-cores cpu_baseline sample")
@@ -194,18 +197,254 @@ def sample_indices(n, k):
                                      np.linspace(0, n - 1, k // 2).astype(np.int64)]))
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher environment: start the N ranks OURSELVES, as a child process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` - the very command the
+    driver's contract spells), decided before torch is imported or any HIP call is made, never by exec; the child's exit
+    code is ours and rank 0's JSON line passes through on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                 # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching the ranks as a child process: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def main_single_process(args):
+    """`python bench.py --gpus N --single-process`: ONE process drives all N GPUs through the C ABI's single-process device group
+    (pmx_mgpu_create = ncclCommInitAll - SURVEY section 7 step 6, and what a Rust caller's BatchPoseidon::new_multi does): no
+    torch.distributed, no launcher.  torch only allocates the per-device buffers and the HIP events on the library's own streams.
+    Same workloads, sizes, step / gather / verification semantics and JSON line as the one-rank-per-GPU form: contiguous shards, no
+    collective on the data path, one final RCCL gather inside the timed region (permutation batches) or the roots all-gather of the
+    sharded tree.  Time = host wall clock from the first enqueue to pmx_mgpu_synchronize returning, bracketed by synchronisation
+    of every device on both sides; the kernel time is the longest per-device HIP-event interval.
+    PMX_BENCH_REHEARSAL=group: the N slots share the visible GPU(s) (test-hook build of the library + a collective library that
+    accepts that: tests/fake_rccl first on LD_LIBRARY_PATH or named by PMX_RCCL_LIBRARY) - every branch executes, no number means anything."""
+    import torch
+    import sponge_amd as S
+    from sponge_amd import _lib, mgpu, synth
+
+    world = args.gpus
+    mode = os.environ.get("PMX_BENCH_REHEARSAL", "")
+    if mode not in ("", "group"):
+        raise SystemExit("--single-process: PMX_BENCH_REHEARSAL is unset or 'group'")
+    rehearsal = mode == "group"
+    if rehearsal:
+        _lib.use_test_library()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the Poseidon path has no CPU fallback")
+    if args.workload in HASH_SHAPES or args.workload in DUPLEX_SHAPES:
+        raise SystemExit("--single-process runs the permutation batches (c2, c3, k3, w*) and the sharded tree (c5)")
+    visible = torch.cuda.device_count()
+    if rehearsal:
+        devices = [l % visible for l in range(world)]
+        _lib.check(_lib.lib().pmx_mgpu_test_shared_device(1))
+    else:
+        if world > visible:
+            raise SystemExit(f"--gpus {world} but only {visible} visible device(s)")
+        devices = list(range(world))
+
+    field_name, rate, alpha, rf, rp, log2_one, log2_total_multi, seed, desc = WORKLOADS[args.workload]
+    t = rate + 1
+    merkle = args.workload == "c5"
+    if args.total_units is not None:
+        n_total, scaling, baseline_cfg = args.total_units, "strong", None
+    elif args.total_log2 is not None:
+        n_total, scaling, baseline_cfg = 1 << args.total_log2, "strong", None
+    elif args.states_per_gpu_log2 is not None:
+        n_total, scaling, baseline_cfg = world << args.states_per_gpu_log2, "weak", None
+    elif log2_total_multi is not None:
+        n_total, scaling, baseline_cfg = 1 << log2_total_multi, "strong", BASELINE_CONFIG.get((args.workload, True))
+    else:
+        n_total, scaling, baseline_cfg = world << log2_one, "weak", None
+    if merkle and (n_total % world or (n_total // world) & (n_total // world - 1) or world & (world - 1)):
+        raise SystemExit("the Merkle workload needs power-of-two leaves and ranks")
+    field = S.FIELDS[field_name]
+    cfg = S.poseidon_config_from_lfsr(field, rate, alpha, rf, rp)
+
+    peak = _lib.PmxValuPeak()
+    _lib.check(_lib.lib().pmx_diag_int_valu_peak(devices[0], 0.1, peak))
+    group = mgpu.DeviceGroup.single_process(cfg, devices=devices)
+    info = group.info()
+    rccl = {"ranks": info["comm_ranks"], "version": info["rccl_version_str"], "rank0_is": info["comm_first_rank"],
+            "via": "pmx_mgpu_create (ncclCommInitAll, one process); gather = pmx_mgpu_all_gather_dev (ncclAllGather / grouped ncclBroadcast)"}
+    if rehearsal:
+        rccl["via"] += "; REHEARSAL: the slots share GPUs, collective library = " + os.environ.get("PMX_RCCL_LIBRARY", "librccl.so.1 on the search path")
+    ctx = group.context(0)
+    spans = [group.local_span(n_total, l) for l in range(world)]
+    n = spans[0][1]
+    slot = {}
+    early = _lib.PmxEngineInfo()
+    _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, _lib.OP_COMPRESS if merkle else _lib.OP_PERMUTE, (n // 2 if merkle else n), 0, early))
+    r = _lib.PmxIssueSlot()
+    _lib.check(_lib.lib().pmx_diag_issue_slot(devices[0], max(1, min(8, early.waves_per_simd)), 0.06, r))
+    slot[max(1, min(8, early.waves_per_simd))] = r
+    devs = [torch.device("cuda", d) for d in devices]
+    streams = [torch.cuda.ExternalStream(group.stream(l), device=devs[l]) for l in range(world)]
+
+    def sync_all():
+        group.synchronize()
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    def fresh_inputs(l):
+        start, count = spans[l]
+        host = synth.random_elements(field, count * (1 if merkle else t), seed, offset=start * (1 if merkle else t))
+        return host, torch.from_numpy(host.view(np.int64).copy()).to(devs[l])
+
+    def make_buffers():
+        b = {"in": [], "top": [], "gathered": [], "host": []}
+        for l in range(world):
+            host, d_in = fresh_inputs(l)
+            count = spans[l][1]
+            b["host"].append(host)
+            if merkle:
+                nodes = torch.zeros((2 * count - 1, 4), dtype=torch.int64, device=devs[l])
+                nodes[:count] = d_in.reshape(count, 4)
+                b["in"].append(nodes)
+                b["top"].append(torch.zeros((2 * world - 1, 4), dtype=torch.int64, device=devs[l]))
+            else:
+                b["in"].append(d_in.reshape(count, t, 4))
+                if args.gather != "none":
+                    b["gathered"].append(torch.empty((n_total, t, 4), dtype=torch.int64, device=devs[l]))
+        return b
+
+    def run_step(b):
+        if merkle:
+            group.merkle_2to1_dev([x.data_ptr() for x in b["in"]], [x.data_ptr() for x in b["top"]], n_total)
+        else:
+            group.permute_shards_dev([x.data_ptr() for x in b["in"]], n_total)       # no collective on the data path
+            if args.gather == "step":
+                run_gather(b)
+
+    def run_gather(b):
+        group.all_gather_dev([x.data_ptr() for x in b["in"]], [x.data_ptr() for x in b["gathered"]], n_total, t)
+
+    def final_gather(b):
+        if not merkle and args.gather == "final":
+            run_gather(b)
+
+    bufs = make_buffers()
+    units_per_step = float(n_total - 1) if merkle else float(n_total)
+    sync_all()
+    t_spin, i_spin = time.perf_counter(), 0
+    while (i_spin < 32) if merkle else (time.perf_counter() - t_spin < args.spinup_seconds):
+        run_step(bufs)
+        i_spin += 1
+        if i_spin % 4 == 0:
+            group.synchronize()
+    for _ in range(args.warmup):
+        run_step(bufs)
+    final_gather(bufs)          # also warms RCCL's lazily built channels up, outside the timed region
+    sync_all()
+
+    def events():
+        out = []
+        for l in range(world):
+            with torch.cuda.device(devs[l]):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(streams[l])
+                out.append(e)
+        return out
+
+    t0 = time.perf_counter()
+    ev0 = events()
+    for _ in range(args.steps):
+        run_step(bufs)
+    ev_k = events()
+    final_gather(bufs)
+    ev1 = events()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    dev_s = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / 1e3
+    steps_s = max(a.elapsed_time(b) for a, b in zip(ev0, ev_k)) / 1e3
+
+    verify = None
+    if not args.no_verify:
+        cr = oracle_engine(field_name, rate, alpha, rf, rp)
+        verify = {"ok": True, "engine": "oracle/poseidon_ref.c (C restatement)", "what": None}
+        b = make_buffers()
+        for g in b["gathered"]:
+            g.zero_()
+        sync_all()
+        run_step(b)
+        if not merkle and b["gathered"] and args.gather != "step":
+            run_gather(b)
+        sync_all()
+        ok, checked = True, 0
+
+        def to_np(x):
+            return x.cpu().numpy().view(np.uint64)
+        if merkle:
+            tops = [to_np(x) for x in b["top"]]
+            for l in range(world):
+                count = spans[l][1]
+                got = to_np(b["in"][l])
+                if count >= 2:
+                    idx = sample_indices(count // 2, 1024)
+                    pairs = np.ascontiguousarray(b["host"][l].reshape(count // 2, 2, 4)[idx])
+                    ok &= bool(np.array_equal(got[count + idx], cr.hash_batch(pairs, 2, 1, threads=0).reshape(-1, 4)))
+                w = min(count, 1024)
+                first = 2 * count - 2 * w
+                ok &= bool(np.array_equal(cr.merkle(np.ascontiguousarray(got[first:first + w]), threads=0)[w:], got[first + w:]))
+                ok &= bool(np.array_equal(tops[l][l], got[-1]))                                               # slot l's root at rank l
+                ok &= bool(np.array_equal(cr.merkle(np.ascontiguousarray(tops[l][:world]), threads=0), tops[l]))   # every device holds the whole top
+            verify["what"] = f"a fresh tree on every device: level 1 on a sample, the top of each subtree, the {world} gathered roots and the levels above them on every device"
+        elif b["gathered"]:
+            for l in range(world):                  # every device's copy of the gathered result, a sample of every rank's span
+                for rr in range(world):
+                    s_r, c_r = spans[rr]
+                    idx = s_r + sample_indices(c_r, 128)
+                    inp = np.stack([synth.random_elements(field, t, seed, offset=int(i) * t) for i in idx])
+                    ok &= bool(np.array_equal(to_np(b["gathered"][l][torch.from_numpy(idx).to(devs[l])]), cr.permute_batch(inp, threads=0)))
+                    checked += len(idx)
+            verify["what"] = f"the gathered buffer of one fresh pass on every device: {checked} states, a sample of every rank's span at its offset"
+        else:
+            for l in range(world):
+                count = spans[l][1]
+                idx = sample_indices(count, 1024)
+                want = cr.permute_batch(np.ascontiguousarray(b["host"][l].reshape(count, t, 4)[idx]), threads=0)
+                ok &= bool(np.array_equal(to_np(b["in"][l])[idx], want))
+            verify["what"] = "a sample of every device's shard of one fresh pass (--gather none)"
+        verify["ok"] = ok
+
+    out = result_line(args, ctx, peak, slot, world=world, n=n, n_total=n_total, units_per_step=units_per_step, elapsed=elapsed,
+                      steps_s=steps_s, dev_s=dev_s, scaling=scaling, baseline_cfg=baseline_cfg, rccl=rccl, verify=verify, rehearsal=rehearsal,
+                      launcher="one process, every GPU through pmx_mgpu_create (ncclCommInitAll); no torch.distributed")
+    out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    group.close()
+    if verify is not None and not verify["ok"]:
+        sys.exit(3)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: either one process drives every GPU through the library's own device group
+        # (--single-process: pmx_mgpu_create = ncclCommInitAll, no torch.distributed at all), or - the default, the form the
+        # contract names - we start one rank per GPU as a child.  Decided here, before torch is imported.
+        if args.single_process:
+            return main_single_process(args)
+        sys.exit(launch_ranks(args))
+    if args.single_process and args.gpus > 1:
+        raise SystemExit("--single-process drives every GPU from ONE process: start it without a launcher (WORLD_SIZE is set)")
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Poseidon path has no CPU fallback")
 
@@ -227,6 +466,8 @@ def main():
         raise SystemExit("PMX_BENCH_REHEARSAL is 1 (gathers staged through the host) or group (the C ABI's device group)")
     rehearsal = rehearsal_mode != ""
     host_staged = rehearsal_mode == "1"
+    if rehearsal_mode == "group":
+        _lib.use_test_library()      # only the test-hook build reads PMX_RCCL_LIBRARY (the stand-in that accepts ranks sharing a GPU)
     if rehearsal:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -456,75 +697,10 @@ def main():
         verify["ok"] = bool(int(flag))
 
     if rank == 0:
-        value = units_per_step * args.steps / elapsed
-        # dominant kernel: permute_kernel (compress kernels in the Merkle mode); its average launch duration from the HIP
-        # events on this rank's launch stream around the K steps (back-to-back launches, nothing else on the stream)
-        kernel_s = steps_s / args.steps
-        per_gpu_units = units_per_step / world
-        bytes_per_unit = 96 if merkle else 2 * t * 32       # 2*t*32 B per permutation; 64 in + 32 out per 2-to-1
-        if hashing:
-            bytes_per_unit = (in_len + out_len) * 32 / perms_per_row
-        if duplex:      # per sponge and step: the input row, the output row, and every permutation's state once in and once out
-            bytes_per_unit = ((in_len + out_len) * 32 + perms_per_row * 2 * t * 32) / perms_per_row
-        algo_bytes = bytes_per_unit * per_gpu_units
-        achieved = algo_bytes / kernel_s / 1e9
-        # The engine as the library's own launchers dispatch it for this call (pmx_ctx_engine_info: schedule, table forms,
-        # matrix-core rows, launch bound) - the instruction accounting below follows the kernels, not a copy of their rules.
-        # ABI <-> internal conversions cost no multiplies on the optimised schedule (pmx_field.hpp: fe_from_abi_scaled).
-        info = _lib.PmxEngineInfo()
-        op = _lib.OP_COMPRESS if merkle else (_lib.OP_HASH if hashing else (_lib.OP_ABSORB if duplex else _lib.OP_PERMUTE))
-        _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, op, (n // 2 if merkle else n), (in_len if duplex else 0), info))
-        mfma_dense = bool(info.mfma_dense)
-        mads = mads_per_permutation(t, alpha, rf, rp, optimised=bool(info.optimised), row_tables=bool(info.row_tables),
-                                    lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense, window=int(info.partial_window))
-        # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
-        # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
-        last_row = 9 if mfma_dense else 81 * t + (18 if info.row_tables else 81)
-        if merkle:
-            mads -= (t - 1) * last_row
-        elif hashing:
-            mads -= (t - out_len) * last_row / perms_per_row
-        mad_rate = mads * per_gpu_units / kernel_s
-        traffic, traffic_src = load_traffic(args.workload, per_gpu_units)
-        valu_issue = load_valu_issue(args.workload, per_gpu_units, kernel_s, peak.compute_units, mads, info, slot)
-        out = {
-            "metric": "Poseidon permutations/sec (%s, t=%d)" % ({"bls12_381_fr": "BLS12-381 Fr", "bn254_fr": "BN254 Fr"}[field_name], t),
-            "value": value, "unit": "permutations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{desc}, {fmt_pow2(n_total)} units in all = {fmt_pow2(n)} per GPU x {world}",
-                       "baseline_config": baseline_cfg,
-                       "arithmetic": "255-bit modular integers as 9 x 29-bit limbs in u32, Montgomery form",
-                       "units_total": n_total, "units_per_gpu": n, "permutations_per_step": units_per_step,
-                       "gather": (args.gather if (world > 1 and not merkle and not hashing) else ("roots" if merkle and world > 1 else "n/a")),
-                       "sharding": f"contiguous x{world}", **({"REHEARSAL": "ranks share one GPU, gloo: not a measurement"} if rehearsal else {}),
-                       "series": "N=1 runs configs[1] (2^20 states); N>1 shard configs[3]'s 2^24 states (strong scaling)"
-                                 if args.workload == "c2" and baseline_cfg else None},
-            "engine": {"name": info.engine.decode(), "threads_per_workgroup": info.threads, "waves_per_simd": info.waves_per_simd,
-                       "lds_bytes_per_workgroup": info.lds_bytes, "optimised_schedule": bool(info.optimised),
-                       "row_tables": bool(info.row_tables), "lane_tables": bool(info.lane_tables), "mfma_dense": mfma_dense,
-                       "partial_window": int(info.partial_window),
-                       "source": "pmx_ctx_engine_info (the launchers' own dispatch conditions)" + (", widest level of the tree" if merkle else "")},
-            "rccl": rccl,
-            "verified": (verify["ok"] if verify else None), "verify": verify,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "pmx::compress_kernel / compress_coop_kernel (per tree level)" if merkle else
-                                   ("pmx::hash_kernel" if hashing else ("the driver's kernels: " + info.engine.decode() if duplex else "pmx::permute_kernel")),
-                         "kernel_ms": 1e3 * kernel_s, "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "integer-VALU bound, not HBM bound (DESIGN.md): see int_valu"},
-            "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": peak.lane_mads_per_s,
-                         "unit": "lane-instr/s", "frac": mad_rate / peak.lane_mads_per_s, "mads_per_permutation": mads,
-                         "dense_layers": "v_mfma_i32_32x32x32_i8 (pmx_mfma.hpp): not counted as multiplies" if mfma_dense else "VALU",
-                         "peak_source": "pmx_diag_int_valu_peak on this device just before the warm-up (%d launches of a dense v_mad_u64_u32 loop, two forms, median of the later half of each)" % peak.launches,
-                         "peak_best_launch": peak.best_lane_mads_per_s,
-                         "peak_by_carry_destination": {"vcc": peak.lane_mads_per_s_vcc, "sgpr_pair": peak.lane_mads_per_s_sgpr}, "shader_clock_hz": peak.shader_clock_hz,
-                         "theoretical_peak": peak.theoretical_lane_mads_per_s, "compute_units": peak.compute_units,
-                         "frac_of_theoretical": mad_rate / peak.theoretical_lane_mads_per_s if peak.theoretical_lane_mads_per_s else None},
-            "valu_issue": valu_issue,
-            "gather_ms": 1e3 * (dev_s - steps_s) if world > 1 else None,
-        }
+        out = result_line(args, ctx, peak, slot, world=world, n=n, n_total=n_total, units_per_step=units_per_step, elapsed=elapsed,
+                          steps_s=steps_s, dev_s=dev_s, scaling=scaling, baseline_cfg=baseline_cfg, rccl=rccl, verify=verify, rehearsal=rehearsal,
+                          in_len=(in_len if (hashing or duplex) else 0), out_len=(out_len if (hashing or duplex) else 0),
+                          perms_per_row=(perms_per_row if (hashing or duplex) else 1))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(field_name, rate, alpha, rf, rp, seed, args.cpu_seconds)
         else:
@@ -538,6 +714,90 @@ def main():
         dist.destroy_process_group()
     if verify is not None and not verify["ok"]:
         sys.exit(3)
+
+
+def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, elapsed, steps_s, dev_s, scaling, baseline_cfg, rccl, verify,
+                rehearsal, in_len=0, out_len=0, perms_per_row=1, launcher=None):
+    """The JSON line (everything but cpu_baseline) from a run's sizes and times: one function for the one-rank-per-GPU form
+    and the single-process form, so that the N = 1 line and both N > 1 lines price the kernels the same way."""
+    from sponge_amd import _lib
+    field_name, rate, alpha, rf, rp, _l1, _lm, _seed, desc = WORKLOADS[args.workload]
+    t = rate + 1
+    merkle = args.workload == "c5"
+    hashing = args.workload in HASH_SHAPES
+    duplex = args.workload in DUPLEX_SHAPES
+    value = units_per_step * args.steps / elapsed
+    # dominant kernel: permute_kernel (compress kernels in the Merkle mode); its average launch duration from the HIP
+    # events on this rank's launch stream around the K steps (back-to-back launches, nothing else on the stream)
+    kernel_s = steps_s / args.steps
+    per_gpu_units = units_per_step / world
+    bytes_per_unit = 96 if merkle else 2 * t * 32       # SURVEY 8d: 2*t*32 B per permutation; 64 in + 32 out per 2-to-1
+    if hashing:
+        bytes_per_unit = (in_len + out_len) * 32 / perms_per_row
+    if duplex:      # per sponge and step: the input row, the output row, and every permutation's state once in and once out
+        bytes_per_unit = ((in_len + out_len) * 32 + perms_per_row * 2 * t * 32) / perms_per_row
+    algo_bytes = bytes_per_unit * per_gpu_units
+    achieved = algo_bytes / kernel_s / 1e9
+    # The engine as the library's own launchers dispatch it for this call (pmx_ctx_engine_info: schedule, table forms,
+    # matrix-core rows, launch bound) - the instruction accounting below follows the kernels, not a copy of their rules.
+    # ABI <-> internal conversions cost no multiplies on the optimised schedule (pmx_field.hpp: fe_from_abi_scaled).
+    info = _lib.PmxEngineInfo()
+    op = _lib.OP_COMPRESS if merkle else (_lib.OP_HASH if hashing else (_lib.OP_ABSORB if duplex else _lib.OP_PERMUTE))
+    _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, op, (n // 2 if merkle else n), (in_len if duplex else 0), info))
+    mfma_dense = bool(info.mfma_dense)
+    mads = mads_per_permutation(t, alpha, rf, rp, optimised=bool(info.optimised), row_tables=bool(info.row_tables),
+                                lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense, window=int(info.partial_window))
+    # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
+    # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
+    last_row = 9 if mfma_dense else 81 * t + (18 if info.row_tables else 81)
+    if merkle:
+        mads -= (t - 1) * last_row
+    elif hashing:
+        mads -= (t - out_len) * last_row / perms_per_row
+    mad_rate = mads * per_gpu_units / kernel_s
+    traffic, traffic_src = load_traffic(args.workload, per_gpu_units)
+    valu_issue = load_valu_issue(args.workload, per_gpu_units, kernel_s, peak.compute_units, mads, info, slot)
+    out = {
+        "metric": "Poseidon permutations/sec (%s, t=%d)" % ({"bls12_381_fr": "BLS12-381 Fr", "bn254_fr": "BN254 Fr"}[field_name], t),
+        "value": value, "unit": "permutations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"{desc}, {fmt_pow2(n_total)} units in all = {fmt_pow2(n)} per GPU x {world}",
+                   "baseline_config": baseline_cfg,
+                   "arithmetic": "255-bit modular integers as 9 x 29-bit limbs in u32, Montgomery form",
+                   "units_total": n_total, "units_per_gpu": n, "permutations_per_step": units_per_step,
+                   "gather": (args.gather if (world > 1 and not merkle and not hashing) else ("roots" if merkle and world > 1 else "n/a")),
+                   "sharding": f"contiguous x{world}", **({"REHEARSAL": "ranks share one GPU, gloo: not a measurement"} if rehearsal else {}),
+                   "series": "N=1 runs configs[1] (2^20 states); N>1 shard configs[3]'s 2^24 states (strong scaling)"
+                             if args.workload == "c2" and baseline_cfg else None},
+        "engine": {"name": info.engine.decode(), "threads_per_workgroup": info.threads, "waves_per_simd": info.waves_per_simd,
+                   "lds_bytes_per_workgroup": info.lds_bytes, "optimised_schedule": bool(info.optimised),
+                   "row_tables": bool(info.row_tables), "lane_tables": bool(info.lane_tables), "mfma_dense": mfma_dense,
+                   "partial_window": int(info.partial_window),
+                   "source": "pmx_ctx_engine_info (the launchers' own dispatch conditions)" + (", widest level of the tree" if merkle else "")},
+        "rccl": rccl,
+        "verified": (verify["ok"] if verify else None), "verify": verify,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "pmx::compress_kernel / compress_coop_kernel (per tree level)" if merkle else
+                               ("pmx::hash_kernel" if hashing else ("the driver's kernels: " + info.engine.decode() if duplex else "pmx::permute_kernel")),
+                     "kernel_ms": 1e3 * kernel_s, "algorithmic_bytes_per_launch": algo_bytes,
+                     "note": "integer-VALU bound, not HBM bound (DESIGN.md): see int_valu"},
+        "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": peak.lane_mads_per_s,
+                     "unit": "lane-instr/s", "frac": mad_rate / peak.lane_mads_per_s, "mads_per_permutation": mads,
+                     "dense_layers": "v_mfma_i32_32x32x32_i8 (pmx_mfma.hpp): not counted as multiplies" if mfma_dense else "VALU",
+                     "peak_source": "pmx_diag_int_valu_peak on this device just before the warm-up (%d launches of a dense v_mad_u64_u32 loop, two forms, median of the later half of each)" % peak.launches,
+                     "peak_best_launch": peak.best_lane_mads_per_s,
+                     "peak_by_carry_destination": {"vcc": peak.lane_mads_per_s_vcc, "sgpr_pair": peak.lane_mads_per_s_sgpr}, "shader_clock_hz": peak.shader_clock_hz,
+                     "theoretical_peak": peak.theoretical_lane_mads_per_s, "compute_units": peak.compute_units,
+                     "frac_of_theoretical": mad_rate / peak.theoretical_lane_mads_per_s if peak.theoretical_lane_mads_per_s else None},
+        "valu_issue": valu_issue,
+        "gather_ms": 1e3 * (dev_s - steps_s) if world > 1 else None,
+    }
+    if launcher:
+        out["config"]["launcher"] = launcher
+    return out
 
 
 def fmt_pow2(n):

@@ -180,11 +180,15 @@ int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64
  * absorb: CryptographicSponge::absorb for in_len native elements per sponge (mod.rs:232-254, 121-150).
  * squeeze: FieldBasedCryptographicSponge::squeeze_native_field_elements(out_len) (mod.rs:321-341,
  * 153-182, including the `!= rate` test of :175).  Sponges in one call may be in different modes.
- * Widths 4..9 (and width 3 from 2^17 sponges up, alpha = 5) run a call as PASSES on the permutation engine of the width (one launch per permutation a sponge of the
- * batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would permute it); the pass
- * lists of the _dev variants live in a block the context keeps per caller stream (calls on different streams stay
- * independent; concurrent calls of ONE context serialise while they enqueue); there a call moves at most 65536 rates of
- * elements per sponge (PMX_ERR_ARG beyond: split the call - to a duplex sponge two calls are the same as one). */
+ * Widths 4..9 (and width 3 from 2^17 sponges up) run a call as PASSES on the permutation engine of the width (one launch per
+ * permutation a sponge of the batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would
+ * permute it).  EVERY absorb / squeeze call moves at most 65536 rates of elements per sponge, whatever the width and the batch
+ * size (PMX_ERR_ARG beyond: split the call - to a duplex sponge two calls are the same as one).
+ * The _dev variants only enqueue on the caller's stream, with two provisos for the pass form: (1) the pass lists live in device
+ * blocks the context keeps in a pool (a call takes the block its stream used last, or one whose earlier use has completed - the
+ * context's own event says so -, or allocates one: calls on different streams stay independent; concurrent calls of ONE context
+ * serialise while they enqueue).  An allocation (hipMalloc) may therefore happen inside the call: these two entry points must not
+ * be captured into a hipGraph.  (2) A stream must outlive the driver work pending on it: synchronise it before destroying it. */
 int pmx_sponge_absorb_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
                             const uint64_t *in, size_t in_len, size_t n);
 int pmx_sponge_squeeze_batch(pmx_ctx *ctx, uint64_t *states, uint32_t *mode_tag, uint32_t *mode_index,
@@ -244,8 +248,8 @@ int pmx_merkle_verify_paths_dev(pmx_ctx *ctx, const uint64_t *d_leaves, const ui
  * streams (pmx_mgpu_stream) and return; pmx_mgpu_synchronize waits for all of them.
  *
  * RCCL is bound when the first group is formed (dlopen of librccl.so.1 by SONAME - a process that already holds a copy
- * keeps it -, then /opt/rocm/lib/librccl.so.1).  The environment variable PMX_RCCL_LIBRARY=<path>, read at that moment,
- * names the build to bind instead; nothing else is tried when it is set. */
+ * keeps it -, then /opt/rocm/lib/librccl.so.1).  The library reads no environment variable for this: a site's own RCCL
+ * build is chosen the way any shared library is, through the loader's search path. */
 #define PMX_UNIQUE_ID_BYTES 128
 #define PMX_MAX_LOCAL_DEVICES 16
 typedef struct pmx_mgpu pmx_mgpu;
@@ -298,9 +302,9 @@ int pmx_mgpu_merkle_2to1_dev(pmx_mgpu *g, uint64_t *const *d_nodes, uint64_t *co
 /* Host leaves [n_leaves][4] -> root [4] (single-process groups). */
 int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t n_leaves, uint64_t *root);
 
-/* (The library's own test hooks - fault injection in the host fan-out, device groups whose slots share one GPU - are
- * declared in poseidon_mi355x_testing.h.  They are inert unless the process runs with PMX_TEST_HOOKS=1 and are not part
- * of this ABI.) */
+/* (Test hooks of the device-group code - fault injection in the host fan-out, device groups whose slots share one GPU, a
+ * named collective library - are declared in poseidon_mi355x_testing.h and exist only in libposeidon_mi355x_test.so, a
+ * second build of the same objects; this library neither exports nor contains them.) */
 
 /* ---- diagnostics ---------------------------------------------------------------------------------------
  * The binding roofline of these kernels is the issue rate of v_mad_u64_u32 (one per 32x32-bit limb product), not

@@ -1,11 +1,13 @@
 /*
- * poseidon_mi355x_testing.h -- test hooks of libposeidon_mi355x.so.  NOT part of the product ABI (poseidon_mi355x.h),
+ * poseidon_mi355x_testing.h -- test hooks of the device-group code.  NOT part of the product ABI (poseidon_mi355x.h),
  * not in the Rust binding; the reference has no counterpart (it has no multi-device code at all,
  * src/poseidon/mod.rs:62-183).
  *
- * The hooks live in the shipped library so that the tests exercise the very binary that ships, but they are inert
- * unless the PROCESS runs with the environment variable PMX_TEST_HOOKS=1 (read once, at the first hook call or group
- * creation): otherwise every setter returns PMX_ERR_UNSUPPORTED and changes nothing.  State is process-wide and atomic.
+ * These symbols exist ONLY in libposeidon_mi355x_test.so: the shipped objects with pmx_mgpu.cpp compiled -DPMX_TEST_HOOKS
+ * (sponge_amd/csrc/Makefile).  libposeidon_mi355x.so, the library that ships, neither exports them nor contains the state
+ * they set (tests/test_abi_and_host.py checks both export tables).  State is process-wide and atomic.  The test build also
+ * reads PMX_RCCL_LIBRARY=<path> when the first group is formed and binds THAT collective library (the tests' stand-in,
+ * tests/fake_rccl, when the ranks of a rehearsal are separate processes); the shipped library binds RCCL by SONAME only.
  */
 #ifndef POSEIDON_MI355X_TESTING_H
 #define POSEIDON_MI355X_TESTING_H
@@ -14,7 +16,7 @@
 extern "C" {
 #endif
 
-/* 1 when PMX_TEST_HOOKS=1 was in the environment, else 0. */
+/* 1 (the test build is loaded). */
 int pmx_test_hooks_enabled(void);
 
 /* The host fan-out of pmx_mgpu_permute_batch / _hash_batch fails on local slot `fail_local` (-1: off) and, with

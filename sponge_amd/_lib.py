@@ -10,6 +10,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libposeidon_mi355x.so")
+# the same library with the device-group test hooks compiled in (csrc/Makefile: -DPMX_TEST_HOOKS; include/poseidon_mi355x_testing.h).
+# Only tests and rehearsals load it, and only by asking for it in code (use_test_library) - never by an environment variable.
+TEST_LIB_PATH = os.path.join(HERE, "libposeidon_mi355x_test.so")
 
 PMX_OK = 0
 PMX_ERR_CONFIG = -1
@@ -147,7 +150,7 @@ SIGNATURES = {
     "pmx_diag_issue_slot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(PmxIssueSlot)]),
 }
 
-# include/poseidon_mi355x_testing.h: inert unless the process runs with PMX_TEST_HOOKS=1 (the library's own tests)
+# include/poseidon_mi355x_testing.h: exported by libposeidon_mi355x_test.so only
 TEST_HOOK_SIGNATURES = {
     "pmx_test_hooks_enabled": (ctypes.c_int, []),
     "pmx_mgpu_test_fault": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
@@ -155,17 +158,42 @@ TEST_HOOK_SIGNATURES = {
 }
 
 _lib = None
+_path = LIB_PATH
+_hooks = False
+
+
+def use_library(path: str, test_hooks: bool = False) -> None:
+    """Bind another build of the library (tests only: the test-hook build, a coverage build).  Before the first lib()."""
+    global _path, _hooks
+    if _lib is not None and os.path.abspath(path) != os.path.abspath(_path):
+        raise RuntimeError("use_library() after another build of the library was loaded")
+    _path, _hooks = path, test_hooks
+
+
+def use_test_library() -> None:
+    """Bind libposeidon_mi355x_test.so (the shipped objects + the device-group test hooks) instead of the shipped library.
+    Must be called before the first lib() of the process; tests and rehearsals only."""
+    use_library(TEST_LIB_PATH, test_hooks=True)
+
+
+def is_test_library() -> bool:
+    return _hooks
+
+
+def library_path() -> str:
+    return _path
 
 
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(_path):
             raise ImportError(
-                f"{LIB_PATH} is missing: build it with `make -C sponge_amd/csrc` "
+                f"{_path} is missing: build it with `make -C sponge_amd/csrc` "
                 "(or __graft_entry__.build()). There is no CPU fallback.")
-        handle = ctypes.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in list(SIGNATURES.items()) + list(TEST_HOOK_SIGNATURES.items()):
+        handle = ctypes.CDLL(_path)
+        sigs = list(SIGNATURES.items()) + (list(TEST_HOOK_SIGNATURES.items()) if _hooks else [])
+        for name, (restype, argtypes) in sigs:
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes

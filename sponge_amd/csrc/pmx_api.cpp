@@ -18,6 +18,7 @@
 #include "pmx_internal.hpp"
 #include "pmx_prepare.hpp"
 #include "pmx_launch.hpp"
+#include "pmx_sponge_plan.hpp"
 
 namespace pmx {
 
@@ -154,9 +155,10 @@ static int ctx_free(pmx_ctx *ctx) {
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     // (the caller's streams are the caller's to drain before it destroys the context, as with every *_dev call)
-    for (auto &kv : ctx->pass_blocks)
-        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-    for (const pmx_ctx::RetiredBlock &r : ctx->pass_retired) (void)hipFree(r.ptr);
+    for (pmx_ctx::PassBlock &b : ctx->pass_pool) {
+        if (b.done) (void)hipEventDestroy(b.done);
+        if (b.ptr) (void)hipFree(b.ptr);
+    }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->d_consts) (void)hipFree(ctx->d_consts);
     delete ctx;
@@ -507,63 +509,67 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
 }
 
 // ---- duplex sponge driver ------------------------------------------------------------------------
-// The pass driver of the wide states launches one kernel per permutation a sponge of the call can need: a call is limited to
-// kMaxPasses of them (65536 rates of elements per sponge and call - 16 MiB at rate 8; longer inputs are absorbed in several calls,
-// which is the same thing to a duplex sponge).  The per-lane kernels of t = 3 and of the run-time-width engine loop inside ONE
-// launch and have no such limit.
-static constexpr int kMaxPasses = 65536;  // launches = permutations a sponge of the call can need
-static int check_pass_count(const pmx_ctx *ctx, int op, size_t n, size_t len, const char *who) {
-    EngineInfo info;
-    if (describe_launch(ctx->dev, ctx->t, op, n, len, &info) == hipSuccess && info.launches > kMaxPasses)
-        return set_error(PMX_ERR_ARG, "%s: %zu elements per sponge is more than 65536 rates (%u) in one call on this width; split the call", who, len,
-                         ctx->dev.rounds.rate);
+// The pass drivers launch one kernel per permutation a sponge of the call can need: a call is limited to kMaxPasses of them
+// (65536 rates of elements per sponge and call - 16 MiB at rate 8; longer inputs are absorbed in several calls, which is the same
+// thing to a duplex sponge).  The limit is the same for EVERY absorb and squeeze call, whichever engine the width and the batch
+// size select (the per-lane kernels loop inside one launch and would not need it: a caller's length limit must not depend on
+// its batch size).
+static constexpr size_t kMaxPasses = 65536;  // launches = permutations a sponge of the call can need
+static int check_pass_count(const pmx_ctx *ctx, int op, size_t /*n*/, size_t len, const char *who) {
+    const uint32_t rate = ctx->dev.rounds.rate;
+    const size_t passes = rate == 0 ? 0 : (op == PMX_OP_SQUEEZE ? squeeze_passes(len, rate) : absorb_passes(len, rate));
+    if (passes > kMaxPasses + 1)     // (passes - 1 permutation launches)
+        return set_error(PMX_ERR_ARG, "%s: %zu elements per sponge is more than 65536 rates (%u) in one call; split the call", who, len, rate);
     return PMX_OK;
 }
 
-// PassScratch::get for a context: the block of this caller stream, grown if needed (called with ctx->pass_lock held).
-// Housekeeping on the way: a retired block is freed once its stream has drained, and when a caller has gone through many
-// streams the blocks of the idle (or destroyed) ones are given back - a stream with work in flight keeps its block.
-static bool stream_idle(hipStream_t st) {
-    const hipError_t e = hipStreamQuery(st);
-    if (e == hipErrorNotReady) return false;
-    if (e != hipSuccess) (void)hipGetLastError();   // a stream that no longer exists: nothing of it can be in flight
-    return true;
-}
+// PassScratch::get / done for a context (called with ctx->pass_lock held).  Nothing on this path frees memory (hipFree waits for
+// the whole device) or asks a CALLER's stream anything (the handle may belong to a stream that is being captured, or that is gone):
+// a block is released by the context's own event, recorded behind the last launch that uses it.
 static hipError_t ctx_pass_scratch(void *owner, hipStream_t st, size_t bytes, uint32_t **out) {
     pmx_ctx *ctx = static_cast<pmx_ctx *>(owner);
-    for (size_t i = 0; i < ctx->pass_retired.size();) {
-        if (stream_idle(ctx->pass_retired[i].stream)) {
-            (void)hipFree(ctx->pass_retired[i].ptr);
-            ctx->pass_retired[i] = ctx->pass_retired.back();
-            ctx->pass_retired.pop_back();
-        } else {
-            ++i;
-        }
-    }
-    constexpr size_t kMaxStreams = 16;
-    if (ctx->pass_blocks.size() > kMaxStreams) {
-        for (auto it = ctx->pass_blocks.begin(); it != ctx->pass_blocks.end();) {
-            if (it->first != st && stream_idle(it->first)) {
-                if (it->second.ptr) (void)hipFree(it->second.ptr);
-                it = ctx->pass_blocks.erase(it);
-            } else {
-                ++it;
+    pmx_ctx::PassBlock *pick = nullptr;
+    for (pmx_ctx::PassBlock &b : ctx->pass_pool)            // the block this stream used last: ordered behind that use by the stream itself
+        if (b.recorded && b.stream == st && b.bytes >= bytes) { pick = &b; break; }
+    if (!pick) {
+        for (pmx_ctx::PassBlock &b : ctx->pass_pool) {      // the smallest idle block that is large enough
+            if (b.bytes < bytes || (pick && pick->bytes <= b.bytes)) continue;
+            if (b.recorded && hipEventQuery(b.done) != hipSuccess) {
+                (void)hipGetLastError();                    // not ready - or not queryable (recorded into a capture): not idle
+                continue;
             }
+            pick = &b;
         }
     }
-    pmx_ctx::PassBlock &b = ctx->pass_blocks[st];
-    if (b.bytes < bytes) {
-        size_t want = b.bytes * 2 > bytes ? b.bytes * 2 : bytes;
-        want = (want + 4095) & ~(size_t)4095;
-        void *fresh = nullptr;
-        const hipError_t e = hipMalloc(&fresh, want);
+    if (!pick) {
+        pmx_ctx::PassBlock fresh;
+        size_t want = (bytes + 4095) & ~(size_t)4095;
+        for (const pmx_ctx::PassBlock &b : ctx->pass_pool)  // grow in doublings: an outgrown block stays in the pool for smaller calls
+            if (b.bytes * 2 > want && b.bytes < bytes) want = b.bytes * 2;
+        hipError_t e = hipMalloc(&fresh.ptr, want);
         if (e != hipSuccess) return e;
-        if (b.ptr) ctx->pass_retired.push_back({b.ptr, st});   // work already enqueued on `st` may still read it
-        b.ptr = fresh;
-        b.bytes = want;
+        e = hipEventCreateWithFlags(&fresh.done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipFree(fresh.ptr);
+            return e;
+        }
+        fresh.bytes = want;
+        ctx->pass_pool.push_back(fresh);
+        pick = &ctx->pass_pool.back();
     }
-    *out = static_cast<uint32_t *>(b.ptr);
+    pick->stream = st;
+    pick->recorded = false;      // in use by a call that is being enqueued: `done` records the event
+    *out = static_cast<uint32_t *>(pick->ptr);
     return hipSuccess;
+}
+static void ctx_pass_done(void *owner, hipStream_t st, uint32_t *block) {
+    pmx_ctx *ctx = static_cast<pmx_ctx *>(owner);
+    for (pmx_ctx::PassBlock &b : ctx->pass_pool) {
+        if (b.ptr != block) continue;
+        if (hipEventRecord(b.done, st) != hipSuccess) (void)hipGetLastError();   // (then only this stream takes the block again)
+        b.recorded = true;
+        return;
+    }
 }
 
 extern "C" int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uint32_t *d_tag, uint32_t *d_index,
@@ -577,7 +583,7 @@ extern "C" int pmx_sponge_absorb_batch_dev(pmx_ctx *ctx, uint64_t *d_states, uin
     PMX_ABI_BEGIN("pmx_sponge_absorb_batch_dev")
     PMX_BIND(ctx);
     std::lock_guard<std::mutex> lock(ctx->pass_lock);
-    PMX_HIP(launch_absorb(ctx->dev, ctx->t, d_states, d_tag, d_index, d_in, in_len, n, (hipStream_t)stream, PassScratch{ctx, ctx_pass_scratch}));
+    PMX_HIP(launch_absorb(ctx->dev, ctx->t, d_states, d_tag, d_index, d_in, in_len, n, (hipStream_t)stream, PassScratch{ctx, ctx_pass_scratch, ctx_pass_done}));
     return PMX_OK;
     PMX_ABI_END
 }
@@ -593,7 +599,7 @@ extern "C" int pmx_sponge_squeeze_batch_dev(pmx_ctx *ctx, uint64_t *d_states, ui
     PMX_ABI_BEGIN("pmx_sponge_squeeze_batch_dev")
     PMX_BIND(ctx);
     std::lock_guard<std::mutex> lock(ctx->pass_lock);
-    PMX_HIP(launch_squeeze(ctx->dev, ctx->t, d_states, d_tag, d_index, d_out, out_len, n, (hipStream_t)stream, PassScratch{ctx, ctx_pass_scratch}));
+    PMX_HIP(launch_squeeze(ctx->dev, ctx->t, d_states, d_tag, d_index, d_out, out_len, n, (hipStream_t)stream, PassScratch{ctx, ctx_pass_scratch, ctx_pass_done}));
     return PMX_OK;
     PMX_ABI_END
 }

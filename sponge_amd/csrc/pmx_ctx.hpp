@@ -5,7 +5,6 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "../../include/poseidon_mi355x.h"
@@ -25,16 +24,15 @@ struct pmx_ctx {
     // handed out by pmx_ctx_acquire are shared between sponges (and threads), so those entry points take this lock;
     // the *_dev entry points only read the immutable fields and enqueue on the caller's stream.
     std::mutex host_lock;
-    // Pass lists of the wide-state absorb / squeeze drivers (pmx_device.hip: sponge_passes): one grow-only device block per
-    // CALLER STREAM - calls enqueued on one stream run one after the other, so they can share a block; calls on different
-    // streams get different ones and stay independent.  A block that is outgrown may still be in use by work already
-    // enqueued: it is retired, not freed, until the context goes.  pass_lock is held while a driver call enqueues, which
-    // also keeps two threads from interleaving their launches on one stream of this context.
-    struct PassBlock { void *ptr = nullptr; size_t bytes = 0; };
-    struct RetiredBlock { void *ptr; hipStream_t stream; };
+    // Pass lists of the absorb / squeeze drivers that run as passes (pmx_device.hip: sponge_passes): a pool of device blocks, each
+    // with an event the CONTEXT owns, recorded on the caller's stream behind the last launch that uses the block.  A call takes the
+    // block its stream used last (stream order makes that safe while the earlier call is still running), else any block whose event
+    // has completed, else a new one; nothing is ever freed or queried through a caller's stream handle on the enqueue path - the
+    // blocks go when the context goes.  pass_lock is held while a driver call enqueues, which also keeps two threads from
+    // interleaving their launches on one stream of this context.
+    struct PassBlock { void *ptr = nullptr; size_t bytes = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool recorded = false; };
     std::mutex pass_lock;
-    std::unordered_map<hipStream_t, PassBlock> pass_blocks;
-    std::vector<RetiredBlock> pass_retired;
+    std::vector<PassBlock> pass_pool;
     // pmx_ctx_acquire / pmx_ctx_release bookkeeping (0 for contexts made by pmx_ctx_create)
     uint64_t cache_key = 0;
     long cache_refs = 0;

@@ -1391,6 +1391,7 @@ struct Launch {
             // handed out blocks whose earlier use was still in flight; tools/soak.py lost sponges and took a memory fault that way)
             e = provider.get(provider.owner, st, (head + 2 * n) * 4, &scratch);
             if (e != hipSuccess) return e;
+            // (from here on every way out passes provider.done: the block is released by the event recorded there)
             lists[0] = scratch + head;
             lists[1] = scratch + head + n;
             e = hipMemsetAsync(scratch, 0, head * 4, st);
@@ -1405,6 +1406,7 @@ struct Launch {
                                c.consts, states, tag, index, io, len, p, last, lists[p & 1], scratch + p, lists[(p + 1) & 1], scratch + p + 1);
             e = hipGetLastError();
         }
+        if (scratch && provider.done) provider.done(provider.owner, st, scratch);   // behind the last launch that reads the lists
         return e;
     }
     // what a launch of `op` would run on (pmx_ctx_engine_info): filled by the engine, completed per kernel family here

@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256) issue_stream_kernel(unsigned *out, int tr
 }  // namespace
 
 extern "C" int pmx_diag_issue_slot(int device, int waves_per_simd, double seconds, pmx_issue_slot *out) {
+    PMX_ABI_BEGIN("pmx_diag_issue_slot")      // (std::vector below: nothing may unwind through the C ABI)
     if (!out) return set_error(PMX_ERR_ARG, "pmx_diag_issue_slot: null pointer");
     *out = pmx_issue_slot{};
     const int ndev = pmx_device_count();
@@ -184,7 +185,9 @@ extern "C" int pmx_diag_issue_slot(int device, int waves_per_simd, double second
     const int n_cu = prop.multiProcessorCount, blocks = n_cu * waves_per_simd;   // a block = one wave on each SIMD of a CU
     int cu_lds = 0;
     if (hipDeviceGetAttribute(&cu_lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess || cu_lds <= 0) cu_lds = 160 * 1024;
-    const size_t lds = (size_t)(cu_lds / waves_per_simd) - 1024;                 // k blocks fit a CU, k + 1 do not
+    size_t lds = (size_t)(cu_lds / waves_per_simd) - 1024;                       // k blocks fit a CU, k + 1 do not
+    int block_lds = 0;                                                           // (one block per CU: no more than a workgroup may ask for - still more than half the CU's)
+    if (hipDeviceGetAttribute(&block_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && block_lds > 0 && lds > (size_t)block_lds) lds = (size_t)block_lds;
     const int trips = 256;                                                       // 65,536 instructions per lane and launch
     unsigned *d_out = nullptr;
     hipStream_t st = nullptr;
@@ -236,4 +239,5 @@ extern "C" int pmx_diag_issue_slot(int device, int waves_per_simd, double second
     out->compute_units = n_cu;
     out->launches = launches;
     return PMX_OK;
+    PMX_ABI_END
 }

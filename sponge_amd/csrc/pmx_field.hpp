@@ -668,6 +668,8 @@ PMX_FN Abi fe_to_abi_scaled(const Fe &x, const FieldRt &f) {
 // a + b mod p on two fully reduced ABI residues (p32: the modulus as 8 x 32-bit limbs, FieldRt::io + kIoP32): one carry chain
 // up, one borrow chain down, a select - the `state[capacity + i] += element` of the sponge drivers (mod.rs:128,143), which is
 // a field addition and needs no Montgomery arithmetic.  a, b < p < 2^255: the sum fits 256 bits and one subtraction reduces it.
+// (Unreduced device-resident data - the host entry points reject it - is still processed modulo p here as in the per-lane
+// kernels: the carry out of the 256-bit sum takes part in the select, so a sum of 2^256 or more is reduced once as well.)
 PMX_FN Abi abi_add_mod(const Abi &a, const Abi &b, const uint32_t *p32) {
     uint32_t sum[8], dif[8];
     uint32_t carry = 0, borrow = 0;
@@ -684,8 +686,9 @@ PMX_FN Abi abi_add_mod(const Abi &a, const Abi &b, const uint32_t *p32) {
         borrow = (uint32_t)(v >> 32) & 1u;
     }
     Abi r;
+    const bool keep_sum = borrow && !carry;   // sum < p
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.w[i] = borrow ? sum[i] : dif[i];
+    for (int i = 0; i < 8; ++i) r.w[i] = keep_sum ? sum[i] : dif[i];
     return r;
 }
 

@@ -16,12 +16,14 @@ hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_
                        size_t n, hipStream_t st);
 // out[i] = 2-to-1 compression of in[2i], in[2i+1]   (rate >= 2)
 hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st);
-// Device scratch for the pass lists of the wide-state drivers (pmx_device.hip: sponge_passes): `get` hands out at least
-// `bytes` bytes that stay valid for everything enqueued on `st` by this call (pmx_api.cpp: one grow-only block per caller
-// stream, owned by the context).  Engines that need no lists never call it.
+// Device scratch for the pass lists of the drivers that run as passes (pmx_device.hip: sponge_passes): `get` hands out at least
+// `bytes` bytes that stay valid for everything enqueued on `st` by this call, `done` is called once behind the call's last launch
+// (pmx_api.cpp: a pool of blocks owned by the context, each released by an event recorded there).  Engines that need no lists
+// call neither.
 struct PassScratch {
-    void *owner;
-    hipError_t (*get)(void *owner, hipStream_t st, size_t bytes, uint32_t **out);
+    void *owner = nullptr;
+    hipError_t (*get)(void *owner, hipStream_t st, size_t bytes, uint32_t **out) = nullptr;
+    void (*done)(void *owner, hipStream_t st, uint32_t *block) = nullptr;
 };
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st, const PassScratch &scratch);

@@ -101,10 +101,9 @@ PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
 }
 
 // One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's
-// correction, as eight 64-bit word sums with carries (mfma_row_words), re-cut into ten 29-bit limbs, one Montgomery step
-// (mfma_row_reduce): V 2^-29 mod p, below 2^243 + p.  Two halves, because the device form runs them beside the matrix-core products
-// of the NEXT row (matrix_rows_mfma_io), a half per stage of that row's table.
-PMX_FN void mfma_row_words(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f, uint32_t (&wd)[9]) {
+// correction, as eight 64-bit word sums with carries, re-cut into ten 29-bit limbs, one Montgomery step: V 2^-29 mod p, below 2^243 + p.
+PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
+    uint32_t wd[9];
     // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from a
     // register the compiler cannot see through - f.unit is 1 - or it would turn each into a sign extension, a 64-bit shift and a
     // 64-bit add.  |t| < 2^50, so the carry into the next word (t >> 32) is the high register as it stands.
@@ -121,8 +120,6 @@ PMX_FN void mfma_row_words(const int32_t (&R)[8][4], const long long *corr, cons
         carry = (int)(t >> 32);
     }
     wd[8] = (uint32_t)carry;   // V >= 0: the top carry is not negative
-}
-PMX_FN Fe mfma_row_reduce(const uint32_t (&wd)[9], const FieldRt &f) {
     uint32_t L[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -145,11 +142,6 @@ PMX_FN Fe mfma_row_reduce(const uint32_t (&wd)[9], const FieldRt &f) {
         acc >>= kW;
     }
     return row;
-}
-PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
-    uint32_t wd[9];
-    mfma_row_words(R, corr, f, wd);
-    return mfma_row_reduce(wd, f);
 }
 
 #if !defined(__HIPCC__)
@@ -203,26 +195,8 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
 // come back unspecified, like matrix_rows_rolled.  s norm.  `tile`: TILE_STEPS KiB of LDS shared by the workgroup's THREADS
 // threads, all of which must arrive here together (two barriers per stage of a row) with every lane active.
 // General form: NIN input elements at `in`, rows [lo, hi) of NOUT into out (which may alias in: the inputs are consumed first).
-//
-// Software pipeline over the rows (round 5): a row's 2 NQ matrix-core products keep the SIMD's matrix pipe busy for 64 NQ clocks
-// during which the wave that issued them has nothing else to issue - and the finish of a row (exchange, word sums, re-cut, Montgomery
-// step: ~170 VALU instructions) depends on nothing but that row's sums.  So the finish of row i - 1 is issued BESIDE the products of
-// row i: the sums move out of the accumulators (the lane exchange does that anyway), the accumulators start row i, and the two
-// halves of the finish (mfma_row_words / mfma_row_reduce) sit in the same basic blocks as the products of the first / the last
-// stage of row i's table, where PMX_MFMA_INTERLEAVE pins the order "one product, a few VALU instructions" (sched_group_barrier).
-#ifndef PMX_MFMA_PIPELINE
-#define PMX_MFMA_PIPELINE 1
-#endif
-template <int N_MFMA, int VALU_PER>
-__device__ __forceinline__ void mfma_interleave() {
-    if constexpr (N_MFMA > 0) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);   // VALU
-        mfma_interleave<N_MFMA - 1, VALU_PER>();
-    }
-}
-#ifndef PMX_MFMA_INTERLEAVE
-#define PMX_MFMA_INTERLEAVE 1   // 0: the compiler's own placement of the finish between the products
+#ifndef PMX_MFMA_LDS_AHEAD
+#define PMX_MFMA_LDS_AHEAD 8   // k-steps of the A operand in flight between the tile and the matrix cores (4 registers each)
 #endif
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
@@ -239,7 +213,7 @@ __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scrat
         for (int u = 0; u < 4; ++u) lane32_swap(W[8 * q + u], W[8 * q + 4 + u]);
     }
     const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(NIN));
-    Fe last = fe_zero();   // the row finished last: row T - 1 when hi == T (the rows outside [lo, hi) are unspecified, so nothing of `out` is kept alive across the loop)
+    Fe last = out[T - 1];
     // this thread's share of a stage of the table: fetched from global memory one stage ahead, so that the fetch runs behind
     // the multiplications of the stage before instead of between the two barriers
     constexpr int kPer = (TILE_STEPS * 64 + THREADS - 1) / THREADS;
@@ -253,37 +227,48 @@ __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scrat
             if (e < count) pre[q] = src[e];
         }
     };
-    mfma_v16i d1, d2;
-    // one stage of row i's table through the tile and its products into d1 / d2; `beside(stage)` is VALU work that does not depend on them
-    auto products = [&](uint32_t i, auto st, auto &&beside) {
-        constexpr int stage = decltype(st)::value, steps = stage == NS - 1 ? NQ - stage * TILE_STEPS : TILE_STEPS;
-        __syncthreads();   // the readers of the stage before are done with the tile
+    if (lo < hi) fetch(lo, 0);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (uint32_t i = lo; i < hi; ++i) {
+        mfma_v16i d1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d2 = d1;
+        static_for<0, NS>([&](auto st) {
+            constexpr int stage = decltype(st)::value, steps = stage == NS - 1 ? NQ - stage * TILE_STEPS : TILE_STEPS;
+            __syncthreads();   // the readers of the stage before are done with the tile
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const uint32_t e = threadIdx.x + q * THREADS;
-            if (e < (uint32_t)steps * 64) tile[e] = pre[q];
-        }
-        __syncthreads();
-        if constexpr (stage + 1 < NS) fetch(i, stage + 1);
-        else if (i + 1 < hi) fetch(i + 1, 0);
+            for (int q = 0; q < kPer; ++q) {
+                const uint32_t e = threadIdx.x + q * THREADS;
+                if (e < (uint32_t)steps * 64) tile[e] = pre[q];
+            }
+            __syncthreads();
+            if constexpr (stage + 1 < NS) fetch(i, stage + 1);
+            else if (i + 1 < hi) fetch(i + 1, 0);
+            // The A operand of up to kAhead k-steps is read out of the tile BEFORE the first product of the stage, and a slot is
+            // refilled as soon as its pair of products has been issued: left to itself the compiler reads one or two k-steps ahead
+            // and then waits the whole LDS round trip (~120 clocks, against the 64 a pair of products keeps the matrix pipe busy)
+            // in front of every pair - a wave spent 22 % of its cycles in s_waitcnt that way (profiles/r04/s_pmc_window_kernels_c3_c2.txt).
+            constexpr int kAhead = steps < PMX_MFMA_LDS_AHEAD ? steps : PMX_MFMA_LDS_AHEAD;
+            mfma_v4i a[kAhead];
 #pragma unroll
-        for (int qq = 0; qq < steps; ++qq) {
-            constexpr int q0 = stage * TILE_STEPS;
-            const int q = q0 + qq;
-            const mfma_v4i a = tile[qq * 64 + lane];
-            const mfma_v4i b1 = {(int)W[8 * q + 0], (int)W[8 * q + 1], (int)W[8 * q + 2], (int)W[8 * q + 3]};
-            const mfma_v4i b2 = {(int)W[8 * q + 4], (int)W[8 * q + 5], (int)W[8 * q + 6], (int)W[8 * q + 7]};
-            d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, d1, 0, 0, 0);   // states 0-31 of the wave
-            d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b2, d2, 0, 0, 0);   // states 32-63
-        }
-        const auto nv = beside(st);
-        constexpr int n_valu = decltype(nv)::value;   // VALU instructions of the work beside (an estimate: the tail follows the last product)
-        // the order inside this block: a product, then its share of the VALU instructions issued beside it
-        if constexpr (PMX_MFMA_INTERLEAVE && n_valu > 0) mfma_interleave<2 * steps, (n_valu + 2 * steps - 1) / (2 * steps)>();
-    };
-    // register v of d1 / d2 holds row 8 (v / 4) + 4 (lane / 32) + v % 4 of the column lane % 32: after the exchange
-    // d1[4g + r] is row 8g + r and d2[4g + r] row 8g + 4 + r of THIS lane's state, i.e. word 2g of the row is d1[4g ..], word 2g + 1 d2[4g ..]
-    auto take_sums = [&](int32_t (&R)[8][4]) {
+            for (int qq = 0; qq < kAhead; ++qq) a[qq] = tile[qq * 64 + lane];
+            PMX_SCHED_FENCE();   // (the reads stay in front: the scheduler would sink them next to their products again)
+#pragma unroll
+            for (int qq = 0; qq < steps; ++qq) {
+                constexpr int q0 = stage * TILE_STEPS;
+                const int q = q0 + qq;
+                const mfma_v4i b1 = {(int)W[8 * q + 0], (int)W[8 * q + 1], (int)W[8 * q + 2], (int)W[8 * q + 3]};
+                const mfma_v4i b2 = {(int)W[8 * q + 4], (int)W[8 * q + 5], (int)W[8 * q + 6], (int)W[8 * q + 7]};
+                d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[qq % kAhead], b1, d1, 0, 0, 0);   // states 0-31 of the wave
+                d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[qq % kAhead], b2, d2, 0, 0, 0);   // states 32-63
+                if (qq + kAhead < steps) {
+                    PMX_SCHED_FENCE();
+                    a[qq % kAhead] = tile[(qq + kAhead) * 64 + lane];
+                    PMX_SCHED_FENCE();
+                }
+            }
+        });
+        // register v of d1 / d2 holds row 8 (v / 4) + 4 (lane / 32) + v % 4 of the column lane % 32: after the exchange
+        // d1[4g + r] is row 8g + r and d2[4g + r] row 8g + 4 + r of THIS lane's state, i.e. word 2g of the row is d1[4g ..], word 2g + 1 d2[4g ..]
+        int32_t R[8][4];
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             uint32_t x = (uint32_t)d1[v], y = (uint32_t)d2[v];
@@ -291,50 +276,9 @@ __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scrat
             R[2 * (v / 4)][v % 4] = (int32_t)x;
             R[2 * (v / 4) + 1][v % 4] = (int32_t)y;
         }
-    };
-    const mfma_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (lo < hi) {
-        fetch(lo, 0);
-#if PMX_MFMA_PIPELINE
-        d1 = zero, d2 = zero;
-        static_for<0, NS>([&](auto st) { products(lo, st, [](auto) { return std::integral_constant<int, 0>{}; }); });
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        for (uint32_t i = lo + 1; i < hi; ++i) {      // the products of row i beside the finish of row i - 1 (never the last row of the layer: a scratch slot)
-            int32_t R[8][4];
-            take_sums(R);
-            d1 = zero, d2 = zero;
-            uint32_t wd[9];
-            static_for<0, NS>([&](auto st) {
-                products(i, st, [&](auto s2) {
-                    constexpr int stage = decltype(s2)::value;
-                    if constexpr (stage == 0) {
-                        mfma_row_words(R, corr + (size_t)(i - 1) * 8, f, wd);
-                        // (nothing but the last stage's half reads the words: without this the compiler sinks the word sums into that
-                        // stage's block and the first stage's products run with nothing beside them)
-                        if constexpr (NS > 1) asm volatile("" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]), "+v"(wd[3]), "+v"(wd[4]), "+v"(wd[5]), "+v"(wd[6]), "+v"(wd[7]), "+v"(wd[8]));
-                    }
-                    if constexpr (stage == NS - 1) sc.set(i - 1, mfma_row_reduce(wd, f));
-                    return std::integral_constant<int, (stage == 0 ? 48 : 0) + (stage == NS - 1 ? 70 : 0)>{};
-                });
-            });
-        }
-        {
-            int32_t R[8][4];
-            take_sums(R);
-            last = mfma_row_finish(R, corr + (size_t)(hi - 1) * 8, f);
-            if (hi < (uint32_t)T) sc.set(hi - 1, last);
-        }
-#else
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        for (uint32_t i = lo; i < hi; ++i) {
-            d1 = zero, d2 = zero;
-            static_for<0, NS>([&](auto st) { products(i, st, [](auto) { return std::integral_constant<int, 0>{}; }); });
-            int32_t R[8][4];
-            take_sums(R);
-            last = mfma_row_finish(R, corr + (size_t)i * 8, f);
-            if (i + 1 < (uint32_t)T) sc.set(i, last);
-        }
-#endif
+        const Fe row = mfma_row_finish(R, corr + (size_t)i * 8, f);
+        if (i + 1 < (uint32_t)T) sc.set(i, row);
+        else last = row;
     }
     static_for<0, T - 1>([&](auto i) { out[i] = sc.get(i); });
     out[T - 1] = last;

@@ -63,13 +63,18 @@ struct Rccl {
 Rccl &rccl_lib() {
     static Rccl *lib = [] {
         Rccl *r = new Rccl();
-        // PMX_RCCL_LIBRARY=<path>: bind THAT build of the collective library (a site's own RCCL; a process that already
-        // holds another copy - PyTorch's - would otherwise get that one by SONAME).  Nothing else is tried when it is set.
-        const char *chosen = std::getenv("PMX_RCCL_LIBRARY");
-        if (chosen && *chosen) {
-            r->handle = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
-        } else {
-            chosen = "librccl.so.1";
+        const char *chosen = "librccl.so.1";
+#ifdef PMX_TEST_HOOKS
+        // (test build only) PMX_RCCL_LIBRARY=<path>: bind THAT collective library - the tests' stand-in for ranks that are separate
+        // processes on one GPU (tests/fake_rccl).  Nothing else is tried when it is set.  The shipped library reads no environment
+        // variable here: it binds RCCL by SONAME, and a site's own build is chosen the way any shared library is (the loader's search path).
+        const char *named = std::getenv("PMX_RCCL_LIBRARY");
+        if (named && *named) {
+            chosen = named;
+            r->handle = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        } else
+#endif
+        {
             for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
                 r->handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
                 if (r->handle) break;
@@ -170,14 +175,16 @@ static int group_contexts(pmx_mgpu *g, const pmx_config *cfg) {
     return PMX_OK;
 }
 
-// Test hooks (include/poseidon_mi355x_testing.h; not part of the product ABI, not in the Rust binding).  They only take
-// effect in a process started with PMX_TEST_HOOKS=1 - anywhere else the setters answer PMX_ERR_UNSUPPORTED and the
-// library behaves as if they did not exist.  Process-wide, read by the fan-out's worker threads: atomics.
+// Test hooks (include/poseidon_mi355x_testing.h; not part of the product ABI, not in the Rust binding) exist ONLY in the test build of
+// this file (-DPMX_TEST_HOOKS: build/pmx_mgpu_test.o -> libposeidon_mi355x_test.so, every other object shared with the shipped library).
+// In libposeidon_mi355x.so the three queries below are compile-time constants and no hook symbol is exported.
 //   fault:          the host fan-out of the next calls fails on one local slot and / or behaves as if no worker thread
 //                   could be started (error carry-back and the serial path, on any box);
 //   shared device:  pmx_mgpu_create accepts the same device ordinal in several slots and more slots than visible devices,
 //                   so that every world > 1 branch below runs on a ONE-GPU box behind tests/fake_rccl (RCCL itself
 //                   refuses two ranks on one device).
+// Process-wide, read by the fan-out's worker threads: atomics.
+#ifdef PMX_TEST_HOOKS
 namespace {
 struct Hooks {
     std::atomic<int> fail_local{-1};
@@ -185,26 +192,26 @@ struct Hooks {
     std::atomic<bool> shared_device{false};
 };
 Hooks g_hooks;
-bool hooks_armed() {
-    static const bool armed = [] {
-        const char *e = std::getenv("PMX_TEST_HOOKS");
-        return e && e[0] == '1' && e[1] == 0;
-    }();
-    return armed;
-}
+inline int hook_fail_local() { return g_hooks.fail_local.load(); }
+inline bool hook_no_threads() { return g_hooks.no_threads.load(); }
+inline bool hook_shared_device() { return g_hooks.shared_device.load(); }
 }  // namespace
-extern "C" int pmx_test_hooks_enabled(void) { return hooks_armed() ? 1 : 0; }
+extern "C" int pmx_test_hooks_enabled(void) { return 1; }
 extern "C" int pmx_mgpu_test_fault(int fail_local, int no_threads) {
-    if (!hooks_armed()) return set_error(PMX_ERR_UNSUPPORTED, "test hooks are off (start the process with PMX_TEST_HOOKS=1)");
     g_hooks.fail_local.store(fail_local);
     g_hooks.no_threads.store(no_threads != 0);
     return PMX_OK;
 }
 extern "C" int pmx_mgpu_test_shared_device(int allow) {
-    if (!hooks_armed()) return set_error(PMX_ERR_UNSUPPORTED, "test hooks are off (start the process with PMX_TEST_HOOKS=1)");
     g_hooks.shared_device.store(allow != 0);
     return PMX_OK;
 }
+#else
+namespace {
+constexpr bool hook_no_threads() { return false; }
+constexpr bool hook_shared_device() { return false; }
+}  // namespace
+#endif
 
 extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *devices, pmx_mgpu **out) {
     PMX_ABI_BEGIN("pmx_mgpu_create")
@@ -213,7 +220,7 @@ extern "C" int pmx_mgpu_create(const pmx_config *cfg, int n_devices, const int *
     const int visible = pmx_device_count();
     if (visible == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
     if (int rc = rccl_ready()) return rc;
-    const bool shared = g_hooks.shared_device.load();   // test hook: slots may share a device (never set in production)
+    const bool shared = hook_shared_device();   // test build only: slots may share a device (constant false in the shipped library)
     const int max_slots = shared || visible > PMX_MAX_LOCAL_DEVICES ? PMX_MAX_LOCAL_DEVICES : visible;
     if (n_devices <= 0 || n_devices > max_slots) return set_error(PMX_ERR_ARG, "n_devices %d out of range [1,%d]", n_devices, max_slots);
     if (shared && !devices) return set_error(PMX_ERR_ARG, "shared-device groups (test hook) name their devices explicitly");
@@ -359,8 +366,11 @@ static int fan_out(pmx_mgpu *g, size_t n, const char *who, Work work) {
             size_t start = 0, count = 0;
             rc = local_span(g, n, l, &start, &count);
             if (!rc && count) {
-                if (g_hooks.fail_local.load() == (int)l) rc = set_error(PMX_ERR_HIP, "injected failure (pmx_mgpu_test_fault)");
-                else rc = work(l, start, count);
+#ifdef PMX_TEST_HOOKS
+                if (hook_fail_local() == (int)l) rc = set_error(PMX_ERR_HIP, "injected failure (pmx_mgpu_test_fault)");
+                else
+#endif
+                    rc = work(l, start, count);
             }
             if (rc) msgs[l] = pmx_last_error();   // the error text is thread-local: carry it back to the caller's thread
         } catch (...) {
@@ -381,7 +391,7 @@ static int fan_out(pmx_mgpu *g, size_t n, const char *who, Work work) {
     serial.reserve(L);
     for (size_t l = 1; l < L; ++l) {
         try {
-            if (g_hooks.no_threads.load()) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+            if (hook_no_threads()) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
             workers.th.emplace_back(run, l);
         } catch (const std::system_error &) {
             serial.push_back(l);

@@ -327,7 +327,7 @@ extern "C" int hc_field_op(const uint64_t modulus[4], int op, const uint64_t *a,
     } else if (op == 3) {
         store_abi(out, fe_to_abi(fe_from_abi(load_abi(a), f), f));
     } else if (op == 4) {
-        // the absorb step of sponge_pass_kernel: a + b on the ABI residues, no multiplication (pmx_device.hip)
+        // the absorb step of the pass kernels (sponge_walk, AbsorbAdjust): a + b on the ABI residues, no multiplication (pmx_device.hip)
         store_abi(out, abi_add_mod(load_abi(a), load_abi(b), f.io + kIoP32));
     } else {
         return PMX_ERR_ARG;

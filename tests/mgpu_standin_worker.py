@@ -2,14 +2,15 @@
 behind the stand-in collective library tests/fake_rccl (a child process of tests/test_gpu_mgpu_standin.py and of
 tools/mgpu_coverage.sh; never collected by pytest).
 
-    LD_LIBRARY_PATH=tests/fake_rccl:$LD_LIBRARY_PATH PMX_TEST_HOOKS=1 \
+    LD_LIBRARY_PATH=tests/fake_rccl:$LD_LIBRARY_PATH \
         python tests/mgpu_standin_worker.py WORLD OUT_JSON [LIBRARY]
 
 The product binds RCCL with dlopen("librccl.so.1"): with tests/fake_rccl first on LD_LIBRARY_PATH it gets the stand-in
 (asserted below through fake_rccl_marker - a run that silently bound the real RCCL fails).  The test hook
-pmx_mgpu_test_shared_device lets pmx_mgpu_create take device 0 in all WORLD slots.  No torch in this process (torch
-would map its own librccl first).  LIBRARY (optional) = another build of libposeidon_mi355x.so, e.g. the one with
-gcov counters in pmx_mgpu.o.
+pmx_mgpu_test_shared_device lets pmx_mgpu_create take device 0 in all WORLD slots: it exists only in
+libposeidon_mi355x_test.so (the shipped objects + pmx_mgpu.cpp compiled -DPMX_TEST_HOOKS), which is what this process binds.
+No torch in this process (torch would map its own librccl first).  LIBRARY (optional) = another test-hook build of the
+library, e.g. the one with gcov counters in pmx_mgpu.o.
 
 Each scenario appends {"name", "ok", "detail"} to OUT_JSON["scenarios"]; the reference has no counterpart for any of
 this (src/poseidon/mod.rs:62-183: states are independent, which is the whole contract the sharding relies on) - the
@@ -41,13 +42,15 @@ def main():
     try:
         from sponge_amd import _lib
         if len(sys.argv) > 3:
-            _lib.LIB_PATH = sys.argv[3]
+            _lib.use_library(sys.argv[3], test_hooks=True)
+        else:
+            _lib.use_test_library()
         import sponge_amd as S
         from sponge_amd import mgpu, synth
         from gpu_helpers import c_oracle, product_config
         lib = _lib.lib()
-        res["library"] = _lib.LIB_PATH
-        assert lib.pmx_test_hooks_enabled() == 1, "run with PMX_TEST_HOOKS=1"
+        res["library"] = _lib.library_path()
+        assert lib.pmx_test_hooks_enabled() == 1
         cfg = product_config(NAME)
         cr = c_oracle(NAME)
         # the copy the product binds: the one PMX_RCCL_LIBRARY names, else the same SONAME on the same search path

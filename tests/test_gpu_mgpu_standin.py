@@ -10,8 +10,8 @@ and its error carry-back, one-group-per-rank with first_rank != 0.  What it cann
 (tests/test_gpu_mgpu.py runs the same entry points on real RCCL with as many ranks as the box has GPUs).
 
 The stand-in is test infrastructure: it is found only because the child process below gets tests/fake_rccl first on
-LD_LIBRARY_PATH; the product is unchanged (the shared-device group needs the PMX_TEST_HOOKS=1 hook, which is inert in
-any other process).  The reference has no counterpart (src/poseidon/mod.rs:62-183: states are independent); expected
+LD_LIBRARY_PATH, and the shared-device group needs a hook that only libposeidon_mi355x_test.so has (the shipped objects with
+pmx_mgpu.cpp compiled -DPMX_TEST_HOOKS; the workers bind that build, the library that ships has no such code).  The reference has no counterpart (src/poseidon/mod.rs:62-183: states are independent); expected
 values are the C restatement's over the whole batch / tree."""
 import json
 import os
@@ -34,7 +34,7 @@ def _ensure_fake():
 
 
 def _child_env(libdir):
-    env = dict(os.environ, PMX_TEST_HOOKS="1")
+    env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = libdir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     return env
 
@@ -89,8 +89,8 @@ assert np.array_equal(cfg.context(0).permute_batch(st), c_oracle("bls_t3_a5_8_31
 
 
 def _xproc_env():
-    """ranks in different processes: the product is told WHICH collective library to bind (PMX_RCCL_LIBRARY, a product
-    feature: a site's own RCCL build) and the stand-in is told that its ranks are processes"""
+    """ranks in different processes: the test-hook build of the library is told WHICH collective library to bind
+    (PMX_RCCL_LIBRARY; the shipped library does not read it) and the stand-in is told that its ranks are processes"""
     return dict(os.environ, PMX_RCCL_LIBRARY=os.path.join(FAKE_DIR, "librccl.so.1"), FAKE_RCCL_XPROC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
 
 
@@ -131,13 +131,14 @@ def test_one_process_per_rank_on_one_gpu(world, shape, tmp_path):
 
 
 def test_a_named_collective_library_that_does_not_exist_is_reported(tmp_path):
-    """PMX_RCCL_LIBRARY names the build to bind; a path that cannot be loaded is PMX_ERR_RCCL with the loader's reason at
-    the first device-group call (nothing else is tried: a caller who names a library wants THAT library)."""
+    """(test-hook build) PMX_RCCL_LIBRARY names the collective library to bind; a path that cannot be loaded is PMX_ERR_RCCL with the
+    loader's reason at the first device-group call (nothing else is tried: a caller who names a library wants THAT library)."""
     code = r'''
 import sys
 sys.path.insert(0, %r)
 import sponge_amd as S
 from sponge_amd import _lib, mgpu
+_lib.use_test_library()          # (the shipped library does not read PMX_RCCL_LIBRARY)
 try:
     mgpu.unique_id()
     sys.exit(2)
@@ -170,3 +171,39 @@ def test_bench_multi_rank_path_runs_through_the_device_group(world, extra, tmp_p
     d = lines[0]
     assert d["verified"] is True and d["n_gpus"] == world and d["rccl"]["ranks"] == world, d
     assert "pmx_mgpu_create_rank" in d["rccl"]["via"] and "REHEARSAL" in d["config"]
+
+
+@pytest.mark.parametrize("world,form,extra", [(2, "ranks", ["--workload", "c2", "--total-log2", "16"]),
+                                              (8, "ranks", ["--workload", "c2", "--total-units", "100003"]),
+                                              (2, "single", ["--workload", "c2", "--total-units", "50001"]),
+                                              (8, "single", ["--workload", "c2", "--total-log2", "17"]),
+                                              (8, "single", ["--workload", "c5", "--total-log2", "17"]),
+                                              (4, "ranks", ["--workload", "c5", "--total-log2", "14"])])
+def test_bench_gpus_n_needs_no_launcher(world, form, extra, tmp_path):
+    """`python bench.py --gpus N` exactly as the driver spells it at N = 1 - no torch.distributed.run around it, no WORLD_SIZE in the
+    environment - must produce its ONE JSON line by itself.  form "ranks": bench.py starts `python -m torch.distributed.run ...` as a
+    CHILD process (before torch is imported, never exec) and exits with its code; form "single": --single-process, one process drives
+    all N device slots through pmx_mgpu_create (ncclCommInitAll).  On this one-GPU box the N ranks / slots share cuda:0 behind the
+    stand-in collective library (PMX_BENCH_REHEARSAL=group: test-hook build of the library): rc 0, one line, rccl.ranks = N,
+    verified = true (every rank's / device's gathered copy or tree top against the C restatement)."""
+    _ensure_fake()
+    root = os.path.dirname(HERE)
+    env = dict(_xproc_env(), PMX_BENCH_REHEARSAL="group")
+    if form == "single":
+        env.pop("FAKE_RCCL_XPROC")                     # the slots are threads of one process here
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--spinup-seconds", "0.05"] + extra
+    if form == "single":
+        cmd.append("--single-process")
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    text, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    lines = [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (text[-2000:], err[-3000:])
+    d = lines[0]
+    assert d["verified"] is True and d["n_gpus"] == world and d["rccl"]["ranks"] == world, d
+    assert d["cpu_baseline"] is None and d["gather_ms"] is not None and "REHEARSAL" in d["config"]
+    if form == "single":
+        assert "pmx_mgpu_create (ncclCommInitAll" in d["rccl"]["via"] and "launcher" in d["config"]
+    else:
+        assert "pmx_mgpu_create_rank" in d["rccl"]["via"] and "launching the ranks as a child process" in err

@@ -1,5 +1,5 @@
 """The absorb / squeeze batch driver on wide states (t = 4..9): passes of a wave-uniform permutation kernel
-(sponge_amd/csrc/pmx_sponge_plan.hpp, pmx_device.hip: sponge_pass_kernel) instead of a per-lane state machine, so that the
+(sponge_amd/csrc/pmx_sponge_plan.hpp, pmx_device.hip: sponge_first_kernel / permute_listed_kernel) instead of a per-lane state machine, so that the
 driver runs on the permutation engine of its width - the matrix-core one at t = 7..9.
 
 Reference semantics: absorb src/poseidon/mod.rs:232-254 + absorb_internal :121-150; squeeze_native_field_elements

@@ -447,7 +447,7 @@ def _toy_cfg(rate, capacity):
 
 
 def _run_passes(hc, cfg, state, tag, index, squeeze, elems_or_len):
-    """What pmx_device.hip's launch loop + sponge_pass_kernel do for ONE sponge: pass p moves chunk p-1 in memory, then
+    """What pmx_device.hip's launch loop + sponge_first_kernel / permute_listed_kernel do for ONE sponge: pass p moves chunk p-1 in memory, then
     permutes where the plan says; the mode words are read-only until the last pass."""
     hc.hc_sponge_pass.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32,
                                   ctypes.c_size_t, ctypes.c_void_p]

@@ -19,7 +19,6 @@ if [ "${PMX_COV_NO_BUILD:-0}" != "1" ]; then
 fi
 rm -f tests/cov/*.gcda
 COV="$ROOT/tests/cov/libposeidon_mi355x_cov.so"
-export PMX_TEST_HOOKS=1
 status=0
 for W in 2 3 8; do
     LD_LIBRARY_PATH="$ROOT/tests/fake_rccl:${LD_LIBRARY_PATH:-}" python3 tests/mgpu_standin_worker.py $W "$OUT/standin_w$W.json" "$COV" \
@@ -30,7 +29,7 @@ LD_LIBRARY_PATH="$ROOT/tests/fake_rccl/broken:${LD_LIBRARY_PATH:-}" python3 - "$
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from sponge_amd import _lib
-_lib.LIB_PATH = sys.argv[1]
+_lib.use_library(sys.argv[1], test_hooks=True)
 import sponge_amd as S
 from sponge_amd import mgpu
 from gpu_helpers import product_config
@@ -48,7 +47,7 @@ PMX_RCCL_LIBRARY=/nonexistent/librccl.so python3 - "$COV" > "$OUT/unloadable.log
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from sponge_amd import _lib
-_lib.LIB_PATH = sys.argv[1]
+_lib.use_library(sys.argv[1], test_hooks=True)
 import sponge_amd as S
 from sponge_amd import mgpu
 try:
