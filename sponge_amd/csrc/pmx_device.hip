@@ -39,10 +39,6 @@
 #define PMX_TU 0
 #endif
 
-#ifndef PMX_CONSTS_IN_LDS
-#define PMX_CONSTS_IN_LDS 1   // RegEngine: 1 = stage ARK/MDS in LDS (broadcast reads), 0 = scalar loads from global
-#endif
-
 namespace pmx {
 
 extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
@@ -51,28 +47,19 @@ extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 // RegEngine: t known at compile time, state in registers (internal field form).
 // LDS: [constants: n_const_words u32, rounded up to 16 B][staging: kThreads * T * 2 uint4]
 // ------------------------------------------------------------------------------------------------
-#ifndef PMX_REG_P_IN_VGPR
-#define PMX_REG_P_IN_VGPR 0   // modulus limbs in vector registers to free 9 SGPRs for the table stream: 46 -> 42 SGPR spills,
-                              // C2 +-0, hash -1.3 % (round 2 A/B)
-#endif
-#ifndef PMX_REG_THREADS
-#define PMX_REG_THREADS 256   // workgroup size of the t = 3 engine: one wave per SIMD of a CU.  A/B (round 2): 128 threads -6 % on
-                              // C2 / hash / tree (waves land unevenly on the SIMDs), 512 threads -0.3 % C2, -3 % tree
-#endif
-#ifndef PMX_REG_TAB_MIN_WAVES
-#define PMX_REG_TAB_MIN_WAVES 4
-#endif
-#ifndef PMX_REG_DRIVER_MIN_WAVES
-#define PMX_REG_DRIVER_MIN_WAVES 4   // absorb / squeeze kernels of the t = 3 engine: left alone they take 140 / 160 VGPRs (3 waves per SIMD);
-                                     // held to 128: absorb +4 %, squeeze +10 % (round 3, second A/B; the first, on the old schedule, was a wash)
-#endif
+// Workgroup of the t = 3 register engine: one wave per SIMD of a CU (A/B, round 2: 128 threads -6 % on C2 / hash / tree - the waves land
+// unevenly on the SIMDs -, 512 threads -0.3 % C2, -3 % tree).  Its large-batch (table) kernels and its absorb / squeeze kernels are held to
+// four waves per SIMD (left alone the allocator took 140 / 160 VGPRs for the drivers: absorb +4 %, squeeze +10 % when held to 128; round 3).
+// The round constants are staged in LDS (broadcast reads) - scalar loads from global memory were 1.2 % faster on C2 in one session, within
+// what one box differs from the next - and the modulus stays in SGPRs (in vector registers: 46 -> 42 SGPR spills, C2 +-0, hash -1.3 %).
+constexpr int kRegThreads = 256, kRegTabMinWaves = 4, kRegDriverMinWaves = 4;
 template <int T, int ALPHA, bool OPT, bool TAB = false>
 struct RegEngine {
     static_assert(OPT || !TAB, "shifted tables exist for the optimised schedule");
-    static constexpr int kThreads = PMX_REG_THREADS;
+    static constexpr int kThreads = kRegThreads;
     // the large-batch (table) kernels live on four waves per SIMD: held to 128 VGPRs (left alone the allocator has taken
     // anything between 105 and 138 for the same source); the element-form kernels serve launches that cannot fill the chip
-    static constexpr int kMinWaves = TAB ? PMX_REG_TAB_MIN_WAVES : 1, kMinWavesDriver = PMX_REG_DRIVER_MIN_WAVES;
+    static constexpr int kMinWaves = TAB ? kRegTabMinWaves : 1, kMinWavesDriver = kRegDriverMinWaves;
     static constexpr bool kWaveUniformOnly = false;   // permute() may be called under a partial EXEC mask (per-lane driver kernels)
     static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
 
@@ -89,30 +76,18 @@ struct RegEngine {
     __host__ __device__ __forceinline__ static uint32_t last_word(const DevConfig &d) { return TAB ? d.opt_full_offset : OPT ? d.coop_offset : d.opt_offset; }
 
     static size_t lds_bytes(const DevConfig &d, uint32_t /*t*/) {
-        return (PMX_CONSTS_IN_LDS ? (size_t)((last_word(d) - first_word(d) + 3) / 4) * 16 : 0) + (size_t)kThreads * kChunks * 16;
+        return (size_t)((last_word(d) - first_word(d) + 3) / 4) * 16 + (size_t)kThreads * kChunks * 16;
     }
 
     __device__ __forceinline__ RegEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
         f.io = consts + d.io_offset;
-#if PMX_REG_P_IN_VGPR
-        // the modulus limbs as VECTOR registers: the table products want every free SGPR for their operand stream
-        if constexpr (TAB) {
-#pragma unroll
-            for (int i = 0; i < kN; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(f.p[i]) : "s"(d.field.p[i]));
-        }
-#endif
         const uint32_t w0 = first_word(d);
-#if PMX_CONSTS_IN_LDS
         const uint32_t const_chunks = (last_word(d) - w0 + 3) / 4;
         const uint4 *g = reinterpret_cast<const uint4 *>(consts + w0);   // offsets are multiples of 12 words = 48 B
         for (uint32_t q = threadIdx.x; q < const_chunks; q += kThreads) pmx_lds[q] = g[q];
         const uint32_t *base = reinterpret_cast<const uint32_t *>(pmx_lds) - w0;
         stage = pmx_lds + const_chunks;
         __syncthreads();
-#else
-        const uint32_t *base = consts;
-        stage = pmx_lds;
-#endif
         tb.tab_full = consts + d.tab_full_offset;
         tb.tab_sparse = consts + d.tab_sparse_offset;
         tb.tab_bdense = consts + d.tab_bdense_offset;
@@ -229,48 +204,36 @@ struct RegEngine {
 // rounds their dynamic indexing (pmx_permute.hpp: permute_hybrid) and doubles as the staging area of the
 // coalesced ABI load/store.  Constants come through the scalar cache (the table is up to 80 KiB at t = 9).
 // ------------------------------------------------------------------------------------------------
-#ifndef PMX_HYB_WAVES
-#define PMX_HYB_WAVES 1   // waves per workgroup of the hybrid engines (each wave owns its own LDS region).  Four-wave workgroups -
-                          // co-resident waves in the same round, sharing its table lines in the scalar cache - were measured:
-                          // C3 -0.6 %, t = 9 hash +0.7 %: the s_waitcnt time of the wide kernels is not a cache-capacity effect
-#endif
-#ifndef PMX_HYB_3WAVE_MAX_T
-#define PMX_HYB_3WAVE_MAX_T 6   // widths up to this one must fit three waves per SIMD: t = 4, 5 do so on their own; t = 6 (176 VGPRs
-                                // when left alone) is +6 % when held to 168; t = 7, 8, 9 spill and lose 23 / 46 / 68 % (round 3 A/B)
-#endif
-#ifndef PMX_MFMA_4WAVE_MAX_T   // the same bounds for the matrix-core engines of the narrow widths (their byte strings and sums want registers)
+// One wave per workgroup for the VALU-row engines, each wave with its own LDS region (four-wave workgroups - co-resident waves in the
+// same round, sharing its table lines in the scalar cache - were measured: C3 -0.6 %, t = 9 hash +0.7 %: the s_waitcnt time of those
+// kernels is not a cache-capacity effect).  Register bounds of the VALU-row engines: t = 4 (133 VGPRs when left alone) held to 128, four
+// waves per SIMD, +3.8 %; t = 5, 6 three waves (t = 6, 176 VGPRs left alone, +6 % when held to 168); t = 7, 8, 9 spill and lose
+// 23 / 46 / 68 % when held to three (round 3 A/B).
+constexpr int kHybWaves = 1, kHyb4WaveMaxT = 4, kHyb3WaveMaxT = 6;
+// MFMA: every product by a constant runs on the matrix cores (pmx_mfma.hpp) - the dense layers and, as windows of up to six S-boxes
+// per layer, the linear part of the partial rounds; the kMfmaWaves waves of a workgroup share one LDS tile of the layer's table
+// rows.  Wave-uniform kernels only (permute, hash, compress, and the passes of the absorb / squeeze driver, which ARE permutation
+// launches: inside a per-lane loop not every lane is active, and the lane exchange of this path needs both lanes of a pair).
+// Register bounds of the matrix-core engines (their byte strings and sums want registers), measured per width:
+#ifndef PMX_MFMA_4WAVE_MAX_T
 #define PMX_MFMA_4WAVE_MAX_T 2
 #endif
 #ifndef PMX_MFMA_3WAVE_MAX_T
 #define PMX_MFMA_3WAVE_MAX_T 5
 #endif
-#ifndef PMX_HYB_4WAVE_MAX_T
-#define PMX_HYB_4WAVE_MAX_T 4   // t = 4 (133 VGPRs when left alone) held to 128: four waves per SIMD, +3.8 % (round 3 A/B)
-#endif
-// MFMA: every product by a constant runs on the matrix cores (pmx_mfma.hpp) - the dense layers and, as windows of up to six S-boxes
-// per layer, the linear part of the partial rounds; the PMX_MFMA_WAVES waves of a workgroup share one LDS tile of the layer's table
-// rows.  Wave-uniform kernels only (permute, hash, compress, and the passes of the absorb / squeeze driver, which ARE permutation
-// launches: inside a per-lane loop not every lane is active, and the lane exchange of this path needs both lanes of a pair).
-#ifndef PMX_MFMA_WAVES
-#define PMX_MFMA_WAVES 4        // waves per workgroup of the matrix-core engines, and
-#endif
-#ifndef PMX_MFMA_TILE_WINDOWS
-#define PMX_MFMA_TILE_WINDOWS 1   // the tile holds a whole row of the WINDOW layers (t - 1 + K elements) where two workgroups per CU still fit
-                                  // (t <= 8), as much as fits at t = 9 (8 KiB: two stages per row): +0.4 ... +2 % (profiles/r04)
-#endif
-#ifndef PMX_MFMA_TILE_STEPS
-#define PMX_MFMA_TILE_STEPS 6   // k-steps (KiB) of a row's table in LDS at a time.  At t = 9 (8 x 18 KiB of scratch per CU) that
-                                // is two workgroups of four waves per CU with a 6 KiB tile each - their phases drift apart, so one's
-                                // MFMAs run under the other's carries - or one of eight waves with a whole row (11 KiB), whose waves
-                                // all multiply and all carry at the same time
-#endif
+// Four waves per workgroup, two workgroups per CU.  The tile holds a whole row of the layer with the longest rows (the window layers:
+// t - 1 + K elements) where two workgroups per CU still fit (t <= 8), as much as fits at t = 9 (8 KiB: two stages per row): +0.4 ...
+// +2 % over a tile sized for the dense layers (profiles/r04).  At t = 9 (8 x 18 KiB of scratch per CU) that is two workgroups of
+// four waves per CU - their phases drift apart, so one's MFMAs run under the other's carries - against one workgroup of eight waves
+// with a whole row, whose waves all multiply and all carry at the same time (6 % slower, round 3).
+constexpr int kMfmaWaves = 4, kMfmaMinTileSteps = 6;
 template <int T, int ALPHA, bool MFMA = false>
 struct HybridEngine {
-    static constexpr int kWaves = MFMA ? PMX_MFMA_WAVES : PMX_HYB_WAVES;
+    static constexpr int kWaves = MFMA ? kMfmaWaves : kHybWaves;
     static constexpr int kThreads = 64 * kWaves;
     // waves per SIMD the register allocation must allow (4: <= 128 VGPRs, 3: <= 168, 2: <= 256)
     static constexpr int kMinWaves = MFMA ? (T <= PMX_MFMA_4WAVE_MAX_T ? 4 : T <= PMX_MFMA_3WAVE_MAX_T ? 3 : 2)
-                                          : (T <= PMX_HYB_4WAVE_MAX_T ? 4 : T <= PMX_HYB_3WAVE_MAX_T ? 3 : 2);
+                                          : (T <= kHyb4WaveMaxT ? 4 : T <= kHyb3WaveMaxT ? 3 : 2);
     static constexpr int kMinWavesDriver = 2;   // absorb / squeeze kernels (per-lane modes: more live state) spill under the tighter bounds
     // the matrix-core rows exchange operands between the lanes of a pair (l, l + 32) and share an LDS tile behind workgroup
     // barriers: permute() must be reached by every lane of the workgroup - never from a per-lane loop (absorb_kernel /
@@ -305,13 +268,12 @@ struct HybridEngine {
     uint4 *region;    // this wave's LDS region
     uint32_t lane;
 
-    // the stage of a row's table the workgroup shares, behind the waves' regions
-    // (a whole row where two workgroups per CU still fit - t = 7: 8 KiB, t = 8: 9 KiB -, PMX_MFMA_TILE_STEPS at t = 9)
-    static constexpr int kTileFit = (int)((80 * 1024 - PMX_MFMA_WAVES * kWaveBytes) / 1024);
-    // (PMX_MFMA_TILE_WINDOWS: sized for the window layers' longer rows - t - 1 + K elements - as well, and as large as still fits)
+    // the stage of a row's table the workgroup shares, behind the waves' regions: a whole row of the longest layer (the window layers:
+    // t - 1 + K elements) where two workgroups per CU still fit, else as many k-steps as fit
+    static constexpr int kTileFit = (int)((80 * 1024 - kMfmaWaves * kWaveBytes) / 1024);
     static constexpr int kWinSteps = (MFMA && mfma_window_for(T) > 0) ? mfma_k_steps(T - 1 + mfma_window_for(T)) : 0;
-    static constexpr int kNeedSteps = (PMX_MFMA_TILE_WINDOWS && kWinSteps > mfma_k_steps(T)) ? kWinSteps : mfma_k_steps(T);
-    static constexpr int kTileSteps = kNeedSteps <= kTileFit ? kNeedSteps : ((PMX_MFMA_TILE_WINDOWS && kTileFit > PMX_MFMA_TILE_STEPS) ? kTileFit : PMX_MFMA_TILE_STEPS);
+    static constexpr int kNeedSteps = kWinSteps > mfma_k_steps(T) ? kWinSteps : mfma_k_steps(T);
+    static constexpr int kTileSteps = kNeedSteps <= kTileFit ? kNeedSteps : (kTileFit > kMfmaMinTileSteps ? kTileFit : kMfmaMinTileSteps);
     static constexpr size_t kTileBytes = MFMA ? (size_t)kTileSteps * 1024 : 0;
     static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes + kTileBytes; }
 
@@ -338,20 +300,9 @@ struct HybridEngine {
     __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi_scaled(x); }      // optimised schedule: see RegEngine
     __device__ __forceinline__ Abi to_abi(const Fe &x) const { return fe_to_abi_scaled(x, f); }
 
-#ifndef PMX_HYB_DIRECT_IO
-#define PMX_HYB_DIRECT_IO 1
-#endif
-#ifndef PMX_HYB_ROLLED_LOAD
-#define PMX_HYB_ROLLED_LOAD(T) ((T) == 6 || (T) >= 9)   // widths whose permute kernel otherwise keeps spills inside the rounds (t = 6 at three
-                                                        // waves per SIMD: 76 -> 12 bytes of scratch; t = 9: 76 -> 0); t = 7, 8 have none and lose 1 %
-#endif
-#ifndef PMX_HYB_STAGED_STORE
-#define PMX_HYB_STAGED_STORE 1
-#endif
-#ifndef PMX_HYB_ROLLED_IO
-#define PMX_HYB_ROLLED_IO 0   // rolled element loops for the state I/O of the wide engines (no spill left inside the rounds at t = 9): C3 -0.8 %, t = 6 +1.5 %, t = 7, 8 -1 %
-#endif
-#if PMX_HYB_DIRECT_IO
+    // widths whose permute kernel otherwise keeps spills inside the rounds read their elements in a rolled loop (t = 6 at three waves per
+    // SIMD: 76 -> 12 bytes of scratch; t = 9: 76 -> 0); t = 7, 8 have none and lose 1 %
+    static constexpr bool kRolledLoad = T == 6 || T >= 9;
     // Every lane reads and writes its own 32 T contiguous bytes with 16-byte accesses.  Across the lanes of a wave these are
     // strided, but every cache line is used in full within the 2 T accesses of the lane that owns it, and a wide permutation
     // moves 64 T bytes in ~2 ms of arithmetic: nothing to gain from staging the wave's span through LDS, and without the
@@ -361,7 +312,7 @@ struct HybridEngine {
     // adds its input there, on the ABI residues, before the bit-slicing - absorb_adjust below)
     template <class Adjust>
     __device__ __forceinline__ void load_elements(const uint4 *g, const Adjust &adjust) {
-        if constexpr (PMX_HYB_ROLLED_LOAD(T)) {
+        if constexpr (kRolledLoad) {
             zero();
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (uint32_t i = 0; i < (uint32_t)T; ++i) set(i, from_abi(adjust(i, abi_from_u4(g[2 * i], g[2 * i + 1]))));
@@ -392,7 +343,6 @@ struct HybridEngine {
         load_elements(reinterpret_cast<const uint4 *>(g_states) + (gid < n ? gid : 0) * kChunks, add);
     }
 
-#if PMX_HYB_STAGED_STORE
     // the store goes through the wave's LDS region so that every 16-byte write instruction covers 1 KiB of contiguous memory:
     // written lane by lane (stride 32 T bytes) the partial lines are not all merged before they leave the L2 - 1.57 x the
     // bytes at t = 9 (WRITE_SIZE, profiles/r03)
@@ -416,75 +366,6 @@ struct HybridEngine {
         }
         __syncthreads();
     }
-#else
-    __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {
-        const size_t gid = (size_t)blockIdx.x * kThreads + threadIdx.x;
-        if (gid < n) {
-            uint4 *g = reinterpret_cast<uint4 *>(g_states) + gid * kChunks;
-#if PMX_HYB_ROLLED_IO
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (uint32_t i = 0; i < (uint32_t)T; ++i) {
-                const Abi a = to_abi(get(i));
-                g[2 * i] = abi_lo(a);
-                g[2 * i + 1] = abi_hi(a);
-            }
-#else
-            static_for<0, T>([&](auto i) {
-                const Abi a = to_abi(s[i]);
-                g[2 * i] = abi_lo(a);
-                g[2 * i + 1] = abi_hi(a);
-            });
-#endif
-        }
-    }
-#endif
-#else
-    // every wave stages its own 64 contiguous states through its own region
-    __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
-        const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
-        const size_t valid = n > first ? (n - first < (size_t)64 ? n - first : (size_t)64) : 0;
-        const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + first * kChunks;
-        const uint32_t n_chunks = (uint32_t)valid * kChunks;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kChunks; ++k) {
-            const uint32_t q = lane + k * 64;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q < n_chunks) v = g[q];
-            region[q] = v;
-        }
-        __syncthreads();
-        // element by element (one ABI element live at a time: reading all T first held 8 T more registers at the kernel's
-        // widest point)
-        static_for<0, T>([&](auto i) {
-            s[i] = from_abi(abi_from_u4(region[lane * kChunks + 2 * i], region[lane * kChunks + 2 * i + 1]));
-            PMX_SCHED_FENCE();
-        });
-        __syncthreads();   // the staging area is the scratch array: finish reading before anyone writes slots
-    }
-
-    __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {
-        const size_t first = (size_t)blockIdx.x * kThreads + (threadIdx.x & ~63u);
-        const size_t valid = n > first ? (n - first < (size_t)64 ? n - first : (size_t)64) : 0;
-        uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * kChunks;
-        const uint32_t n_chunks = (uint32_t)valid * kChunks;
-        __syncthreads();
-        static_for<0, T>([&](auto i) {
-            const Abi a = to_abi(s[i]);
-            region[lane * kChunks + 2 * i] = abi_lo(a);
-            region[lane * kChunks + 2 * i + 1] = abi_hi(a);
-            PMX_SCHED_FENCE();   // one element at a time: interleaved, the T conversions are the widest point of the kernel
-        });
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kChunks; ++k) {
-            const uint32_t q = lane + k * 64;
-            if (q < n_chunks) g[q] = region[q];
-        }
-        __syncthreads();
-    }
-
-#endif
 
     // One state per lane at a per-lane address (permute_listed_kernel: the sponges of a pass, gathered through an index
     // list).  Every lane reads and writes its own 32 T contiguous bytes with 16-byte accesses: each line is used in full by
@@ -565,8 +446,8 @@ struct HybridEngine {
         o.threads = kThreads;
         o.optimised = 1;
         // (window engines: the only rows left on the VALU are the history products of the S-box inputs - pmx_mfma.hpp: mfma_hist_tab)
-        o.row_tables = (MFMA && mfma_window_for(T) > 0) ? (mfma_hist_tab(T) ? 1 : 0) : (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB);
-        o.lane_tables = T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB;
+        o.row_tables = (MFMA && mfma_window_for(T) > 0) ? (mfma_hist_tab(T) ? 1 : 0) : (T <= kHybridTabMaxT);
+        o.lane_tables = 1;   // (the identity lanes of the VALU-row engines take shifted tables at every width)
         o.mfma_dense = MFMA;
         o.partial_window = MFMA ? mfma_window_for(T) : 0;
     }
@@ -1422,11 +1303,8 @@ struct Launch {
 
 #if PMX_TU == 99
 // ---- tuning aid (Makefile target asm1): ONE kernel of one hybrid engine, for reading its ISA and register report in seconds -------
-#ifndef PMX_ONE_T
-#define PMX_ONE_T 9
-#endif
-#ifndef PMX_ONE_ALPHA
-#define PMX_ONE_ALPHA 5
+#if !defined(PMX_ONE_T) || !defined(PMX_ONE_ALPHA)
+#error "PMX_TU = 99 (make asm1) names its engine with -DPMX_ONE_T=<width> -DPMX_ONE_ALPHA=<5 | 0>"
 #endif
 template __global__ void permute_kernel<HybridEngine<PMX_ONE_T, PMX_ONE_ALPHA, true>>(const DevConfig, const uint32_t *__restrict__, uint64_t *__restrict__, size_t);
 #elif PMX_TU != 0
@@ -1656,13 +1534,7 @@ static bool lds_fits(const DevConfig &c, uint32_t t) { return Engine::lds_bytes(
 // The shifted tables trade multiplies for a constant stream, and a stream needs a second wave on the SIMD to hide
 // behind: measured per launch at t = 3, the table form wins from 2^17 states up (permute; 2^18 for compress), below
 // that - fewer than two waves per SIMD - the element form is 7-25 % faster (lone-wave latency 0.145 vs 0.16 ms).
-#ifndef PMX_TAB_MIN_PERMUTE
-#define PMX_TAB_MIN_PERMUTE ((size_t)1 << 17)
-#endif
-#ifndef PMX_TAB_MIN_COMPRESS
-#define PMX_TAB_MIN_COMPRESS ((size_t)1 << 18)
-#endif
-static constexpr size_t kTabMinPermute = PMX_TAB_MIN_PERMUTE, kTabMinCompress = PMX_TAB_MIN_COMPRESS;
+static constexpr size_t kTabMinPermute = (size_t)1 << 17, kTabMinCompress = (size_t)1 << 18;
 
 // t = 3, alpha 5 / 17, fewer than `limit` units: the element-form engine
 #define PMX_SMALL_BATCH(LIMIT, CALL)                                                                 \
@@ -1683,9 +1555,7 @@ static bool quad_shape(const DevConfig &c, uint32_t t) { return quad_table(c, t)
 // Small batches are latency: the quad engine up to this many states / rows / sponges (one dependent chain of 32 k instead
 // of 58-67 k instructions: 0.066 instead of 0.145 ms up to 4096 states, 0.078 at 2^14, 0.132 vs 0.151 at 2^15; above, the
 // one-lane kernels fill the chip better).
-#ifndef PMX_QUAD_MAX_SPONGES
-#define PMX_QUAD_MAX_SPONGES 32768
-#endif
+static constexpr size_t kQuadMaxSponges = 32768;
 #define PMX_QUAD_LAUNCH(KERNEL, ...)                                                                                        \
     do {                                                                                                                    \
         const dim3 grid_((unsigned)((n + 63) / 64));                                                                        \
@@ -1712,14 +1582,14 @@ static bool t3_mfma(const DevConfig &c, uint32_t t, size_t n) {
 // the hybrid family's half by exponent, as PMX_DISPATCH picks it for the wider states
 #define PMX_T3_MFMA(CALL) (c.rounds.alpha == 5 ? hybrid5_##CALL : hybridg_##CALL)
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
-    if (quad_table(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(permute_quad_kernel, states, n);
+    if (quad_table(c, t) && n <= kQuadMaxSponges) PMX_QUAD_LAUNCH(permute_quad_kernel, states, n);
     if (t3_mfma(c, t, n)) return PMX_T3_MFMA(permute(c, t, states, n, st));
     PMX_SMALL_BATCH(kTabMinPermute, permute(c, t, states, n, st));
     PMX_DISPATCH(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                        size_t n, hipStream_t st) {
-    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(hash_quad_kernel, in, in_len, out, out_len, n);
+    if (quad_shape(c, t) && n <= kQuadMaxSponges) PMX_QUAD_LAUNCH(hash_quad_kernel, in, in_len, out, out_len, n);
     if (t3_mfma(c, t, n)) return PMX_T3_MFMA(hash(c, t, in, in_len, out, out_len, n, st));
     PMX_SMALL_BATCH(kTabMinPermute, hash(c, t, in, in_len, out, out_len, n, st));
     PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
@@ -1729,10 +1599,7 @@ hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_
 // half a wave per SIMD there and is bound by the 51k-multiply dependent chain of a single permutation (0.145 ms),
 // while the quad kernel's chain is 23k multiplies (0.067 ms alone on a SIMD, 0.12 ms with two waves per SIMD at 32768
 // compressions; A/B at 16384 vs 32768 on a 2^21-leaf tree: 4.70 vs 4.65 ms).
-#ifndef PMX_COOP_MAX_UNITS
-#define PMX_COOP_MAX_UNITS 32768
-#endif
-static constexpr size_t kCoopMaxUnits = PMX_COOP_MAX_UNITS;
+static constexpr size_t kCoopMaxUnits = 32768;
 
 template <int ALPHA>
 static hipError_t launch_compress_coop(const DevConfig &c, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
@@ -1754,14 +1621,14 @@ hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, u
 
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st, const PassScratch &scratch) {
-    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(absorb_quad_kernel, states, tag, index, in, in_len, n);
+    if (quad_shape(c, t) && n <= kQuadMaxSponges) PMX_QUAD_LAUNCH(absorb_quad_kernel, states, tag, index, in, in_len, n);
     if (t3_mfma(c, t, n)) return PMX_T3_MFMA(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
     PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
     PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
 }
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st, const PassScratch &scratch) {
-    if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
+    if (quad_shape(c, t) && n <= kQuadMaxSponges) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
     if (t3_mfma(c, t, n)) return PMX_T3_MFMA(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
     PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
     PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
@@ -1782,14 +1649,14 @@ hipError_t describe_launch(const DevConfig &c, uint32_t t, int op, size_t n, siz
     o->width = (int)t;
     switch (op) {
         case PMX_OP_PERMUTE:
-            if (quad_table(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) return describe_quad(c, o);
+            if (quad_table(c, t) && n <= kQuadMaxSponges) return describe_quad(c, o);
             if (t3_mfma(c, t, n)) return PMX_T3_MFMA(describe(c, t, op, len, o));
             PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
             break;
         case PMX_OP_HASH:
         case PMX_OP_ABSORB:
         case PMX_OP_SQUEEZE:
-            if (quad_shape(c, t) && n <= (size_t)PMX_QUAD_MAX_SPONGES) return describe_quad(c, o);
+            if (quad_shape(c, t) && n <= kQuadMaxSponges) return describe_quad(c, o);
             if (t3_mfma(c, t, n)) return PMX_T3_MFMA(describe(c, t, op, len, o));
             PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
             break;

@@ -403,9 +403,6 @@ PMX_FN Fe tab_dot(const Fe *z, const uint32_t *tab, const Fe &s, const FieldRt &
 // Here the stream is cut into chunks of at most 27 words - three terms of one column of a row, or three columns of
 // a single product; the rows are laid out so that a chunk is contiguous - chunk c + 1 is loaded while chunk c is
 // multiplied, and a scheduling fence after every chunk stops anything else from moving up.
-#ifndef PMX_TAB_PREFETCH
-#define PMX_TAB_PREFETCH 1
-#endif
 
 template <int N, bool ADD = false>
 PMX_FN Fe tab_dot_stream(const Fe *z, const uint32_t *tab, const FieldRt &f, const Fe *addend = nullptr) {
@@ -425,12 +422,11 @@ PMX_FN Fe tab_dot_stream(const Fe *z, const uint32_t *tab, const FieldRt &f, con
 #pragma unroll
         for (int w = 0; w < cnt * kN; ++w) b[w] = tab[(k * NG + g) * kTabChunkWords + w];
     };
-    if constexpr (PMX_TAB_PREFETCH) load(std::integral_constant<int, 0>{}, buf[0]);
+    load(std::integral_constant<int, 0>{}, buf[0]);
     static_for<0, kChunks>([&](auto cc) {
         constexpr int c = decltype(cc)::value, k = c / NG, g = c % NG;
         constexpr int cnt = (N - kTabChunk * g) < kTabChunk ? (N - kTabChunk * g) : kTabChunk;
-        if constexpr (!PMX_TAB_PREFETCH) load(cc, buf[c & 1]);
-        else if constexpr (c + 1 < kChunks) load(std::integral_constant<int, c + 1>{}, buf[(c + 1) & 1]);
+        if constexpr (c + 1 < kChunks) load(std::integral_constant<int, c + 1>{}, buf[(c + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < cnt; ++i) {
 #pragma unroll
@@ -460,11 +456,10 @@ PMX_FN void tab_lanes_stream(const Fe &z0, const uint32_t *tab, Fe *s, const Fie
 #pragma unroll
         for (int w = 0; w < kTabChunk * kN; ++w) b[w] = tab[(c / kParts) * kTabOneWords + (c % kParts) * kTabChunkWords + w];
     };
-    if constexpr (PMX_TAB_PREFETCH) load(std::integral_constant<int, 0>{}, buf[0]);
+    load(std::integral_constant<int, 0>{}, buf[0]);
     static_for<0, kChunks>([&](auto cc) {
         constexpr int c = decltype(cc)::value, l = c / kParts, h = c % kParts;
-        if constexpr (!PMX_TAB_PREFETCH) load(cc, buf[c & 1]);
-        else if constexpr (c + 1 < kChunks) load(std::integral_constant<int, c + 1>{}, buf[(c + 1) & 1]);
+        if constexpr (c + 1 < kChunks) load(std::integral_constant<int, c + 1>{}, buf[(c + 1) & 1]);
 #pragma unroll
         for (int kk = 0; kk < kTabChunk; ++kk) {
 #pragma unroll

@@ -33,11 +33,9 @@ namespace pmx {
 // Widths whose dense layers go to the matrix cores.  A row costs ~155 VALU instructions of finish plus its share of the state's
 // re-cut (26 per element) and 2 x ceil(36 t / 32) MFMA issue slots, against 81 t + 81 multiplies and their carries on the VALU.
 #ifndef PMX_MFMA_MIN_T
-#define PMX_MFMA_MIN_T 3
+#define PMX_MFMA_MIN_T 3   // (10: the library never selects these engines nor builds their tables - INTEGRATION.md section 8)
 #endif
-#ifndef PMX_MFMA_MAX_T
-#define PMX_MFMA_MAX_T 9
-#endif
+#define PMX_MFMA_MAX_T 9   // (a row's mid-column budget and the 36 t / 32 k-steps are laid out for t <= 9)
 constexpr int kMfmaElemBytes = 36;   // K bytes per element (33 used)
 constexpr int kMfmaShift = 29;       // the tables hold c 2^(8 b + kMfmaShift): the row finish divides by 2^29 (one Montgomery step)
 PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32; }
@@ -55,12 +53,9 @@ PMX_FN constexpr int mfma_layer_words_io(int n_in, int n_out) { return n_out * m
 #ifndef PMX_MFMA_WINDOW
 #define PMX_MFMA_WINDOW 6
 #endif
-#ifndef PMX_MFMA_WINDOW_MIN_T
-#define PMX_MFMA_WINDOW_MIN_T 3
-#endif
 // window size of a width (0: its partial rounds keep their sparse layers on the VALU)
 PMX_FN constexpr int mfma_window_for(int t) {
-    return (t >= PMX_MFMA_WINDOW_MIN_T && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T) ? (PMX_MFMA_WINDOW < t ? PMX_MFMA_WINDOW : t) : 0;
+    return (t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T) ? (PMX_MFMA_WINDOW < t ? PMX_MFMA_WINDOW : t) : 0;
 }
 PMX_FN constexpr int mfma_window_hist(int k) { return (k - 1) * (k - 2) / 2; }   // history constants per window
 // The history constants as stored: elements (kFeStride words each), or - widths up to PMX_MFMA_HIST_TAB_MAX_T - shifted tables
@@ -104,10 +99,20 @@ PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
 // correction, as eight 64-bit word sums with carries, re-cut into ten 29-bit limbs, one Montgomery step: V 2^-29 mod p, below 2^243 + p.
 PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
     uint32_t wd[9];
-    // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from a
-    // register the compiler cannot see through - f.unit is 1 - or it would turn each into a sign extension, a 64-bit shift and a
-    // 64-bit add.  |t| < 2^50, so the carry into the next word (t >> 32) is the high register as it stands.
-    const int w1 = (int)f.unit, w8 = (int)(f.unit << 8), w16 = (int)(f.unit << 16), w24 = (int)(f.unit << 24);
+    // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from
+    // registers the compiler cannot see through, or it would turn each into a sign extension, a 64-bit shift and a 64-bit add - and
+    // from VECTOR registers, so that the row's correction, a wave-uniform 64-bit value in a scalar pair, can be the addend of the word's
+    // first mad as it stands (an instruction takes one scalar operand: with the weights in SGPRs every correction word cost two
+    // v_mov, 16 per row).  |t| < 2^50, so the carry into the next word (t >> 32) is the high register as it stands.
+    int w1, w8, w16, w24;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mov_b32 %0, 1" : "=v"(w1));
+    asm("v_mov_b32 %0, 0x100" : "=v"(w8));
+    asm("v_mov_b32 %0, 0x10000" : "=v"(w16));
+    asm("v_mov_b32 %0, 0x1000000" : "=v"(w24));
+#else
+    w1 = 1, w8 = 1 << 8, w16 = 1 << 16, w24 = 1 << 24;
+#endif
     int carry = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
@@ -120,13 +125,17 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
         carry = (int)(t >> 32);
     }
     wd[8] = (uint32_t)carry;   // V >= 0: the top carry is not negative
+    // ten 29-bit limbs out of the nine words: one funnel shift and one mask each
     uint32_t L[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         const int bit = kW * k, wi = bit / 32, sh = bit % 32;
-        uint64_t pair = wd[wi];
-        if (wi + 1 < 9) pair |= (uint64_t)wd[wi + 1] << 32;
-        L[k] = (uint32_t)(pair >> sh) & kMask;
+        const uint32_t lo = wd[wi], hi = wi + 1 < 9 ? wd[wi + 1] : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        L[k] = (sh == 0 ? lo : __builtin_amdgcn_alignbit(hi, lo, sh)) & kMask;
+#else
+        L[k] = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & kMask;
+#endif
     }
     // ONE Montgomery step: V < 2^272, so (V + m p) / 2^29 < 2^243 + p already fits nine limbs (the table carries the 2^29)
     uint64_t acc = L[0];
@@ -195,9 +204,10 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
 // come back unspecified, like matrix_rows_rolled.  s norm.  `tile`: TILE_STEPS KiB of LDS shared by the workgroup's THREADS
 // threads, all of which must arrive here together (two barriers per stage of a row) with every lane active.
 // General form: NIN input elements at `in`, rows [lo, hi) of NOUT into out (which may alias in: the inputs are consumed first).
-#ifndef PMX_MFMA_LDS_AHEAD
-#define PMX_MFMA_LDS_AHEAD 8   // k-steps of the A operand in flight between the tile and the matrix cores (4 registers each)
-#endif
+// k-steps of the A operand in flight between the tile and the matrix cores (4 registers each): as many as a stage has, up to 8 - but 2 at
+// t = 5, whose kernels sit on the 168 registers of three waves per SIMD (8 ahead: 104 instead of 48 bytes of scratch per lane, -5.5 %;
+// profiles/r05/d_ab_lds_tile_read_ahead.txt)
+PMX_FN constexpr int mfma_lds_ahead(int t) { return t == 5 ? 2 : 8; }
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
                                                     uint32_t lo, uint32_t hi) {
@@ -246,7 +256,7 @@ __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scrat
             // refilled as soon as its pair of products has been issued: left to itself the compiler reads one or two k-steps ahead
             // and then waits the whole LDS round trip (~120 clocks, against the 64 a pair of products keeps the matrix pipe busy)
             // in front of every pair - a wave spent 22 % of its cycles in s_waitcnt that way (profiles/r04/s_pmc_window_kernels_c3_c2.txt).
-            constexpr int kAhead = steps < PMX_MFMA_LDS_AHEAD ? steps : PMX_MFMA_LDS_AHEAD;
+            constexpr int kAhead = steps < mfma_lds_ahead(NOUT) ? steps : mfma_lds_ahead(NOUT);
             mfma_v4i a[kAhead];
 #pragma unroll
             for (int qq = 0; qq < kAhead; ++qq) a[qq] = tile[qq * 64 + lane];

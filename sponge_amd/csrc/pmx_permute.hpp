@@ -142,15 +142,8 @@ PMX_FN void permute_opt(Fe (&s)[T], const OptTables &tb, const Rounds &c, const 
 // loads, no VALU work) and folded into a value the caller keeps alive, so the loads are real and are issued here -
 // a whole S-box ahead of the products that consume the table, which then find their lines in the scalar cache
 // instead of paying an L2 round trip per chunk with only two waves per SIMD to hide it.
-#ifndef PMX_HYBRID_TOUCH
-#define PMX_HYBRID_TOUCH 1   // +1..4 % at t = 4..9
-#endif
-#ifndef PMX_HYBRID_TOUCH_ROW0
-#define PMX_HYBRID_TOUCH_ROW0 0   // warm-up of the element-form row 0 of t >= 6 as well: C3 -1 % (round 2 A/B)
-#endif
-#ifndef PMX_HYBRID_WIDE_ROW0_TAB
-#define PMX_HYBRID_WIDE_ROW0_TAB 0
-#endif
+// (kept on: +1..4 % at t = 4..9 on the VALU-row engines.  Tried and not kept, DESIGN.md section 8: warming the element-form row 0 of
+// t >= 6 as well, C3 -1 %; row 0 of the wide sparse layers as a streamed shifted table, t = 8, 9 -4..-5 %.)
 template <int WORDS>
 PMX_FN uint32_t table_touch(const uint32_t *tab) {
     uint32_t x = 0;
@@ -159,41 +152,24 @@ PMX_FN uint32_t table_touch(const uint32_t *tab) {
     return x ^ tab[WORDS - 1];   // the table need not start on a line boundary: its last words may sit in one more line
 }
 
-#ifndef PMX_OPT_TAB_TOUCH
-#define PMX_OPT_TAB_TOUCH 0   // the same warm-up for t = 3: C2 -0.5 %, hash +0.8 % - four waves per SIMD already hide the misses
-#endif
-#ifndef PMX_OPT_TAB_STREAM
-#define PMX_OPT_TAB_STREAM 0   // 1: permute_opt_tab consumes its tables through the explicitly pipelined stream forms
-#endif
+// (Tried for t = 3 as well and not kept, DESIGN.md section 8: the same warm-up, C2 -0.5 %, hash +0.8 % - four waves per SIMD already
+// hide the misses; the explicitly pipelined stream forms for permute_opt_tab, C2 -3 %.)
 // shifted tables of one sparse round: row 0 over its T-1 constants v, then the T-1 single constants w
 PMX_FN constexpr int sparse_tab_words(int t) { return tab_row_words(t - 1) + (t - 1) * kTabOneWords; }
 // one row of a dense layer as a shifted table; NORM: z_0 + sum_{j>=1} z_j c_j (the table holds c_1 ..)
 template <int T, bool NORM>
 PMX_FN Fe row_tab(const Fe (&z)[T], const uint32_t *tab, const FieldRt &f) {
-#if PMX_OPT_TAB_STREAM
-    if constexpr (NORM && T > 1) return tab_dot_stream<T - 1, true>(&z[1], tab, f, &z[0]);
-    else return tab_dot_stream<T>(z, tab, f);
-#else
     if constexpr (NORM && T > 1) return tab_dot<T - 1, true>(&z[1], tab, z[0], f);
     else return tab_dot<T, false>(z, tab, z[0], f);
-#endif
 }
 
 // a sparse layer on shifted tables: s = (z_0, u) in, the next state out
 template <int T>
 PMX_FN void sparse_layer_tab(Fe (&s)[T], const uint32_t *sp, const FieldRt &f) {
     const Fe z0 = s[0];
-#if PMX_OPT_TAB_STREAM
-    if constexpr (T > 1) s[0] = tab_dot_stream<T - 1, true>(&s[1], sp, f, &z0);
-#else
     if constexpr (T > 1) s[0] = tab_dot<T - 1, true>(&s[1], sp, z0, f);   // z_0 + v . u
-#endif
     PMX_TRACK(0, s[0], f);
-#if PMX_OPT_TAB_STREAM
-    tab_lanes_stream<T - 1>(z0, sp + tab_row_words(T - 1), &s[1], f);
-#else
     static_for<1, T>([&](auto i) { s[i] = tab_dot<1, true>(&z0, sp + tab_row_words(T - 1) + (i - 1) * kTabOneWords, s[i], f); });
-#endif
     static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
 }
 
@@ -201,14 +177,10 @@ template <int T, int ALPHA>
 PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, const Fe &one, const FieldRt &f, uint32_t want_lo = 0,
                             uint32_t want_hi = T) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
-    uint32_t guard = 0;   // keeps table_touch's loads alive
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
         const uint32_t *rk = tb.ark + (size_t)r * T * kFeStride;
         const bool full = r < first_partial || r > last_partial;
         const bool sparse_layer = r + 1 >= first_partial && r < last_partial;
-        if constexpr (PMX_OPT_TAB_TOUCH) {
-            if (sparse_layer) guard ^= table_touch<sparse_tab_words(T)>(tb.tab_sparse + (size_t)(r + 1 - first_partial) * sparse_tab_words(T));
-        }
         s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         if (full) static_for<1, T>([&](auto i) { s[i] = fe_sbox<ALPHA>(fe_add_lazy(s[i], fe_const(rk + i * kFeStride)), c.alpha, one, f); });
         if (sparse_layer) {
@@ -226,7 +198,6 @@ PMX_FN void permute_opt_tab(Fe (&s)[T], const OptTables &tb, const Rounds &c, co
             }
         }
     }
-    if (PMX_OPT_TAB_TOUCH && guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -276,25 +247,14 @@ PMX_FN Fe matrix_row_add(const Fe *s, const uint32_t *row, const Fe &addend, con
 // tab_lanes_stream).  Measured on the default tables: with every matrix as tables t = 4 gains 10 % and t = 5 3-9 %, t = 6 nothing, and
 // t = 7..9 LOSE 6-10 % - at 2 waves per SIMD the latency of a 400 KiB table that misses the 16 KiB scalar cache on
 // every load is not covered by a one-chunk look-ahead, and the SGPR file has no room for a deeper one.  So up to
-// PMX_HYBRID_TAB_MAX_T everything is tables; above it only the identity lanes are (171 -> 108 multiplies each, half
+// kHybridTabMaxT everything is tables; above it only the identity lanes are (171 -> 108 multiplies each, half
 // the stream of the whole round), while the t-term rows, where one reduction is already shared by t products and a
 // table would save 63 of 810 multiplies, stay on the element form: +3..7 % at t = 6..9.
-#ifndef PMX_HYBRID_TAB_MAX_T
-#define PMX_HYBRID_TAB_MAX_T 5
-#endif
-#ifndef PMX_HYBRID_TAB_AUTO
-#define PMX_HYBRID_TAB_AUTO 0   // t <= PMX_HYBRID_TAB_MAX_T: 0 = the hand-pipelined stream forms, 1 = compiler-scheduled tab_dot.  The
-                                // compiler's own placement of the scalar loads was 1 % (t = 4) and 6 % (t = 5) faster in round 2 and
-                                // collapsed in round 3 (538 SGPR spills in the t = 5 sparse layer - 967 lane moves per 783 multiplies -
-                                // after an unrelated change: 2.6 -> 1.9e8 /s); the streams are 3.5 and 2.6e8 /s whatever else changes
-#endif
-#ifndef PMX_HYBRID_WIDE_NORM
-#define PMX_HYBRID_WIDE_NORM 1   // t >= 6: 1 = normalised dense layers skip the product by ONE (a second rolled row block in the kernel),
-                                 // 0 = they run the last round's t-term row code on the same table
-#endif
-#ifndef PMX_HYBRID_WIDE_LANES_TAB
-#define PMX_HYBRID_WIDE_LANES_TAB 1
-#endif
+constexpr int kHybridTabMaxT = 5;
+// (Below that width the tables are consumed through the hand-pipelined stream forms: the compiler's own placement of the scalar loads
+// was 1 % (t = 4) and 6 % (t = 5) faster in round 2 and collapsed in round 3 - 538 SGPR spills in the t = 5 sparse layer after an
+// unrelated change, 2.6 -> 1.9e8 /s.  The normalised dense layers of t >= 6 skip the product by ONE in a second rolled row block:
+// through the last round's t-term row code on the same table they were slower at every width, C3 -0.9 %, t = 7 -2.4 %.)
 
 // The t rows of one dense layer with the element loop rolled (dynamic indexing through the scratch): NORM rows are
 // s_0 + sum_{j>=1} c_j s_j - the same code for every row, which is why the normalised entry is column 0 and not the
@@ -305,13 +265,8 @@ template <int T, bool NORM, class Scratch>
 PMX_FN void matrix_rows_rolled_tab(Fe (&s)[T], Scratch &sc, const uint32_t *mat, const FieldRt &f, uint32_t lo = 0, uint32_t hi = T) {
     auto row = [&](uint32_t i) {
         const uint32_t *tab = mat + (size_t)i * tab_row_words(T);
-#if PMX_HYBRID_TAB_AUTO
-        if constexpr (NORM) return tab_dot<T - 1, true>(&s[1], tab, s[0], f);
-        else return tab_dot<T, false>(s, tab, s[0], f);
-#else
         if constexpr (NORM) return tab_dot_stream<T - 1, true>(&s[1], tab, f, &s[0]);
         else return tab_dot_stream<T>(s, tab, f);
-#endif
     };
     const uint32_t end = hi < (uint32_t)T ? hi : (uint32_t)T - 1;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
@@ -411,14 +366,10 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             s[T - 1] = fe_sbox<ALPHA>(fe_add_lazy(s[T - 1], fe_const(rk + (T - 1) * kFeStride)), c.alpha, one, f);
             static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
         } else if constexpr (!(MFMA_THREADS > 0 && MFMA_WINDOW > 0)) {   // partial round: S-box on lane 0; lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom)
-            if constexpr (PMX_HYBRID_TOUCH) {
-                if (sparse_layer) {
-                    const uint32_t *rt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
-                    if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_ROW0_TAB) guard ^= table_touch<tab_row_words(T - 1)>(rt);
-                    if constexpr (T <= PMX_HYBRID_TAB_MAX_T || PMX_HYBRID_WIDE_LANES_TAB) guard ^= table_touch<(T - 1) * kTabOneWords>(rt + tab_row_words(T - 1));
-                    if constexpr (T > PMX_HYBRID_TAB_MAX_T && PMX_HYBRID_TOUCH_ROW0)   // the element-form row 0 of the wide engines
-                        guard ^= table_touch<T * kFeStride>(tb.sparse + (size_t)layer * (2 * T - 1) * kFeStride);
-                }
+            if (sparse_layer) {   // warm the scalar cache for this round's tables, a whole S-box ahead of their use
+                const uint32_t *rt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
+                if constexpr (T <= kHybridTabMaxT) guard ^= table_touch<tab_row_words(T - 1)>(rt);
+                guard ^= table_touch<(T - 1) * kTabOneWords>(rt + tab_row_words(T - 1));
             }
             s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         }
@@ -426,45 +377,19 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
         if (sparse_layer && !kWindows) {
             const uint32_t *spt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
             const Fe z0 = s[0];
-            if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
+            if constexpr (T <= kHybridTabMaxT) {
                 PMX_SCHED_FENCE();
-#if PMX_HYBRID_TAB_AUTO
-                s[0] = tab_dot<T - 1, true>(&s[1], spt, z0, f);   // z_0 + v . u
-#else
                 s[0] = tab_dot_stream<T - 1, true>(&s[1], spt, f, &z0);
-#endif
                 PMX_TRACK(0, s[0], f);
-#if PMX_HYBRID_TAB_AUTO
-                static_for<1, T>([&](auto i) {
-                    PMX_SCHED_FENCE();
-                    s[i] = tab_dot<1, true>(&z0, spt + tab_row_words(T - 1) + (i - 1) * kTabOneWords, s[i], f);
-                });
-                PMX_SCHED_FENCE();
-#else
                 tab_lanes_stream<T - 1>(z0, spt + tab_row_words(T - 1), &s[1], f);
-#endif
             } else {
                 const uint32_t *sp = tb.sparse + (size_t)layer * (2 * T - 1) * kFeStride;
-                if constexpr (PMX_HYBRID_WIDE_ROW0_TAB) {
-                    PMX_SCHED_FENCE();
-                    s[0] = tab_dot_stream<T - 1, true>(&s[1], spt, f, &z0);
-                    PMX_SCHED_FENCE();
-                } else {
-                    s[0] = matrix_row_add<T - 1>(&s[1], sp + kFeStride, z0, f);   // z_0 + v . u
-                }
+                s[0] = matrix_row_add<T - 1>(&s[1], sp + kFeStride, z0, f);   // z_0 + v . u
                 PMX_TRACK(0, s[0], f);
-                if constexpr (PMX_HYBRID_WIDE_LANES_TAB) {
-                    // wide states: only the identity lanes take tables - that is where they pay (108 instead of 171 multiplies
-                    // each); a 9-term row saves 63 of 810 and would double the constant stream
-                    PMX_SCHED_FENCE();
-                    tab_lanes_stream<T - 1>(z0, spt + tab_row_words(T - 1), &s[1], f);
-                } else {
-                    static_for<1, T>([&](auto i) {
-                        PMX_SCHED_FENCE();
-                        s[i] = mont_mul_add(z0, fe_const(sp + (T + i - 1) * kFeStride), s[i], f);
-                    });
-                    PMX_SCHED_FENCE();
-                }
+                // wide states: only the identity lanes take tables - that is where they pay (108 instead of 171 multiplies
+                // each); a 9-term row saves 63 of 810 and would double the constant stream
+                PMX_SCHED_FENCE();
+                tab_lanes_stream<T - 1>(z0, spt + tab_row_words(T - 1), &s[1], f);
             }
             static_for<1, T>([&](auto i) { PMX_TRACK(1, s[i], f); });
         } else {
@@ -481,23 +406,18 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
 #else
                 matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, tile, f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
 #endif
-            } else if constexpr (T <= PMX_HYBRID_TAB_MAX_T) {
+            } else if constexpr (T <= kHybridTabMaxT) {
                 const uint32_t *mat = full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense;
                 if (last) matrix_rows_rolled_tab<T, false>(s, sc, mat, f, want_lo, want_hi);
                 else matrix_rows_rolled_tab<T, true>(s, sc, mat, f);
             } else {
                 const uint32_t *mat = full ? tb.full + (size_t)o * T * T * kFeStride : tb.bdense;
-                if constexpr (PMX_HYBRID_WIDE_NORM) {
-                    if (last) matrix_rows_rolled<T, false>(s, sc, mat, f, want_lo, want_hi);
-                    else matrix_rows_rolled<T, true>(s, sc, mat, f);
-                } else {   // one block of row code: the element table keeps ONE in column 0, the t-term rows serve every dense layer
-                    if (last) matrix_rows_rolled<T, false>(s, sc, mat, f, want_lo, want_hi);
-                    else matrix_rows_rolled<T, false>(s, sc, mat, f);
-                }
+                if (last) matrix_rows_rolled<T, false>(s, sc, mat, f, want_lo, want_hi);
+                else matrix_rows_rolled<T, true>(s, sc, mat, f);
             }
         }
     }
-    if (PMX_HYBRID_TOUCH && guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1): the compiler cannot know
+    if (guard == 0x9e3779b9u && f.unit == 0) s[0].l[0] ^= 1;   // never true (unit is 1): the compiler cannot know
 }
 
 // ------------------------------------------------------------------------------------------------------------
