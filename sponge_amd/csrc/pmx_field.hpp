@@ -118,6 +118,7 @@ constexpr int kIoP32 = 0, kIoToInt = 8, kIoToAbi = 8 + kN, kIoWords = 28;
 
 #if defined(PMX_HOSTCHECK) && !defined(__HIPCC__)
 void hostcheck_track(int tag, const Fe &x, const FieldRt &f);   // defined in tests/hostcheck/pmx_hostcheck.cpp
+void hostcheck_below_2_256(const Fe &x);                        // counts the elements that are not (pmx_mfma.hpp: inputs of a matrix-core layer)
 #endif
 
 // a stored constant: kFeStride words, 9 used (wave-uniform address -> scalar loads / LDS broadcast)

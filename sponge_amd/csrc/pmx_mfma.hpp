@@ -5,8 +5,10 @@
 // 81 t + 81 limb products (pmx_permute.hpp: matrix_rows_rolled); here it is an int8 GEMM whose N dimension is the 64 states
 // of the wave (one per lane), whose K dimension is the bytes of the state and whose M dimension is the bytes of the result:
 //
-//   * every element z_j (nine 29-bit limbs, value < 2^261 < 2^264) is re-cut into 33 bytes u_{j,b}; an element takes 36
-//     bytes of K (9 words, the top three bytes zero), the state t * 36, in k-steps of 32;
+//   * every element z_j a layer takes in is an S-box output (a Montgomery product: below 1.3 p) or a row of the layer before
+//     (below 2^243 + p), so with p < 2^255 it is below 2^256: it is re-cut into 32 bytes u_{j,b} - eight words, exactly ONE k-step of
+//     the matrix-core instruction per element (round 5; rounds 3-4 carried 36 bytes per element, 33 used, for values up to 2^261:
+//     -12 ... -25 % products per row, 16 registers fewer at t = 9).  prepare() grants the tables only where the bound holds (alpha >= 2);
 //   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 29) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
 //     (pmx_prepare.hpp: put_mfma_layer; the modulus' top byte must be <= 126 for 32 of them to do), laid out as the A
 //     operand: 16 bytes per lane and k-step, lane l = row e (l & 31) and half (l >> 5) of the k-step;
@@ -36,7 +38,7 @@ namespace pmx {
 #define PMX_MFMA_MIN_T 3   // (10: the library never selects these engines nor builds their tables - INTEGRATION.md section 8)
 #endif
 #define PMX_MFMA_MAX_T 9   // (a row's mid-column budget and the 36 t / 32 k-steps are laid out for t <= 9)
-constexpr int kMfmaElemBytes = 36;   // K bytes per element (33 used)
+constexpr int kMfmaElemBytes = 32;   // K bytes per element: every input of a layer is below 2^256 (see above), one k-step each
 constexpr int kMfmaShift = 29;       // the tables hold c 2^(8 b + kMfmaShift): the row finish divides by 2^29 (one Montgomery step)
 PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32; }
 PMX_FN constexpr int mfma_row_words(int t) { return mfma_k_steps(t) * 64 * 4; }             // A operand of one output row
@@ -77,22 +79,24 @@ PMX_FN constexpr size_t mfma_window_words(int t, int k, size_t windows) {
     return (size_t)mfma_layer_words(t) + windows * ((size_t)mfma_layer_words_io(t - 1 + k, t) + (size_t)mfma_window_hist_words(t, k));
 }
 
-// the state's K bytes: nine 32-bit words per element (u - 128 in every byte), padded with zero digits to whole k-steps
+// the state's K bytes: eight 32-bit words per element (u - 128 in every byte); s[j] norm and below 2^256
 template <int T>
 PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
+    static_assert(kMfmaElemBytes == 32 && mfma_k_steps(T) == T, "one k-step per element");
     static_for<0, T>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
+#if defined(PMX_HOSTCHECK) && !defined(__HIPCC__)
+        hostcheck_below_2_256(s[j]);   // tests/hostcheck: the bound the 32-byte form rests on, checked on every element of every layer
+#endif
 #pragma unroll
-        for (int w = 0; w < 9; ++w) {
+        for (int w = 0; w < 8; ++w) {
             const int bit = 32 * w, li = bit / kW, sh = bit % kW;
             uint64_t v = (uint64_t)s[j].l[li] >> sh;
             if (li + 1 < kN) v |= (uint64_t)s[j].l[li + 1] << (kW - sh);
             if (li + 2 < kN && 2 * kW - sh < 32) v |= (uint64_t)s[j].l[li + 2] << (2 * kW - sh);
-            W[9 * j + w] = (uint32_t)v ^ 0x80808080u;
+            W[8 * j + w] = (uint32_t)v ^ 0x80808080u;
         }
     });
-#pragma unroll
-    for (int w = 9 * T; w < 8 * mfma_k_steps(T); ++w) W[w] = 0x80808080u;   // (their table bytes are zero)
 }
 
 // One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's
@@ -204,16 +208,16 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
 // come back unspecified, like matrix_rows_rolled.  s norm.  `tile`: TILE_STEPS KiB of LDS shared by the workgroup's THREADS
 // threads, all of which must arrive here together (two barriers per stage of a row) with every lane active.
 // General form: NIN input elements at `in`, rows [lo, hi) of NOUT into out (which may alias in: the inputs are consumed first).
-// k-steps of the A operand in flight between the tile and the matrix cores (4 registers each): as many as a stage has, up to 8 - but 2 at
-// t = 5, whose kernels sit on the 168 registers of three waves per SIMD (8 ahead: 104 instead of 48 bytes of scratch per lane, -5.5 %;
-// profiles/r05/d_ab_lds_tile_read_ahead.txt)
-PMX_FN constexpr int mfma_lds_ahead(int t) { return t == 5 ? 2 : 8; }
+// k-steps of the A operand in flight between the tile and the matrix cores (4 registers each): as many as a stage has, up to 8 - 4 at
+// t = 5, whose kernels sit on the 168 registers of three waves per SIMD (8 ahead spilled there: -5.5 %, profiles/r05/d_ab_lds_tile_read_ahead.txt)
+PMX_FN constexpr int mfma_lds_ahead(int t) { return t == 5 ? 4 : 8; }
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
                                                     uint32_t lo, uint32_t hi) {
     constexpr int T = NOUT;
     constexpr int NQ = mfma_k_steps(NIN), NW = 8 * NQ;
     constexpr int NS = (NQ + TILE_STEPS - 1) / TILE_STEPS;   // the tile holds TILE_STEPS k-steps: a row passes through it in NS stages
+    constexpr int SPS = (NQ + NS - 1) / NS;                  // ... of SPS k-steps each (the last one the remainder): balanced
     const uint32_t lane = threadIdx.x & 63;
     uint32_t W[NW];
     mfma_state_words<NIN>(in, W);
@@ -224,34 +228,36 @@ __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scrat
     }
     const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(NIN));
     Fe last = out[T - 1];
-    // this thread's share of a stage of the table: fetched from global memory one stage ahead, so that the fetch runs behind
-    // the multiplications of the stage before instead of between the two barriers
-    constexpr int kPer = (TILE_STEPS * 64 + THREADS - 1) / THREADS;
-    mfma_v4i pre[kPer];
-    auto fetch = [&](uint32_t row, int stage) {
-        const mfma_v4i *src = reinterpret_cast<const mfma_v4i *>(layer) + ((size_t)row * NQ + (size_t)stage * TILE_STEPS) * 64;
-        const uint32_t count = (uint32_t)((stage == NS - 1 ? NQ - stage * TILE_STEPS : TILE_STEPS) * 64);
+    // This thread's share of every stage of a row's table, one register buffer per stage: a buffer is refilled with the SAME stage of the
+    // NEXT row as soon as its contents are in the tile, so a fetch has a whole row's time to land.  (With one buffer refilled a stage
+    // ahead - round 4 - the fetch for the second stage of a two-stage row had the 16 products of the first to hide behind: 512 clocks
+    // against an L2 round trip of more; a lone workgroup spent 29 % of its time waiting, profiles/r05/f_c3_by_batch_size.txt.)
+    constexpr int kPer = (SPS * 64 + THREADS - 1) / THREADS;
+    mfma_v4i pre[NS][kPer];
+    auto fetch = [&](uint32_t row, auto st) {
+        constexpr int stage = decltype(st)::value;
+        const mfma_v4i *src = reinterpret_cast<const mfma_v4i *>(layer) + ((size_t)row * NQ + (size_t)stage * SPS) * 64;
+        constexpr uint32_t count = (uint32_t)((stage == NS - 1 ? NQ - stage * SPS : SPS) * 64);
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
             const uint32_t e = threadIdx.x + q * THREADS;
-            if (e < count) pre[q] = src[e];
+            if (e < count) pre[stage][q] = src[e];
         }
     };
-    if (lo < hi) fetch(lo, 0);
+    if (lo < hi) static_for<0, NS>([&](auto st) { fetch(lo, st); });
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (uint32_t i = lo; i < hi; ++i) {
         mfma_v16i d1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d2 = d1;
         static_for<0, NS>([&](auto st) {
-            constexpr int stage = decltype(st)::value, steps = stage == NS - 1 ? NQ - stage * TILE_STEPS : TILE_STEPS;
+            constexpr int stage = decltype(st)::value, steps = stage == NS - 1 ? NQ - stage * SPS : SPS;
             __syncthreads();   // the readers of the stage before are done with the tile
 #pragma unroll
             for (int q = 0; q < kPer; ++q) {
                 const uint32_t e = threadIdx.x + q * THREADS;
-                if (e < (uint32_t)steps * 64) tile[e] = pre[q];
+                if (e < (uint32_t)steps * 64) tile[e] = pre[stage][q];
             }
             __syncthreads();
-            if constexpr (stage + 1 < NS) fetch(i, stage + 1);
-            else if (i + 1 < hi) fetch(i + 1, 0);
+            if (i + 1 < hi) fetch(i + 1, st);
             // The A operand of up to kAhead k-steps is read out of the tile BEFORE the first product of the stage, and a slot is
             // refilled as soon as its pair of products has been issued: left to itself the compiler reads one or two k-steps ahead
             // and then waits the whole LDS round trip (~120 clocks, against the 64 a pair of products keeps the matrix pipe busy)
@@ -263,7 +269,7 @@ __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scrat
             PMX_SCHED_FENCE();   // (the reads stay in front: the scheduler would sink them next to their products again)
 #pragma unroll
             for (int qq = 0; qq < steps; ++qq) {
-                constexpr int q0 = stage * TILE_STEPS;
+                constexpr int q0 = stage * SPS;
                 const int q = q0 + qq;
                 const mfma_v4i b1 = {(int)W[8 * q + 0], (int)W[8 * q + 1], (int)W[8 * q + 2], (int)W[8 * q + 3]};
                 const mfma_v4i b2 = {(int)W[8 * q + 4], (int)W[8 * q + 5], (int)W[8 * q + 6], (int)W[8 * q + 7]};

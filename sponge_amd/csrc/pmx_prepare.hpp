@@ -78,7 +78,7 @@ inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in
         long long colsum[32] = {0};
         for (size_t j = 0; j < n_in; ++j) {
             U256 y = times_pow2(hf, hf.from_mont(rows[i * n_in + j]), kMfmaShift);
-            for (size_t b = 0; b < 33; ++b) {
+            for (size_t b = 0; b < (size_t)kMfmaElemBytes; ++b) {   // (the inputs of a layer are below 2^256: pmx_mfma.hpp)
                 // balanced bytes of y: digit e in [-128, 127], carry into the next
                 unsigned carry = 0;
                 const size_t k = j * kMfmaElemBytes + b, q = k / 32, r = k % 32, h = r / 16, byte = r % 16;
@@ -630,7 +630,8 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     // dense layers of the widest states as int8 GEMM operands
     while (out.consts.size() % 4) out.consts.push_back(0u);   // 16-byte operands
     out.mfma_offset = out.consts.size();
-    out.mfma_dense = out.has_opt && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T && n_full >= 1 && (hf.p.l[3] >> 56) <= 126;
+    // (alpha >= 2: a layer's inputs must be below 2^256 - S-box outputs that ARE products, pmx_mfma.hpp; p < 2^255 is a limit of the build)
+    out.mfma_dense = out.has_opt && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T && n_full >= 1 && (hf.p.l[3] >> 56) <= 126 && cfg->alpha >= 2;
     if (out.mfma_dense) {
         const size_t lw = (size_t)mfma_layer_words((int)t);
         out.consts.resize(out.mfma_offset + (n_full + 1) * lw, 0u);

@@ -27,6 +27,18 @@ void pmx::hostcheck_track(int tag, const Fe &x, const FieldRt &f) {
     const double b = (double)(v / pv);
     if (b > g_max_b[tag]) g_max_b[tag] = b;
 }
+// inputs of the matrix-core layers (pmx_mfma.hpp: mfma_state_words): each must be norm and below 2^256 - the 32-byte form drops the ninth word
+static unsigned long long g_layer_inputs = 0, g_layer_inputs_too_large = 0;
+void pmx::hostcheck_below_2_256(const Fe &x) {
+    ++g_layer_inputs;
+    bool bad = (x.l[kN - 1] >> (256 - kW * (kN - 1))) != 0;      // bits 256 .. 260 live in the top limb
+    for (int i = 0; i < kN; ++i) bad |= x.l[i] > kMask;
+    if (bad) ++g_layer_inputs_too_large;
+}
+extern "C" void hc_layer_inputs(unsigned long long *seen, unsigned long long *too_large) {
+    *seen = g_layer_inputs;
+    *too_large = g_layer_inputs_too_large;
+}
 extern "C" void hc_track_reset() {
     for (int t = 0; t < 4; ++t) { g_max_limb[t] = 0; g_max_b[t] = 0; }
 }

@@ -1,6 +1,9 @@
-"""The N>1 path on CPU: world_size-2 gloo processes exercise the sharding, the final gather and the sharded
-Merkle reduction exactly as bench.py drives them on GPUs (there the per-rank engine is the HIP library; here
-the oracle's C restatement stands in as the per-rank engine so that no GPU is needed)."""
+"""The torch.distributed helpers of sponge_amd/distributed.py on CPU: world_size-2 gloo processes exercise the shard arithmetic, the
+equal and the ragged (host-staged) gather and the sharded Merkle reduction that `bench.py --allow-torch-gather` / PMX_BENCH_REHEARSAL=1
+fall back to.  What this file tests is those Python helpers - the per-rank engine here is the oracle's C restatement, so that no GPU is
+needed.  It does NOT test the product's multi-rank path: that is pmx_mgpu_* in the C ABI, whose every world > 1 branch runs on a GPU
+behind the stand-in collective library (tests/test_gpu_mgpu_standin.py: in-process slots, one process per rank, and bench.py's own
+`--gpus N` forms) and on real RCCL with as many ranks as the box has GPUs (tests/test_gpu_mgpu.py)."""
 import os
 import socket
 

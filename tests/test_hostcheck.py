@@ -393,6 +393,11 @@ def test_partial_rounds_as_windows_every_size_and_width(K):
         out = limbs.copy()
         assert hc.hc_permute_hybrid_mfma(ctypes.byref(c), out.ctypes.data, len(states)) == 0, (K, t, alpha, rf, rp)
         assert cref.limbs_to_elems(out, p) == want, (K, t, alpha, rf, rp)
+    # every element that entered a matrix-core layer above - S-box outputs and rows of the layer before, over all these widths, exponents
+    # and edge states - was norm and below 2^256: the bound the 32-byte (one k-step per element) form of pmx_mfma.hpp rests on
+    seen, too_large = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    hc.hc_layer_inputs(ctypes.byref(seen), ctypes.byref(too_large))
+    assert seen.value > 1000 and too_large.value == 0, (seen.value, too_large.value)
 
 
 @pytest.mark.parametrize("rate", [2, 4])
