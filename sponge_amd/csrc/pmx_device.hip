@@ -216,7 +216,7 @@ constexpr int kHybWaves = 1, kHyb4WaveMaxT = 4, kHyb3WaveMaxT = 6;
 // launches: inside a per-lane loop not every lane is active, and the lane exchange of this path needs both lanes of a pair).
 // Register bounds of the matrix-core engines (their byte strings and sums want registers), measured per width:
 #ifndef PMX_MFMA_4WAVE_MAX_T
-#define PMX_MFMA_4WAVE_MAX_T 2
+#define PMX_MFMA_4WAVE_MAX_T 3   // (t = 3: 123 / 125 VGPRs since the 32-byte elements of round 5 - four waves without a spill; it was 151 before)
 #endif
 #ifndef PMX_MFMA_3WAVE_MAX_T
 #define PMX_MFMA_3WAVE_MAX_T 5

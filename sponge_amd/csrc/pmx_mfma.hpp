@@ -22,9 +22,9 @@
 //     carry pass, a re-cut into ten 29-bit limbs and ONE Montgomery step (division by 2^29, which the table carries: round 3
 //     took two, but V / 2^29 + p already fits nine limbs) give the row below 2^243 + p - 9 multiplies instead of 810.
 //
-// The 11 KiB of table one row of t = 9 needs pass through an LDS tile once per WORKGROUP, in stages (read per wave from L2 they
-// are 101 KiB per wave and layer and the L2 -> L1 path sets the time), which is why the engines that use this run several waves
-// per workgroup (pmx_device.hip: PMX_MFMA_WAVES, PMX_MFMA_TILE_STEPS).  tools/mfma_dense_proto.{py,hip} is the stand-alone form of the same code with its check against Python
+// The table of one row (n_in KiB: 9 for a dense row of t = 9, 14 for a row of its window layers) passes through an LDS tile once per
+// WORKGROUP, in stages (read per wave from L2 the L2 -> L1 path sets the time), which is why the engines that use this run several waves
+// per workgroup (pmx_device.hip: kMfmaWaves, HybridEngine::kTileSteps).  tools/mfma_dense_proto.{py,hip} is the stand-alone form of the same code with its check against Python
 // integers; profiles/r03/g_mfma_dense_proto.txt its measurements.
 #pragma once
 

@@ -528,3 +528,14 @@ def test_absorb_addition_on_abi_residues(hc, p):
         out = np.zeros(4, dtype=np.uint64)
         assert hc.hc_field_op(mod.ctypes.data, 4, aa.ctypes.data, bb.ctypes.data, out.ctypes.data) == 0
         assert O.from_limbs([int(x) for x in out]) == (a + b) % p
+    # unreduced device-resident data (the host entry points reject it; `_dev` callers own their buffers): the carry out of the 256-bit
+    # sum takes part in the select, so a sum of 2^256 or more is still reduced once - congruent to a + b mod p like the per-lane kernels'
+    # arithmetic, never the bare low 256 bits of the sum
+    for a, b in [(2**256 - 1, 2**256 - 1), (2**256 - 1, 1), (2**255, 2**255), (p + 5, 2**256 - p)]:
+        aa = np.array(O.to_limbs(a), dtype=np.uint64)
+        bb = np.array(O.to_limbs(b), dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        assert hc.hc_field_op(mod.ctypes.data, 4, aa.ctypes.data, bb.ctypes.data, out.ctypes.data) == 0
+        got = O.from_limbs([int(x) for x in out])
+        assert got == (a + b - p) % 2**256, (a, b, got)            # one subtraction of p, whatever the carry
+        assert got % p == (a + b) % p or a + b - p >= 2**256       # ... which is congruent to a + b whenever the difference fits 256 bits

@@ -61,3 +61,27 @@ def test_null_arguments():
     assert lib.pmx_ctx_release(None) == _lib.PMX_OK
     assert lib.pmx_ctx_cache_clear() == _lib.PMX_OK
     assert not lib.pmx_mgpu_stream(None, 0) and not lib.pmx_mgpu_ctx(None, 0)
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must not answer with a usage message (rounds 1-4 did): it starts
+    its ranks itself, as a CHILD process, and exits with the child's code.  Without a GPU every rank refuses ("no CPU fallback") and the
+    code is not zero - what this CPU test pins is the launcher: the child command, no hang, no exec, the failure carried back.  The same
+    command on one GPU behind the stand-in collective library, with its JSON line checked: tests/test_gpu_mgpu_standin.py."""
+    import os
+    import subprocess
+    import sys
+    if _lib.lib().pmx_device_count() > 0:
+        pytest.skip("a GPU is present: tests/test_gpu_mgpu_standin.py runs the real thing")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode != 0 and not p.stdout.strip(), (p.returncode, p.stdout[-500:])
+    assert "launching the ranks as a child process" in err and "torch.distributed.run" in err and "--nproc-per-node=2" in err
+    assert "needs an MI355X" in err, err[-2000:]
+    # ... and the one-process form says the same without starting anything
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0 and b"needs an MI355X" in p.stderr
