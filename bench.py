@@ -86,7 +86,7 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     if chain is None:
         bits = bin(alpha)[3:]
         chain = len(bits) * sqr + bits.count("1") * mul
-    red = 18 if row_tables else 81
+    red = 18 if row_tables == 1 or row_tables is True else 81
     dot = 81 * t + red                                      # a t-term row
     norm = 81 * (t - 1) + red + 9                           # a normalised row: t - 1 terms + 9 multiply-by-one injections of the addend
     lane = (81 + 18 + 9) if lane_tables else (mul + 9)
@@ -98,7 +98,10 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     if optimised and mfma_dense and window > 0:
         n_win = -(-rp // window)
         sizes = [rp - (n_win - 1) * window] + [window] * (n_win - 1)
-        hist = sum(81 * (k - 1) + red + 9 for kw in sizes for k in range(2, kw))     # (`row_tables`: their constants as shifted tables)
+        if row_tables == 2:      # the history terms as rows on the matrix cores too (pmx_mfma.hpp: mfma_hist_rows): a row finish each
+            hist = sum(9 for kw in sizes for k in range(2, kw))
+        else:
+            hist = sum(81 * (k - 1) + red + 9 for kw in sizes for k in range(2, kw))     # (`row_tables`: their constants as shifted tables)
         return (rf * t + rp) * chain + (rf + n_win) * t * 9 + hist
     if optimised:
         # S-box layers: RF full, RP partial.  Linear layers: RF - 2 normalised dense (every full round but the entrance and the
@@ -745,11 +748,11 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
     op = _lib.OP_COMPRESS if merkle else (_lib.OP_HASH if hashing else (_lib.OP_ABSORB if duplex else _lib.OP_PERMUTE))
     _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, op, (n // 2 if merkle else n), (in_len if duplex else 0), info))
     mfma_dense = bool(info.mfma_dense)
-    mads = mads_per_permutation(t, alpha, rf, rp, optimised=bool(info.optimised), row_tables=bool(info.row_tables),
+    mads = mads_per_permutation(t, alpha, rf, rp, optimised=bool(info.optimised), row_tables=int(info.row_tables),
                                 lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense, window=int(info.partial_window))
     # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
     # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
-    last_row = 9 if mfma_dense else 81 * t + (18 if info.row_tables else 81)
+    last_row = 9 if mfma_dense else 81 * t + (18 if info.row_tables == 1 else 81)
     if merkle:
         mads -= (t - 1) * last_row
     elif hashing:
@@ -773,7 +776,7 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
                              if args.workload == "c2" and baseline_cfg else None},
         "engine": {"name": info.engine.decode(), "threads_per_workgroup": info.threads, "waves_per_simd": info.waves_per_simd,
                    "lds_bytes_per_workgroup": info.lds_bytes, "optimised_schedule": bool(info.optimised),
-                   "row_tables": bool(info.row_tables), "lane_tables": bool(info.lane_tables), "mfma_dense": mfma_dense,
+                   "row_tables": bool(info.row_tables), "history_rows_on_matrix_cores": int(info.row_tables) == 2, "lane_tables": bool(info.lane_tables), "mfma_dense": mfma_dense,
                    "partial_window": int(info.partial_window),
                    "source": "pmx_ctx_engine_info (the launchers' own dispatch conditions)" + (", widest level of the tree" if merkle else "")},
         "rccl": rccl,

@@ -149,7 +149,8 @@ typedef struct pmx_engine_info {
     int waves_per_simd;  /* the kernel's launch bound (what its register allocation is held to) */
     int lds_bytes;       /* dynamic LDS per workgroup */
     int optimised;       /* 1: optimised round schedule (sparse partial rounds, normalised layers), 0: the reference's dense one */
-    int row_tables;      /* 1: t-term matrix rows consume shifted tables (81 t + 18 multiplies), 0: element form (81 t + 81) */
+    int row_tables;      /* 1: t-term matrix rows consume shifted tables (81 t + 18 multiplies), 0: element form (81 t + 81);
+                          * window engines: how the history terms of the S-box inputs are formed - 1 shifted tables, 2 rows on the matrix cores */
     int lane_tables;     /* 1: identity-lane updates of the sparse layers consume shifted tables */
     int mfma_dense;      /* 1: rows of the dense layers come from the matrix cores (int8 GEMM, pmx_mfma.hpp) */
     int launches;        /* kernel launches of the call: 1, or the passes of an absorb / squeeze call on wide states (and on device-filling t = 3 calls) */

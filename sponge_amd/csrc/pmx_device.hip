@@ -445,8 +445,8 @@ struct HybridEngine {
         else std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,%s>", T, ALPHA, MFMA ? "mfma" : "valu");
         o.threads = kThreads;
         o.optimised = 1;
-        // (window engines: the only rows left on the VALU are the history products of the S-box inputs - pmx_mfma.hpp: mfma_hist_tab)
-        o.row_tables = (MFMA && mfma_window_for(T) > 0) ? (mfma_hist_tab(T) ? 1 : 0) : (T <= kHybridTabMaxT);
+        // (window engines: the only rows left are the history terms of the S-box inputs - 1: shifted tables on the VALU, 2: rows on the matrix cores)
+        o.row_tables = (MFMA && mfma_window_for(T) > 0) ? (mfma_hist_tab(T) ? 1 : 2) : (T <= kHybridTabMaxT);
         o.lane_tables = 1;   // (the identity lanes of the VALU-row engines take shifted tables at every width)
         o.mfma_dense = MFMA;
         o.partial_window = MFMA ? mfma_window_for(T) : 0;

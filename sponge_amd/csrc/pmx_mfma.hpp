@@ -60,43 +60,56 @@ PMX_FN constexpr int mfma_window_for(int t) {
     return (t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T) ? (PMX_MFMA_WINDOW < t ? PMX_MFMA_WINDOW : t) : 0;
 }
 PMX_FN constexpr int mfma_window_hist(int k) { return (k - 1) * (k - 2) / 2; }   // history constants per window
-// The history constants as stored: elements (kFeStride words each), or - widths up to PMX_MFMA_HIST_TAB_MAX_T - shifted tables
-// (pmx_field.hpp: tab_dot), one row of k - 1 constants per S-box input x_{k+1}, k = 2 .. K - 1: 63 multiplies fewer per input
-// (81 (k-1) + 27 instead of 81 (k-1) + 90) for a constant stream that needs a third wave on the SIMD to hide behind - measured
-// (profiles/r04/q_ab_history_tables.txt): t = 3 +1.4 %, t = 5 +0.7 %, t = 6 -2.9 %, t = 8 -3.3 %, t = 9 -1.8 %.
+// The history terms of a window's S-box inputs, x_{k+1} - z_k = u_k + sum_{i<k} h_{k,i} z_i (k = 2 .. K - 1): at t = 3 - ONE term per window -
+// a product by a shifted table on the VALU (pmx_field.hpp: tab_dot; profiles/r04/q_ab_history_tables.txt), from t = 4 rows on the matrix
+// cores (below; profiles/r05/k_ab_history_rows_on_the_matrix_cores.txt, l_ab_history_rows_t4_t5.txt: t = 4 +1.8 %, 5 +3.7 %, 6 +6.3 %, 7 +4.7 %,
+// 8 +4.9 %, 9 +3.6 % over tables (t <= 5) / elements (t >= 6)).
 #ifndef PMX_MFMA_HIST_TAB_MAX_T
-#define PMX_MFMA_HIST_TAB_MAX_T 5
+#define PMX_MFMA_HIST_TAB_MAX_T 3
 #endif
 PMX_FN constexpr bool mfma_hist_tab(int t) { return t <= PMX_MFMA_HIST_TAB_MAX_T; }
+// ROWS ON THE MATRIX CORES (round 5): the history term is itself a product by constants of values that are cut into bytes for the window's
+// layer anyway - one row of k inputs (z_1 .. z_{k-1}, u_k), its A operand read straight from global memory a whole S-box ahead (k KiB per
+// wave: no tile, no barrier), its 2 k products issued right behind S-box k.  125 VALU instructions + 2 k products instead of the
+// 81 (k - 1) + 90 multiplies of the element form (t = 9: 4 rows and 28 products per window instead of 1170 multiplies).
+PMX_FN constexpr bool mfma_hist_rows(int t) { return !mfma_hist_tab(t); }
+PMX_FN constexpr int mfma_hist_row_words(int k) { return mfma_k_steps(k) * 64 * 4 + 16; }          // the row of x_{k+1}: k inputs, eight correction words
+PMX_FN constexpr int mfma_hist_rows_offset(int k) {                                               // words in front of it
+    int w = 0;
+    for (int j = 2; j < k; ++j) w += mfma_hist_row_words(j);
+    return w;
+}
+// input q of that row, as an index into the window layer's inputs (u_1 .. u_{t-1}, z_1 .. z_K): z_1 .. z_{k-1}, then u_k
+PMX_FN constexpr int mfma_hist_row_input(int t, int k, int q) { return q < k - 1 ? t - 1 + q : k - 1; }
 PMX_FN constexpr int mfma_hist_tab_offset(int k) {   // words in front of the row of x_{k+1}
     int w = 0;
     for (int j = 2; j < k; ++j) w += tab_row_words(j - 1);
     return w;
 }
-PMX_FN constexpr int mfma_window_hist_words(int t, int k) { return mfma_hist_tab(t) ? mfma_hist_tab_offset(k) : mfma_window_hist(k) * kFeStride; }
+PMX_FN constexpr int mfma_window_hist_words(int t, int k) { return mfma_hist_tab(t) ? mfma_hist_tab_offset(k) : mfma_hist_rows_offset(k); }
 // words of the window tables of a config: the entry layer (t -> t), then per window its layer (t - 1 + K -> t) and its history constants
 PMX_FN constexpr size_t mfma_window_words(int t, int k, size_t windows) {
     return (size_t)mfma_layer_words(t) + windows * ((size_t)mfma_layer_words_io(t - 1 + k, t) + (size_t)mfma_window_hist_words(t, k));
 }
 
-// the state's K bytes: eight 32-bit words per element (u - 128 in every byte); s[j] norm and below 2^256
+// one element's K bytes: eight 32-bit words (u - 128 in every byte); x norm and below 2^256
+PMX_FN void mfma_cut_element(const Fe &x, uint32_t *w8) {
+#if defined(PMX_HOSTCHECK) && !defined(__HIPCC__)
+    hostcheck_below_2_256(x);   // tests/hostcheck: the bound the 32-byte form rests on, checked on every element of every layer
+#endif
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const int bit = 32 * w, li = bit / kW, sh = bit % kW;
+        uint64_t v = (uint64_t)x.l[li] >> sh;
+        if (li + 1 < kN) v |= (uint64_t)x.l[li + 1] << (kW - sh);
+        if (li + 2 < kN && 2 * kW - sh < 32) v |= (uint64_t)x.l[li + 2] << (2 * kW - sh);
+        w8[w] = (uint32_t)v ^ 0x80808080u;
+    }
+}
 template <int T>
 PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
     static_assert(kMfmaElemBytes == 32 && mfma_k_steps(T) == T, "one k-step per element");
-    static_for<0, T>([&](auto jj) {
-        constexpr int j = decltype(jj)::value;
-#if defined(PMX_HOSTCHECK) && !defined(__HIPCC__)
-        hostcheck_below_2_256(s[j]);   // tests/hostcheck: the bound the 32-byte form rests on, checked on every element of every layer
-#endif
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const int bit = 32 * w, li = bit / kW, sh = bit % kW;
-            uint64_t v = (uint64_t)s[j].l[li] >> sh;
-            if (li + 1 < kN) v |= (uint64_t)s[j].l[li + 1] << (kW - sh);
-            if (li + 2 < kN && 2 * kW - sh < 32) v |= (uint64_t)s[j].l[li + 2] << (2 * kW - sh);
-            W[8 * j + w] = (uint32_t)v ^ 0x80808080u;
-        }
-    });
+    static_for<0, T>([&](auto jj) { mfma_cut_element(s[decltype(jj)::value], &W[8 * decltype(jj)::value]); });
 }
 
 // One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's
@@ -159,37 +172,65 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
 
 #if !defined(__HIPCC__)
 // Host form for tests/hostcheck (g++, no matrix cores): the same tables, bytes and finish, the GEMM as plain integer sums.
-// NIN input elements -> rows [lo, hi) of NOUT into out (NOUT - 1 <= the scratch's slots).
-template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
-inline void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, void * /*tile*/, const FieldRt &f, uint32_t lo, uint32_t hi) {
-    constexpr int NQ = mfma_k_steps(NIN);
-    uint32_t W[8 * NQ];
-    mfma_state_words<NIN>(in, W);
+// the 32 sums of row i of a layer with NQ k-steps over the operand words W, finished
+template <int NQ>
+inline Fe mfma_row_host(const uint32_t *W, const uint32_t *layer, size_t n_rows, uint32_t i, const FieldRt &f) {
     const int8_t *bytes = reinterpret_cast<const int8_t *>(layer);
-    const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)NOUT * mfma_row_words(NIN));
+    const long long *corr = reinterpret_cast<const long long *>(layer + n_rows * (size_t)(NQ * 64 * 4));
+    int32_t R[8][4];
+    for (int e = 0; e < 32; ++e) {
+        long long sum = 0;
+        for (int k = 0; k < 32 * NQ; ++k) {
+            const int u = (int)(int8_t)((W[k / 4] >> (8 * (k % 4))) & 0xff);
+            const int q = k / 32, h = (k % 32) / 16, byte = k % 16;
+            sum += (long long)u * bytes[(((size_t)i * NQ + q) * 64 + 32 * h + e) * 16 + byte];
+        }
+        R[e / 4][e % 4] = (int32_t)sum;
+    }
+    return mfma_row_finish(R, corr + (size_t)i * 8, f);
+}
+// the operand form of an element (device: the second half of the words goes to the partner lane)
+inline void mfma_cut_operand(const Fe &x, uint32_t *w8) { mfma_cut_element(x, w8); }
+// rows [lo, hi) of NOUT over the operand words of NIN inputs (NOUT - 1 <= the scratch's slots)
+template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
+inline void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, void * /*tile*/, const FieldRt &f, uint32_t lo, uint32_t hi) {
     Fe last = out[NOUT - 1];
     for (uint32_t i = lo; i < hi; ++i) {
-        int32_t R[8][4];
-        for (int e = 0; e < 32; ++e) {
-            long long sum = 0;
-            for (int k = 0; k < 32 * NQ; ++k) {
-                const int u = (int)(int8_t)((W[k / 4] >> (8 * (k % 4))) & 0xff);
-                const int q = k / 32, h = (k % 32) / 16, byte = k % 16;
-                sum += (long long)u * bytes[(((size_t)i * NQ + q) * 64 + 32 * h + e) * 16 + byte];
-            }
-            R[e / 4][e % 4] = (int32_t)sum;
-        }
-        const Fe row = mfma_row_finish(R, corr + (size_t)i * 8, f);
+        const Fe row = mfma_row_host<NIN>(W, layer, NOUT, i, f);
         if (i + 1 < (uint32_t)NOUT) sc.set(i, row);
         else last = row;
     }
     static_for<0, NOUT - 1>([&](auto i) { out[i] = sc.get(i); });
     out[NOUT - 1] = last;
 }
+template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
+inline void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi) {
+    uint32_t W[8 * NIN];
+    mfma_state_words<NIN>(in, W);
+    matrix_rows_mfma_w<NIN, NOUT, THREADS, TILE_STEPS>(W, out, sc, layer, tile, f, lo, hi);
+}
 template <int T, int THREADS, int TILE_STEPS, class Scratch>
 inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi) {
     matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi);
 }
+// one history row of a window (mfma_hist_rows): load / products / finish, as the device issues them around an S-box
+template <int T>
+struct MfmaHistRow {
+    const uint32_t *loaded = nullptr, *table = nullptr;   // (the next row is loaded while this one is still to be finished)
+    uint32_t Wc[8 * PMX_MFMA_WINDOW];
+    template <int KK>
+    void load(const uint32_t *tab) { loaded = tab; }
+    template <int KK, int NW>
+    void products(const uint32_t (&W)[NW]) {
+        table = loaded;
+        static_for<0, KK>([&](auto qq) {
+            constexpr int q = decltype(qq)::value, g = mfma_hist_row_input(T, KK, q);
+            for (int w = 0; w < 8; ++w) Wc[8 * q + w] = W[8 * g + w];
+        });
+    }
+    template <int KK>
+    Fe finish(const FieldRt &f) { return mfma_row_host<KK>(Wc, table, 1, 0, f); }
+};
 #endif
 
 #if defined(__HIPCC__)   // (tests/hostcheck compiles the headers with g++: no matrix cores there)
@@ -211,21 +252,22 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
 // k-steps of the A operand in flight between the tile and the matrix cores (4 registers each): as many as a stage has, up to 8 - 4 at
 // t = 5, whose kernels sit on the 168 registers of three waves per SIMD (8 ahead spilled there: -5.5 %, profiles/r05/d_ab_lds_tile_read_ahead.txt)
 PMX_FN constexpr int mfma_lds_ahead(int t) { return t == 5 ? 4 : 8; }
+// the operand form of an element: its eight words, the second half handed to the partner lane (+-32) - lanes 32-63 of a product feed
+// the second half of every k-step for the states of lanes 0-31
+__device__ __forceinline__ void mfma_cut_operand(const Fe &x, uint32_t *w8) {
+    mfma_cut_element(x, w8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lane32_swap(w8[u], w8[4 + u]);
+}
+// the rows over the operand words W of the NIN inputs (mfma_cut_operand each)
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
-__device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
-                                                    uint32_t lo, uint32_t hi) {
+__device__ __forceinline__ void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
+                                                   uint32_t lo, uint32_t hi) {
     constexpr int T = NOUT;
-    constexpr int NQ = mfma_k_steps(NIN), NW = 8 * NQ;
+    constexpr int NQ = mfma_k_steps(NIN);
     constexpr int NS = (NQ + TILE_STEPS - 1) / TILE_STEPS;   // the tile holds TILE_STEPS k-steps: a row passes through it in NS stages
     constexpr int SPS = (NQ + NS - 1) / NS;                  // ... of SPS k-steps each (the last one the remainder): balanced
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t W[NW];
-    mfma_state_words<NIN>(in, W);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) lane32_swap(W[8 * q + u], W[8 * q + 4 + u]);
-    }
     const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(NIN));
     Fe last = out[T - 1];
     // This thread's share of every stage of a row's table, one register buffer per stage: a buffer is refilled with the SAME stage of the
@@ -299,11 +341,60 @@ __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scrat
     static_for<0, T - 1>([&](auto i) { out[i] = sc.get(i); });
     out[T - 1] = last;
 }
+template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
+__device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
+                                                    uint32_t lo, uint32_t hi) {
+    uint32_t W[8 * NIN];
+    static_for<0, NIN>([&](auto j) { mfma_cut_operand(in[decltype(j)::value], &W[8 * decltype(j)::value]); });
+    matrix_rows_mfma_w<NIN, NOUT, THREADS, TILE_STEPS>(W, out, sc, layer, tile, f, lo, hi);
+}
 template <int T, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f, uint32_t lo,
                                                  uint32_t hi) {
     matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi);
 }
+
+// One history row of a window (mfma_hist_rows): load<KK> fetches the row's A operand (KK k-steps, 16 bytes per lane each) straight from
+// global memory - issued a whole S-box before products<KK> consumes it -, products<KK> issues the 2 KK matrix-core instructions over the
+// operand words of its inputs, finish<KK> brings the sums home and reduces them.  Every lane of the wave must be active.
+template <int T>
+struct MfmaHistRow {
+    mfma_v4i a[PMX_MFMA_WINDOW > 2 ? PMX_MFMA_WINDOW - 1 : 1];
+    mfma_v16i d1, d2;
+    const long long *loaded_corr, *corr;   // (the next row is loaded while this one is still to be finished)
+    template <int KK>
+    __device__ __forceinline__ void load(const uint32_t *table) {
+        const mfma_v4i *src = reinterpret_cast<const mfma_v4i *>(table) + (threadIdx.x & 63);
+#pragma unroll
+        for (int q = 0; q < KK; ++q) a[q] = src[q * 64];
+        loaded_corr = reinterpret_cast<const long long *>(table + (size_t)mfma_k_steps(KK) * 64 * 4);
+    }
+    template <int KK, int NW>
+    __device__ __forceinline__ void products(const uint32_t (&W)[NW]) {
+        const mfma_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        d1 = zero, d2 = zero;
+        corr = loaded_corr;
+        static_for<0, KK>([&](auto qq) {
+            constexpr int q = decltype(qq)::value, g = mfma_hist_row_input(T, KK, q);
+            const mfma_v4i b1 = {(int)W[8 * g + 0], (int)W[8 * g + 1], (int)W[8 * g + 2], (int)W[8 * g + 3]};
+            const mfma_v4i b2 = {(int)W[8 * g + 4], (int)W[8 * g + 5], (int)W[8 * g + 6], (int)W[8 * g + 7]};
+            d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q], b1, d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q], b2, d2, 0, 0, 0);
+        });
+    }
+    template <int KK>
+    __device__ __forceinline__ Fe finish(const FieldRt &f) {
+        int32_t R[8][4];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            uint32_t x = (uint32_t)d1[v], y = (uint32_t)d2[v];
+            lane32_swap(x, y);
+            R[2 * (v / 4)][v % 4] = (int32_t)x;
+            R[2 * (v / 4) + 1][v % 4] = (int32_t)y;
+        }
+        return mfma_row_finish(R, corr, f);
+    }
+};
 
 #endif  // __HIPCC__
 

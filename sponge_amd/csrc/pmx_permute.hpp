@@ -311,33 +311,65 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             if (r == first_partial) {   // the whole partial section: windows, each closed by one layer on the matrix cores
                 constexpr int K = MFMA_WINDOW, NIN = T - 1 + K;
                 constexpr size_t kLayer = (size_t)mfma_layer_words_io(NIN, T), kPer = kLayer + (size_t)mfma_window_hist_words(T, K);
-                constexpr bool kHistTab = mfma_hist_tab(T);
                 const uint32_t n_win = (c.partial_rounds + K - 1) / K;
                 uint32_t kw = c.partial_rounds - (n_win - 1) * K;   // the first window is the short one
                 const uint32_t *wt = tb.win + mfma_layer_words(T);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (uint32_t w = 0; w < n_win; ++w, wt += kPer, kw = K) {
+                    const uint32_t *hist = wt + kLayer;
+                    if constexpr (mfma_hist_rows(T)) {
+                        // History terms as rows on the matrix cores (pmx_mfma.hpp: mfma_hist_rows).  The inputs of the window's layer are cut into
+                        // operand words as they appear - the carried lanes now, every S-box output when it exists - and the row of x_{k+1}
+                        // (inputs z_1 .. z_{k-1}, u_k) is formed right behind S-box k from a table fetched in front of it.
+                        uint32_t W[8 * NIN];
+                        static_for<1, T>([&](auto i) { mfma_cut_operand(s[i], &W[8 * (i - 1)]); });
+                        MfmaHistRow<T> hr;
+                        if constexpr (K > 2) hr.template load<2>(hist);
+                        Fe z = fe_sbox<ALPHA>(s[0], c.alpha, one, f);                 // z_1 = x_1^alpha: x_1 came whole out of the layer before
+                        mfma_cut_operand(z, &W[8 * (T - 1)]);
+                        Fe x = fe_add_lazy(s[1], z);                                  // x_2 = z_1 + u_1
+                        static_for<2, K + 1>([&](auto kk) {
+                            constexpr int k = decltype(kk)::value;                    // S-box k, and in front of it the row of x_{k+1}
+                            if ((uint32_t)k <= kw) {
+                                const bool row = k < K && (uint32_t)k < kw;           // (wave-uniform)
+                                z = fe_sbox<ALPHA>(x, c.alpha, one, f);
+                                mfma_cut_operand(z, &W[8 * (T - 2 + k)]);
+                                if constexpr (k < K) {
+                                    // The row's products are issued BEHIND S-box k, its A operand having been fetched in front of it: issued in
+                                    // front as well (they need none of z_k) the 32 sums stay live across the S-box and the kernels of t = 8, 9
+                                    // spill (C3 -3.3 %, t = 8 -1.9 %, t = 6, 7 the same: profiles/r05/k_ab_history_rows_in_front_of_or_behind_their_sbox.txt)
+                                    if (row) {
+                                        hr.template products<k>(W);
+                                        if constexpr (k + 1 < K) hr.template load<k + 1>(hist + mfma_hist_rows_offset(k + 1));
+                                        x = fe_add_lazy(hr.template finish<k>(f), z);   // x_{k+1} = z_k + (u_k + sum_{i<k} h_{k,i} z_i)
+                                    }
+                                }
+                            } else {
+                                mfma_cut_operand(fe_zero(), &W[8 * (T - 2 + k)]);     // a short first window: no such round (its table columns are zero)
+                            }
+                        });
+#if defined(__HIPCC__)
+                        matrix_rows_mfma_w<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(W, s, sc, wt, static_cast<mfma_v4i *>(tile), f, 0u, (uint32_t)T);
+#else
+                        matrix_rows_mfma_w<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(W, s, sc, wt, tile, f, 0u, (uint32_t)T);
+#endif
+                    } else {
                     Fe in[NIN];
                     static_for<1, T>([&](auto i) { in[i - 1] = s[i]; });
-                    const uint32_t *hist = wt + kLayer;
                     in[T - 1] = fe_sbox<ALPHA>(s[0], c.alpha, one, f);               // z_1 = x_1^alpha: x_1 came whole out of the layer before
                     static_for<1, K>([&](auto kk) {
                         constexpr int k = decltype(kk)::value;                        // z_{k+1} from x_{k+1} = z_k + u_k + sum_{i<k} h_{k,i} z_i
                         if ((uint32_t)k < kw) {
                             Fe x = s[k];
-                            if constexpr (k == 2 && kHistTab) {        // one constant: the compact single-constant table
+                            if constexpr (k == 2) {                    // one constant: the compact single-constant table
                                 PMX_SCHED_FENCE();
                                 tab_lanes_stream<1>(in[T - 1], hist, &x, f);
                                 PMX_SCHED_FENCE();
-                            } else if constexpr (k >= 3 && kHistTab) {
+                            } else if constexpr (k >= 3) {
                                 const Fe x0 = x;
                                 PMX_SCHED_FENCE();
                                 x = tab_dot_stream<k - 1, true>(&in[T - 1], hist + mfma_hist_tab_offset(k), f, &x0);
                                 PMX_SCHED_FENCE();
-                            } else if constexpr (k >= 2) {
-                                Fe hc[k - 1];
-                                static_for<0, k - 1>([&](auto i) { hc[i] = fe_const(hist + (size_t)(mfma_window_hist(k) + i) * kFeStride); });
-                                x = mont_dot_add<k - 1>(&in[T - 1], hc, x, f);
                             }
                             in[T - 1 + k] = fe_sbox<ALPHA>(fe_add_lazy(x, in[T - 2 + k]), c.alpha, one, f);
                         } else {
@@ -349,6 +381,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
 #else
                     matrix_rows_mfma_io<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(in, s, sc, wt, tile, f, 0u, (uint32_t)T);
 #endif
+                    }
                 }
                 r = last_partial;
                 continue;

@@ -657,8 +657,12 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
                 if (mfma_hist_tab((int)t)) {
                     for (uint32_t k = 2; k < K; ++k)
                         put_shifted_row(hf, &plan.hist[w * nh + (size_t)mfma_window_hist((int)k)], k - 1, dst + mfma_hist_tab_offset((int)k));
-                } else {
-                    for (size_t h = 0; h < nh; ++h) to_limbs29(times_pow2(hf, plan.hist[w * nh + h], 5), dst + h * kFeStride);
+                } else {   // the history terms as matrix-core rows: the row of x_{k+1} over (z_1 .. z_{k-1}, u_k), coefficients (h_{k,.}, ONE)
+                    for (uint32_t k = 2; k < K; ++k) {
+                        std::vector<U256> row(&plan.hist[w * nh + (size_t)mfma_window_hist((int)k)], &plan.hist[w * nh + (size_t)mfma_window_hist((int)k)] + (k - 1));
+                        row.push_back(hf.r);
+                        put_mfma_layer_io(hf, row.data(), k, 1, nullptr, dst + mfma_hist_rows_offset((int)k));
+                    }
                 }
                 dst += (size_t)mfma_window_hist_words((int)t, (int)K);
             }
