@@ -73,6 +73,11 @@ PMX_FN constexpr bool mfma_hist_tab(int t) { return t <= PMX_MFMA_HIST_TAB_MAX_T
 // wave: no tile, no barrier), its 2 k products issued right behind S-box k.  125 VALU instructions + 2 k products instead of the
 // 81 (k - 1) + 90 multiplies of the element form (t = 9: 4 rows and 28 products per window instead of 1170 multiplies).
 PMX_FN constexpr bool mfma_hist_rows(int t) { return !mfma_hist_tab(t); }
+// With the history terms as rows, the only outputs of a layer inside the partial section that are ever needed as field ELEMENTS are row 0
+// (x_1, the first S-box input) and row 1 (u_1: x_2 = z_1 + u_1); the other carried lanes only ever enter matrix-core rows again.  Those
+// rows are finished in OPERAND form (mfma_row_finish_operand: one Montgomery step of 32 bits in the word domain, the result - below
+// 2^240 + p - IS the eight operand words) and travel between the layers as such: no re-cut into limbs, no 29-bit step, no byte cut.
+PMX_FN constexpr int mfma_fe_rows(int t) { return mfma_hist_rows(t) ? 2 : t; }
 PMX_FN constexpr int mfma_hist_row_words(int k) { return mfma_k_steps(k) * 64 * 4 + 16; }          // the row of x_{k+1}: k inputs, eight correction words
 PMX_FN constexpr int mfma_hist_rows_offset(int k) {                                               // words in front of it
     int w = 0;
@@ -114,8 +119,7 @@ PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
 
 // One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's
 // correction, as eight 64-bit word sums with carries, re-cut into ten 29-bit limbs, one Montgomery step: V 2^-29 mod p, below 2^243 + p.
-PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
-    uint32_t wd[9];
+PMX_FN void mfma_row_word_sums(const int32_t (&R)[8][4], const long long *corr, uint32_t (&wd)[9]) {
     // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from
     // registers the compiler cannot see through, or it would turn each into a sign extension, a 64-bit shift and a 64-bit add - and
     // from VECTOR registers, so that the row's correction, a wave-uniform 64-bit value in a scalar pair, can be the addend of the word's
@@ -142,6 +146,10 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
         carry = (int)(t >> 32);
     }
     wd[8] = (uint32_t)carry;   // V >= 0: the top carry is not negative
+}
+PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
+    uint32_t wd[9];
+    mfma_row_word_sums(R, corr, wd);
     // ten 29-bit limbs out of the nine words: one funnel shift and one mask each
     uint32_t L[10];
 #pragma unroll
@@ -170,11 +178,43 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
     return row;
 }
 
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y);
+#endif
+// A row in OPERAND form (mfma_fe_rows): the table carries 2^32, the Montgomery step runs in the word domain - m = V (-p^-1) mod 2^32,
+// (V + m p) / 2^32 < 2^240 + p < 2^256 - and the eight result words, u - 128 per byte (and on the device the second half handed to the
+// partner lane), ARE the operand words of a layer input.  They travel in the first eight words of an Fe-sized container (the scratch
+// slots hold nine words either way).  95 VALU instructions instead of 125 for the element form and 27 for cutting it again.
+PMX_FN Fe mfma_row_finish_operand(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
+    uint32_t wd[9];
+    mfma_row_word_sums(R, corr, wd);
+    const uint32_t m = wd[0] * f.io[kIoPinv32];
+    uint64_t acc = 0;
+    Fe row;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        acc = (uint64_t)m * f.io[kIoP32 + k] + wd[k] + (acc >> 32);   // (2^32 - 1)^2 + 2 (2^32 - 1) = 2^64 - 1: no overflow
+        if (k >= 1) row.l[k - 1] = (uint32_t)acc ^ 0x80808080u;
+    }
+    row.l[7] = (wd[8] + (uint32_t)(acc >> 32)) ^ 0x80808080u;
+    row.l[8] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lane32_swap(row.l[u], row.l[4 + u]);
+#endif
+    return row;
+}
+// the operand words of an input that arrives in operand form already
+PMX_FN void mfma_copy_operand(const Fe &x, uint32_t *w8) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) w8[w] = x.l[w];
+}
+
 #if !defined(__HIPCC__)
 // Host form for tests/hostcheck (g++, no matrix cores): the same tables, bytes and finish, the GEMM as plain integer sums.
 // the 32 sums of row i of a layer with NQ k-steps over the operand words W, finished
 template <int NQ>
-inline Fe mfma_row_host(const uint32_t *W, const uint32_t *layer, size_t n_rows, uint32_t i, const FieldRt &f) {
+inline Fe mfma_row_host(const uint32_t *W, const uint32_t *layer, size_t n_rows, uint32_t i, const FieldRt &f, bool as_element = true) {
     const int8_t *bytes = reinterpret_cast<const int8_t *>(layer);
     const long long *corr = reinterpret_cast<const long long *>(layer + n_rows * (size_t)(NQ * 64 * 4));
     int32_t R[8][4];
@@ -187,16 +227,17 @@ inline Fe mfma_row_host(const uint32_t *W, const uint32_t *layer, size_t n_rows,
         }
         R[e / 4][e % 4] = (int32_t)sum;
     }
-    return mfma_row_finish(R, corr + (size_t)i * 8, f);
+    return as_element ? mfma_row_finish(R, corr + (size_t)i * 8, f) : mfma_row_finish_operand(R, corr + (size_t)i * 8, f);
 }
 // the operand form of an element (device: the second half of the words goes to the partner lane)
 inline void mfma_cut_operand(const Fe &x, uint32_t *w8) { mfma_cut_element(x, w8); }
 // rows [lo, hi) of NOUT over the operand words of NIN inputs (NOUT - 1 <= the scratch's slots)
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
-inline void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, void * /*tile*/, const FieldRt &f, uint32_t lo, uint32_t hi) {
+inline void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, void * /*tile*/, const FieldRt &f, uint32_t lo, uint32_t hi,
+                               uint32_t fe_rows = NOUT) {
     Fe last = out[NOUT - 1];
     for (uint32_t i = lo; i < hi; ++i) {
-        const Fe row = mfma_row_host<NIN>(W, layer, NOUT, i, f);
+        const Fe row = mfma_row_host<NIN>(W, layer, NOUT, i, f, i < fe_rows);
         if (i + 1 < (uint32_t)NOUT) sc.set(i, row);
         else last = row;
     }
@@ -204,14 +245,15 @@ inline void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &s
     out[NOUT - 1] = last;
 }
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
-inline void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi) {
+inline void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi,
+                                uint32_t fe_rows = NOUT) {
     uint32_t W[8 * NIN];
     mfma_state_words<NIN>(in, W);
-    matrix_rows_mfma_w<NIN, NOUT, THREADS, TILE_STEPS>(W, out, sc, layer, tile, f, lo, hi);
+    matrix_rows_mfma_w<NIN, NOUT, THREADS, TILE_STEPS>(W, out, sc, layer, tile, f, lo, hi, fe_rows);
 }
 template <int T, int THREADS, int TILE_STEPS, class Scratch>
-inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi) {
-    matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi);
+inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi, uint32_t fe_rows = T) {
+    matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi, fe_rows);
 }
 // one history row of a window (mfma_hist_rows): load / products / finish, as the device issues them around an S-box
 template <int T>
@@ -262,7 +304,7 @@ __device__ __forceinline__ void mfma_cut_operand(const Fe &x, uint32_t *w8) {
 // the rows over the operand words W of the NIN inputs (mfma_cut_operand each)
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
-                                                   uint32_t lo, uint32_t hi) {
+                                                   uint32_t lo, uint32_t hi, uint32_t fe_rows = NOUT) {
     constexpr int T = NOUT;
     constexpr int NQ = mfma_k_steps(NIN);
     constexpr int NS = (NQ + TILE_STEPS - 1) / TILE_STEPS;   // the tile holds TILE_STEPS k-steps: a row passes through it in NS stages
@@ -334,7 +376,10 @@ __device__ __forceinline__ void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN],
             R[2 * (v / 4)][v % 4] = (int32_t)x;
             R[2 * (v / 4) + 1][v % 4] = (int32_t)y;
         }
-        const Fe row = mfma_row_finish(R, corr + (size_t)i * 8, f);
+        // (rows from fe_rows on - wave-uniform - stay in operand form: they only ever enter matrix-core rows again, mfma_fe_rows)
+        Fe row;
+        if (i < fe_rows) row = mfma_row_finish(R, corr + (size_t)i * 8, f);
+        else row = mfma_row_finish_operand(R, corr + (size_t)i * 8, f);
         if (i + 1 < (uint32_t)T) sc.set(i, row);
         else last = row;
     }
@@ -343,15 +388,15 @@ __device__ __forceinline__ void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN],
 }
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
-                                                    uint32_t lo, uint32_t hi) {
+                                                    uint32_t lo, uint32_t hi, uint32_t fe_rows = NOUT) {
     uint32_t W[8 * NIN];
     static_for<0, NIN>([&](auto j) { mfma_cut_operand(in[decltype(j)::value], &W[8 * decltype(j)::value]); });
-    matrix_rows_mfma_w<NIN, NOUT, THREADS, TILE_STEPS>(W, out, sc, layer, tile, f, lo, hi);
+    matrix_rows_mfma_w<NIN, NOUT, THREADS, TILE_STEPS>(W, out, sc, layer, tile, f, lo, hi, fe_rows);
 }
 template <int T, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f, uint32_t lo,
-                                                 uint32_t hi) {
-    matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi);
+                                                 uint32_t hi, uint32_t fe_rows = T) {
+    matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi, fe_rows);
 }
 
 // One history row of a window (mfma_hist_rows): load<KK> fetches the row's A operand (KK k-steps, 16 bytes per lane each) straight from

@@ -321,8 +321,12 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                         // History terms as rows on the matrix cores (pmx_mfma.hpp: mfma_hist_rows).  The inputs of the window's layer are cut into
                         // operand words as they appear - the carried lanes now, every S-box output when it exists - and the row of x_{k+1}
                         // (inputs z_1 .. z_{k-1}, u_k) is formed right behind S-box k from a table fetched in front of it.
+                        // (the carried lanes behind the first arrive in operand form from the layer before - pmx_mfma.hpp: mfma_fe_rows)
                         uint32_t W[8 * NIN];
-                        static_for<1, T>([&](auto i) { mfma_cut_operand(s[i], &W[8 * (i - 1)]); });
+                        static_for<1, T>([&](auto i) {
+                            if constexpr ((int)i < mfma_fe_rows(T)) mfma_cut_operand(s[i], &W[8 * (i - 1)]);
+                            else mfma_copy_operand(s[i], &W[8 * (i - 1)]);
+                        });
                         MfmaHistRow<T> hr;
                         if constexpr (K > 2) hr.template load<2>(hist);
                         Fe z = fe_sbox<ALPHA>(s[0], c.alpha, one, f);                 // z_1 = x_1^alpha: x_1 came whole out of the layer before
@@ -348,10 +352,11 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                                 mfma_cut_operand(fe_zero(), &W[8 * (T - 2 + k)]);     // a short first window: no such round (its table columns are zero)
                             }
                         });
+                        const uint32_t fe_rows = w + 1 < n_win ? (uint32_t)mfma_fe_rows(T) : (uint32_t)T;   // (the last layer feeds S-boxes on every lane)
 #if defined(__HIPCC__)
-                        matrix_rows_mfma_w<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(W, s, sc, wt, static_cast<mfma_v4i *>(tile), f, 0u, (uint32_t)T);
+                        matrix_rows_mfma_w<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(W, s, sc, wt, static_cast<mfma_v4i *>(tile), f, 0u, (uint32_t)T, fe_rows);
 #else
-                        matrix_rows_mfma_w<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(W, s, sc, wt, tile, f, 0u, (uint32_t)T);
+                        matrix_rows_mfma_w<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(W, s, sc, wt, tile, f, 0u, (uint32_t)T, fe_rows);
 #endif
                     } else {
                     Fe in[NIN];
@@ -433,11 +438,15 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             if constexpr (MFMA_THREADS > 0) {
                 const uint32_t n_full = c.total_rounds - c.partial_rounds - 1;   // the layer after the last partial round follows the full rounds' own
                 const uint32_t *lay = tb.mfma + (size_t)(full ? o : n_full) * mfma_layer_words(T);
-                if (kWindows && sparse_layer) lay = tb.win;   // the entrance round's layer leads into the first window (same code, other table)
+                uint32_t fe_rows = (uint32_t)T;
+                if (kWindows && sparse_layer) {   // the entrance round's layer leads into the first window (same code, other table)
+                    lay = tb.win;
+                    fe_rows = (uint32_t)mfma_fe_rows(T);
+                }
 #if defined(__HIPCC__)
-                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, static_cast<mfma_v4i *>(tile), f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
+                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, static_cast<mfma_v4i *>(tile), f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T, fe_rows);
 #else
-                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, tile, f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T);
+                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, tile, f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T, fe_rows);
 #endif
             } else if constexpr (T <= kHybridTabMaxT) {
                 const uint32_t *mat = full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense;

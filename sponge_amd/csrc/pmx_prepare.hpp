@@ -70,14 +70,17 @@ struct Prepared {
 // k = 32 q + 16 (l >> 5) + 0..15 of the state's byte string (k = 36 j + b), as balanced signed bytes; then per row the eight
 // word sums of 128 * sum_k Y_k (the state's bytes enter as u - 128).
 // General form: n_out rows of n_in constants; aff (may be null): one constant per row added to the row's value.
-inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in, size_t n_out, const U256 *aff, uint32_t *dst) {
+// fe_rows: rows [0, fe_rows) are finished as field elements (one Montgomery step of 29 bits), the rest in OPERAND form (one of 32 bits:
+// pmx_mfma.hpp, mfma_row_finish_operand) - the table carries the power of two its row's finish divides by
+inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in, size_t n_out, const U256 *aff, uint32_t *dst, size_t fe_rows = (size_t)-1) {
     const size_t nq = (size_t)mfma_k_steps((int)n_in), row_words = (size_t)mfma_row_words((int)n_in);
     int8_t *bytes = reinterpret_cast<int8_t *>(dst);
     long long *corr = reinterpret_cast<long long *>(dst + n_out * row_words);
     for (size_t i = 0; i < n_out; ++i) {
         long long colsum[32] = {0};
+        const int shift = i < fe_rows ? kMfmaShift : 32;
         for (size_t j = 0; j < n_in; ++j) {
-            U256 y = times_pow2(hf, hf.from_mont(rows[i * n_in + j]), kMfmaShift);
+            U256 y = times_pow2(hf, hf.from_mont(rows[i * n_in + j]), shift);
             for (size_t b = 0; b < (size_t)kMfmaElemBytes; ++b) {   // (the inputs of a layer are below 2^256: pmx_mfma.hpp)
                 // balanced bytes of y: digit e in [-128, 127], carry into the next
                 unsigned carry = 0;
@@ -98,7 +101,7 @@ inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in
         }
         // the row's constant in the units of V: its internal form (x 2^261) times the 2^kMfmaShift the finish divides by
         U256 add = {{0, 0, 0, 0}};
-        if (aff) add = times_pow2(hf, hf.from_mont(aff[i]), 261 + kMfmaShift);
+        if (aff) add = times_pow2(hf, hf.from_mont(aff[i]), 261 + shift);
         for (size_t w = 0; w < 8; ++w) {
             long long v = 0;
             for (size_t tt = 0; tt < 4; ++tt) v += (128 * colsum[4 * w + tt]) * (1ll << (8 * tt));
@@ -649,10 +652,12 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
             const size_t lw_in = (size_t)mfma_layer_words_io((int)(t - 1 + K), (int)t), nh = (size_t)mfma_window_hist((int)K);
             out.consts.resize(out.win_offset + mfma_window_words((int)t, (int)K, plan.n_win), 0u);
             uint32_t *dst = &out.consts[out.win_offset];
-            put_mfma_layer_io(hf, plan.entry_rows.data(), t, t, plan.entry_aff.data(), dst);
+            // (rows that only feed matrix-core inputs - every carried lane but the first, where the history terms are rows too - stay in
+            // operand form between the layers: pmx_mfma.hpp, mfma_fe_rows; the last window's layer feeds S-boxes on every lane)
+            put_mfma_layer_io(hf, plan.entry_rows.data(), t, t, plan.entry_aff.data(), dst, (size_t)mfma_fe_rows((int)t));
             dst += mfma_layer_words((int)t);
             for (size_t w = 0; w < plan.n_win; ++w) {
-                put_mfma_layer_io(hf, plan.rows[w].data(), t - 1 + K, t, plan.aff[w].data(), dst);
+                put_mfma_layer_io(hf, plan.rows[w].data(), t - 1 + K, t, plan.aff[w].data(), dst, w + 1 < plan.n_win ? (size_t)mfma_fe_rows((int)t) : (size_t)t);
                 dst += lw_in;
                 if (mfma_hist_tab((int)t)) {
                     for (uint32_t k = 2; k < K; ++k)
@@ -683,6 +688,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     std::memcpy(&out.consts[out.io_offset + kIoP32], hf.p.l, 32);
     to_limbs29(times_pow2(hf, hf.r, 10), &out.consts[out.io_offset + kIoToInt]);   // 2^266 mod p
     to_limbs29(hf.r, &out.consts[out.io_offset + kIoToAbi]);                       // 2^256 mod p
+    out.consts[out.io_offset + kIoPinv32] = (uint32_t)hf.inv;                      // -p^-1 mod 2^32
     f.io = out.consts.data() + out.io_offset;   // host view; valid while `out` is neither copied nor resized
     to_limbs29(times_pow2(hf, hf.r, 5), out.one.l);     // 2^261 mod p
     out.c.rate = cfg->rate;
