@@ -302,9 +302,12 @@ __device__ __forceinline__ void mfma_cut_operand(const Fe &x, uint32_t *w8) {
     for (int u = 0; u < 4; ++u) lane32_swap(w8[u], w8[4 + u]);
 }
 // the rows over the operand words W of the NIN inputs (mfma_cut_operand each)
+// (fe_rows < NOUT only where the width has operand-form rows at all - mfma_fe_rows: elsewhere the operand finish is not even compiled in,
+// or the t = 3 kernel, which has none, pays its registers: 32 bytes of scratch per lane at four waves per SIMD, HBM writes 1.34 x)
 template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
 __device__ __forceinline__ void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
                                                    uint32_t lo, uint32_t hi, uint32_t fe_rows = NOUT) {
+    constexpr bool kOperandRows = mfma_fe_rows(NOUT) < NOUT;
     constexpr int T = NOUT;
     constexpr int NQ = mfma_k_steps(NIN);
     constexpr int NS = (NQ + TILE_STEPS - 1) / TILE_STEPS;   // the tile holds TILE_STEPS k-steps: a row passes through it in NS stages
@@ -378,7 +381,7 @@ __device__ __forceinline__ void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN],
         }
         // (rows from fe_rows on - wave-uniform - stay in operand form: they only ever enter matrix-core rows again, mfma_fe_rows)
         Fe row;
-        if (i < fe_rows) row = mfma_row_finish(R, corr + (size_t)i * 8, f);
+        if (!kOperandRows || i < fe_rows) row = mfma_row_finish(R, corr + (size_t)i * 8, f);
         else row = mfma_row_finish_operand(R, corr + (size_t)i * 8, f);
         if (i + 1 < (uint32_t)T) sc.set(i, row);
         else last = row;
