@@ -965,7 +965,8 @@ def load_valu_issue(workload, per_gpu_units, kernel_s, compute_units, mads, info
         out["floor_source"] = "pmx_diag_issue_slot on this device before the warm-up, %d launches, exactly %d waves resident per SIMD; floor = the fastest stream" % (r.launches, waves)
     try:
         w = json.load(open(os.path.join(ROOT, "profiles", "valu_instructions.json")))[workload]
-        if abs(w["units_per_launch"] - per_gpu_units) > 1 or not compute_units or w.get("engine", info.engine.decode()) != info.engine.decode():
+        # (the count per permutation is a property of the kernel, not of the batch size: quoted whenever the engine is the one the pass was taken on)
+        if not compute_units or w.get("engine", info.engine.decode()) != info.engine.decode():
             raise KeyError(workload)
         per_unit = w.get("valu_instructions_per_permutation", w["valu_instructions_per_wave"])   # what a lane executes per permutation
         ns = kernel_s * 1e9 * compute_units * 4 / (per_unit * per_gpu_units / 64.0)
@@ -977,7 +978,11 @@ def load_valu_issue(workload, per_gpu_units, kernel_s, compute_units, mads, info
     except Exception:
         out["valu_instructions_per_permutation"] = None
         out["frac"] = None
-        out["count_source"] = "no SQ_INSTS_VALU pass committed for this workload / engine"
+        if workload in ("c5", "d3", "d9"):
+            out["count_source"] = ("not quoted: a step of this workload is several kernels (one per tree level / pass 0 and the listed passes of an absorb and of a "
+                                   "squeeze), so there is no single per-permutation count; their SQ counters per kernel: profiles/r05/z_valu_driver_and_tree_kernels.txt")
+        else:
+            out["count_source"] = "no SQ_INSTS_VALU pass committed for this workload / engine"
     return out
 
 

@@ -328,7 +328,8 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                             else mfma_copy_operand(s[i], &W[8 * (i - 1)]);
                         });
                         MfmaHistRow<T> hr;
-                        if constexpr (K > 2) hr.template load<2>(hist);
+                        constexpr bool kFetchAhead = T != 5;   // (t = 5 sits on the 168 registers of three waves per SIMD: the 16 of a fetched-ahead table spill)
+                        if constexpr (K > 2 && kFetchAhead) hr.template load<2>(hist);
                         Fe z = fe_sbox<ALPHA>(s[0], c.alpha, one, f);                 // z_1 = x_1^alpha: x_1 came whole out of the layer before
                         mfma_cut_operand(z, &W[8 * (T - 1)]);
                         Fe x = fe_add_lazy(s[1], z);                                  // x_2 = z_1 + u_1
@@ -343,8 +344,9 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                                     // front as well (they need none of z_k) the 32 sums stay live across the S-box and the kernels of t = 8, 9
                                     // spill (C3 -3.3 %, t = 8 -1.9 %, t = 6, 7 the same: profiles/r05/k_ab_history_rows_in_front_of_or_behind_their_sbox.txt)
                                     if (row) {
+                                        if constexpr (!kFetchAhead) hr.template load<k>(hist + mfma_hist_rows_offset(k));
                                         hr.template products<k>(W);
-                                        if constexpr (k + 1 < K) hr.template load<k + 1>(hist + mfma_hist_rows_offset(k + 1));
+                                        if constexpr (k + 1 < K && kFetchAhead) hr.template load<k + 1>(hist + mfma_hist_rows_offset(k + 1));
                                         x = fe_add_lazy(hr.template finish<k>(f), z);   // x_{k+1} = z_k + (u_k + sum_{i<k} h_{k,i} z_i)
                                     }
                                 }
