@@ -191,7 +191,7 @@ struct RegEngine {
     }
 
     // lanes [want_lo, want_hi) of the result are all the caller will read (see permute_opt); default: the whole state
-    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T) {
+    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T, bool /*lane0_zero*/ = false) {
         if constexpr (TAB) permute_opt_tab<T, ALPHA>(s, tb, c, one, f, want_lo, want_hi);
         else if constexpr (OPT) permute_opt<T, ALPHA>(s, tb, c, one, f, want_lo, want_hi);
         else permute_dense<T, ALPHA>(s, tb.ark, tb.mds, c, one, f);
@@ -467,9 +467,10 @@ struct HybridEngine {
         });
     }
 
-    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T) {
+    // lane0_zero: the caller knows lane 0 of the state is zero (pmx_permute.hpp: the window engines skip its round-0 S-box)
+    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T, bool lane0_zero = false) {
         permute_hybrid<T, ALPHA, Scratch, MFMA ? kThreads : 0, kTileSteps, MFMA ? mfma_window_for(T) : 0>(s, sc, tb, c, one, f, want_lo, want_hi,
-                                                                                                          pmx_lds + kWaves * (kWaveBytes / 16));
+                                                                                                          pmx_lds + kWaves * (kWaveBytes / 16), lane0_zero);
     }
 };
 
@@ -582,7 +583,7 @@ struct LdsEngine {
         o.optimised = o.row_tables = o.lane_tables = o.mfma_dense = 0;
     }
 
-    __device__ __forceinline__ void permute(uint32_t /*want_lo*/ = 0, uint32_t /*want_hi*/ = PMX_MAX_WIDTH) {
+    __device__ __forceinline__ void permute(uint32_t /*want_lo*/ = 0, uint32_t /*want_hi*/ = PMX_MAX_WIDTH, bool /*lane0_zero*/ = false) {
         uint32_t *const home = cur;
         permute_dense_rt<ALPHA>(*this, t, ark, mds, c, one, f);
         // Lanes may permute a different number of times (per-sponge modes) while load/store_states use the
@@ -695,14 +696,16 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     size_t k_in = 0, rem = out_len, pos = 0;
     uint32_t idx = 0;
     bool squeezing = false, need = false;
+    bool fresh = c.capacity >= 1;   // until the first permutation the capacity lanes of the new sponge - lane 0 among them - are zero
     // The sponge is dropped when the row is done, so the LAST permutation only has to produce the lanes the last squeeze
     // copies out: [capacity, capacity + rem) once rem <= rate elements are left (want_hi; otherwise the whole state).
     const uint32_t t_all = c.rate + c.capacity;
     uint32_t want_hi = t_all;
     for (;;) {
         if (need) {
-            e.permute(want_hi < t_all ? c.capacity : 0, want_hi);
+            e.permute(want_hi < t_all ? c.capacity : 0, want_hi, fresh);
             need = false;
+            fresh = false;
         }
         if (k_in < in_len) {                                   // absorb_internal, mod.rs:121-150
             if (idx == c.rate) {                               // rate full and more input remains
@@ -755,7 +758,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     e.zero();
     e.set(e.c.capacity, e.from_abi(abi_load(pair)));
     e.set(e.c.capacity + 1, e.from_abi(abi_load(pair + 8)));
-    e.permute(e.c.capacity, e.c.capacity + 1);   // only the digest lane of the result is read
+    e.permute(e.c.capacity, e.c.capacity + 1, e.c.capacity >= 1);   // only the digest lane of the result is read; lane 0 (capacity) went in as zero
     const Abi digest = e.to_abi(e.get(e.c.capacity));
     if (active) abi_store(reinterpret_cast<uint32_t *>(out + gid * 4), digest);
 }

@@ -575,7 +575,9 @@ PMX_FN Fe fe_sbox(const Fe &x, uint64_t alpha, const Fe &one, const FieldRt &f) 
         return mont_mul(y, x, f);
     } else {
         if (alpha == 0) return one;
-        if (alpha == 1) return fe_normalize(x);
+        // alpha = 1: x itself, but as a Montgomery PRODUCT (x * 2^261 * 2^-261): the optimised schedules add an S-box output into rows
+        // unreduced and cut it into 32 bytes for the matrix cores, both on the bound of a product (B < 1.3, below 2^256), not of a lazy sum
+        if (alpha == 1) return mont_mul(x, one, f);
         const int top = 63 - __builtin_clzll(alpha);
         Fe acc = mont_sqr(x, f);
         if ((alpha >> (top - 1)) & 1) acc = mont_mul(acc, x, f);

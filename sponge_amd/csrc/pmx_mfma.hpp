@@ -8,7 +8,7 @@
 //   * every element z_j a layer takes in is an S-box output (a Montgomery product: below 1.3 p) or a row of the layer before
 //     (below 2^243 + p), so with p < 2^255 it is below 2^256: it is re-cut into 32 bytes u_{j,b} - eight words, exactly ONE k-step of
 //     the matrix-core instruction per element (round 5; rounds 3-4 carried 36 bytes per element, 33 used, for values up to 2^261:
-//     -12 ... -25 % products per row, 16 registers fewer at t = 9).  prepare() grants the tables only where the bound holds (alpha >= 2);
+//     -12 ... -25 % products per row, 16 registers fewer at t = 9).  the bound holds for every exponent: alpha = 1 is formed as the product x * 1 and alpha = 0 is the constant 1 (pmx_field.hpp: fe_sbox));
 //   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 29) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
 //     (pmx_prepare.hpp: put_mfma_layer; the modulus' top byte must be <= 126 for 32 of them to do), laid out as the A
 //     operand: 16 bytes per lane and k-step, lane l = row e (l & 31) and half (l >> 5) of the k-step;

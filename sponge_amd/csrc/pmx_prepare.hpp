@@ -187,13 +187,13 @@ inline bool mat_inverse(const HostField &f, HostMat a, HostMat &inv) {
 // (t-1) + B_z + 1 <= 10.3 p for t <= 9, so the S-box input x = row0 + constant is below 11.3 p and the S-box output z_0
 // below B_z p with
 //     alpha >= 4: the chain ends in a product with x of a value < 1.05 p  ->  B_z < 1.05 * 11.3 / 64 + 1 < 1.2
-//     alpha = 3: x^2 * x, x^2 < 3 p -> B_z < 1.6;   alpha = 2: B_z < 3;   alpha = 1: z_0 = x, B_z < 11.3;
+//     alpha = 3: x^2 * x, x^2 < 3 p -> B_z < 1.6;   alpha = 2: B_z < 3;   alpha = 1: z_0 = x as the product x * 1 (fe_sbox), B_z < 1.2;
 //     alpha = 0: z_0 = 1.
 // A lane starts as an S-box output of the entrance round (< 1.3 p), takes its first update there and one more per sparse
 // partial round, growing by at most (B_z / Q + 1) p each time; the dense layer after the last partial round adds its own
 // + p.  The schedule is used when all of that stays below Q.
 inline bool opt_schedule_lane_headroom(long double two_261_over_p, uint32_t partial_rounds, uint64_t alpha) {
-    const long double bz = alpha == 0 ? 1.0L : alpha == 1 ? 11.3L : alpha == 2 ? 3.0L : alpha == 3 ? 1.6L : 1.3L;
+    const long double bz = alpha == 0 ? 1.0L : alpha == 2 ? 3.0L : alpha == 3 ? 1.6L : 1.3L;
     const long double growth = 1.0L + bz / two_261_over_p;
     const long double worst = 1.4L + growth * (long double)partial_rounds + 1.5L;
     return worst < two_261_over_p;
@@ -532,6 +532,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     }
     // optimised schedule
     std::vector<U256> src_full, src_sparse, src_bdense, entrance_scale, exit_scale, arkopt_exit, ark_true;
+    U256 arkopt_first = {{0, 0, 0, 0}};   // ark'[0][0]
     HostMat M_true;
     const uint32_t half = cfg->full_rounds / 2, rp = cfg->partial_rounds;
     const size_t n_full = cfg->full_rounds ? (size_t)cfg->full_rounds - 1 : 0;   // matrices in `full`
@@ -550,6 +551,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
                                         &entrance_scale, &exit_scale);
         if (out.has_opt) {
             arkopt_exit.assign(ark_opt.begin() + (long)((size_t)(half + rp) * t), ark_opt.begin() + (long)((size_t)(half + rp) * t + t));
+            arkopt_first = ark_opt[0];
             ark_true = ark;
             M_true = M;
         }
@@ -633,8 +635,8 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     // dense layers of the widest states as int8 GEMM operands
     while (out.consts.size() % 4) out.consts.push_back(0u);   // 16-byte operands
     out.mfma_offset = out.consts.size();
-    // (alpha >= 2: a layer's inputs must be below 2^256 - S-box outputs that ARE products, pmx_mfma.hpp; p < 2^255 is a limit of the build)
-    out.mfma_dense = out.has_opt && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T && n_full >= 1 && (hf.p.l[3] >> 56) <= 126 && cfg->alpha >= 2;
+    // (a layer's inputs must be below 2^256: S-box outputs ARE products for every alpha - pmx_field.hpp: fe_sbox; p < 2^255 is a limit of the build)
+    out.mfma_dense = out.has_opt && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T && n_full >= 1 && (hf.p.l[3] >> 56) <= 126;
     if (out.mfma_dense) {
         const size_t lw = (size_t)mfma_layer_words((int)t);
         out.consts.resize(out.mfma_offset + (n_full + 1) * lw, 0u);
@@ -650,7 +652,7 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         WindowPlan plan;
         if (K <= t && derive_window_layers(hf, t, half, rp, cfg->alpha, K, ark_true, M_true, entrance_scale, exit_scale, arkopt_exit.data(), plan)) {
             const size_t lw_in = (size_t)mfma_layer_words_io((int)(t - 1 + K), (int)t), nh = (size_t)mfma_window_hist((int)K);
-            out.consts.resize(out.win_offset + mfma_window_words((int)t, (int)K, plan.n_win), 0u);
+            out.consts.resize(out.win_offset + mfma_window_words((int)t, (int)K, plan.n_win) + kFeStride, 0u);
             uint32_t *dst = &out.consts[out.win_offset];
             // (rows that only feed matrix-core inputs - every carried lane but the first, where the history terms are rows too - stay in
             // operand form between the layers: pmx_mfma.hpp, mfma_fe_rows; the last window's layer feeds S-boxes on every lane)
@@ -671,6 +673,9 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
                 }
                 dst += (size_t)mfma_window_hist_words((int)t, (int)K);
             }
+            // behind the windows: S-box(ark'[0][0]) - what lane 0 of round 0 is when that lane comes in as zero (the capacity lane of a fresh
+            // sponge: every 2-to-1 compression, the first permutation of every hash row), so those kernels skip that S-box (pmx_permute.hpp)
+            to_limbs29(times_pow2(hf, host_pow(hf, arkopt_first, cfg->alpha), 5), dst);
             out.mfma_window = K;
         } else {
             out.mfma_dense = false;

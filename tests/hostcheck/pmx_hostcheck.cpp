@@ -178,8 +178,11 @@ static int permute_hybrid_mfma_t(const Prepared &pp, uint64_t *states, size_t n)
         Fe s[T];
         HostScratch<T> sc;
         for (int i = 0; i < T; ++i) s[i] = fe_from_abi_scaled(load_abi(states + (k * T + i) * 4));
-        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, 256, 6, KW>(s, sc, tb, pp.c, pp.one, pp.f);
-        else permute_hybrid<T, 0, HostScratch<T>, 256, 6, KW>(s, sc, tb, pp.c, pp.one, pp.f);
+        // a state whose lane 0 is zero takes the shortcut the compress / hash kernels take for a fresh sponge (lane0_zero)
+        const uint64_t *lane0 = states + (k * T) * 4;
+        const bool z0 = KW > 0 && !(lane0[0] | lane0[1] | lane0[2] | lane0[3]);
+        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, 256, 6, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, nullptr, z0);
+        else permute_hybrid<T, 0, HostScratch<T>, 256, 6, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, nullptr, z0);
         for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
     }
     return PMX_OK;
@@ -215,6 +218,9 @@ extern "C" int hc_permute_hybrid(const pmx_config *cfg, uint64_t *states, size_t
         case 3: permute_hybrid_t<3>(pp, states, n); break;
         case 4: permute_hybrid_t<4>(pp, states, n); break;
         case 5: permute_hybrid_t<5>(pp, states, n); break;
+        case 6: permute_hybrid_t<6>(pp, states, n); break;
+        case 7: permute_hybrid_t<7>(pp, states, n); break;
+        case 8: permute_hybrid_t<8>(pp, states, n); break;
         case 9: permute_hybrid_t<9>(pp, states, n); break;
         default: return PMX_ERR_UNSUPPORTED;
     }

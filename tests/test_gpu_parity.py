@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import sponge_amd as S
-from sponge_amd import synth
+from sponge_amd import _lib, synth
 from oracle import kats as K
 
 from gpu_helpers import c_oracle, ints, product_config
@@ -631,3 +631,31 @@ def test_merkle_forest_bad_arguments():
     assert lib.pmx_merkle_2to1_forest(cfg.context()._h, ctypes.c_void_p(leaves.ctypes.data), 0, 4, None, None) == -2
     assert lib.pmx_merkle_2to1_forest(cfg.context()._h, None, 1, 4, None, None) == -2
     assert lib.pmx_merkle_2to1_forest_dev(cfg.context()._h, None, 1, 4, None) == -2
+
+
+@pytest.mark.parametrize("rate", [2, 3, 5, 8, 9])
+@pytest.mark.parametrize("alpha", [0, 1, 2])
+def test_small_exponents_on_every_engine(rate, alpha):
+    """The optimised schedules add an S-box output into rows unreduced, and pmx_mfma.hpp cuts it into 32 bytes - one k-step of the
+    matrix-core instruction per element: both stand on the bound of a Montgomery PRODUCT.  alpha = 1 used to hand its lazy input
+    through (wrong results at t = 6 ... 9) and is formed as the product x * 1 since (pmx_field.hpp: fe_sbox), so it runs the same
+    engines as every other exponent.  Whole permutations at both ends of the engine thresholds and a hash, against the C port (the
+    reference accepts any alpha: src/poseidon/mod.rs:63-74)."""
+    import ctypes
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    f, t = S.BLS12_381_FR, rate + 1
+    cfg = S.poseidon_config_from_lfsr(f, rate, alpha, 8, 57)
+    cr = cref.CRef(O.make_config(O.BLS12_381_FR, 255, rate, alpha, 8, 57))
+    info = _lib.PmxEngineInfo()
+    _lib.check(_lib.lib().pmx_ctx_engine_info(cfg.context()._h, _lib.OP_PERMUTE, 1 << 18, 0, ctypes.byref(info)))
+    assert info.mfma_dense == (1 if t <= 9 else 0), info.engine
+    assert (b"mfma" in info.engine) == (t <= 9), info.engine
+    pm = f.modulus
+    for n in (333, (1 << 17) + 5) if t == 3 else (333,):
+        states = synth.random_elements(f, n * t, seed=900 + 10 * rate + alpha).reshape(n, t, 4)
+        states[0] = f.from_ints([pm - 1] * t).reshape(t, 4)
+        states[1] = f.from_ints([0] * t).reshape(t, 4)
+        assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0)), n
+    msgs = synth.random_elements(f, 70 * (rate + 2), seed=alpha).reshape(70, rate + 2, 4)
+    assert np.array_equal(cfg.context().hash_batch(msgs, rate + 2, 2), cr.hash_batch(msgs, rate + 2, 2, threads=0))

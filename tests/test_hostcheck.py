@@ -265,11 +265,12 @@ def test_long_partial_sections_leave_the_optimised_schedule(hc):
     rng = random.Random(3)
     hc.hc_track_reset.argtypes = []
     hc.hc_track_get.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    # alpha = 1 and 2 are the S-boxes whose output is NOT small (z_0 up to ~10 p resp. 2.7 p): the lanes grow faster
-    # and prepare() allows fewer rounds
+    # alpha = 2 is the S-box whose output is NOT small (z_0 up to 2.7 p): the lanes grow faster and prepare() allows fewer rounds
+    # (alpha = 1 is formed as the product x * 1 - pmx_field.hpp: fe_sbox - and is as small as any other)
     for p, bits, rp, alpha, expect_opt in [(O.BLS12_381_FR, 255, 66, 5, True), (O.BLS12_381_FR, 255, 67, 5, False),
-                                           (O.BN254_FR, 254, 120, 5, True), (O.BLS12_381_FR, 255, 58, 1, True),
-                                           (O.BLS12_381_FR, 255, 60, 1, False), (O.BLS12_381_FR, 255, 64, 2, True)]:
+                                           (O.BN254_FR, 254, 120, 5, True), (O.BLS12_381_FR, 255, 66, 1, True),
+                                           (O.BLS12_381_FR, 255, 67, 1, False), (O.BLS12_381_FR, 255, 64, 2, True),
+                                           (O.BLS12_381_FR, 255, 66, 2, False)]:
         cfg = O.make_config(p, bits, 2, alpha, 8, rp)
         states = [[rng.randrange(p) for _ in range(3)] for _ in range(4)] + [[p - 1] * 3]
         want = [x for st in states for x in O.permute(cfg, st)]
@@ -356,6 +357,59 @@ def test_matrix_core_tables_only_for_moduli_whose_residues_fit_32_balanced_bytes
         assert rc == (0 if ok else -4), (hex(p >> 248), rc)
         if ok:
             assert cref.limbs_to_elems(out, p) == want
+
+
+@pytest.mark.parametrize("t", [3, 4, 6, 9])
+@pytest.mark.parametrize("alpha", [0, 1, 2, 3])
+def test_small_exponents_on_every_schedule(hc, t, alpha):
+    """The optimised schedules add an S-box output into rows unreduced and the matrix-core form cuts it into 32 bytes: both stand on the
+    bound of a Montgomery PRODUCT (below 1.3 p).  alpha = 1 used to hand its lazy input through - wrong results on the hybrid engines of
+    t >= 6 - and is formed as the product x * 1 since (pmx_field.hpp: fe_sbox); alpha = 0 is the constant 1.  Every schedule of the host
+    build against the oracle (the reference accepts any alpha: src/poseidon/mod.rs:63-74)."""
+    for name in ("hc_permute_hybrid_mfma", "hc_permute_hybrid", "hc_permute_rt"):
+        getattr(hc, name).argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    p, rate = O.BLS12_381_FR, t - 1
+    cfg = O.make_config(p, 255, rate, alpha, 8, 57)
+    rng = random.Random(10 * t + alpha)
+    states = [[rng.randrange(p) for _ in range(t)] for _ in range(3)] + [[p - 1] * t, [0] * t]
+    want = [x for st in states for x in O.permute(cfg, st)]
+    limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), t, 4)
+    ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+    mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+    c = PmxConfig()
+    c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = 8, 57, alpha, rate, 1
+    for i, l in enumerate(O.to_limbs(p)):
+        c.modulus[i] = l
+    c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+    for name in ("hc_permute_hybrid_mfma", "hc_permute_hybrid", "hc_permute_rt") + (("hc_permute",) if t in (3, 4, 9) else ()):
+        out = limbs.copy()
+        assert getattr(hc, name)(ctypes.byref(c), out.ctypes.data, len(states)) == 0, (name, t, alpha)
+        assert cref.limbs_to_elems(out, p) == want, (name, t, alpha)
+
+
+@pytest.mark.parametrize("t,alpha", [(3, 5), (3, 17), (4, 5), (9, 5)])
+def test_a_zero_capacity_lane_skips_its_first_sbox(hc, t, alpha):
+    """pmx_permute.hpp (lane0_zero): compress and the first permutation of a hash row know lane 0 is zero, so round 0 puts the config's
+    constant S-box(ark'[0][0]) (pmx_prepare.hpp, behind the window tables) there instead of computing it.  The host build takes that
+    shortcut whenever lane 0 of a state is zero: such states must still match the oracle."""
+    hc.hc_permute_hybrid_mfma.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    p = O.BLS12_381_FR
+    rf, rp = 8, {3: 57, 4: 56, 9: 57}[t]
+    cfg = O.make_config(p, 255, t - 1, alpha, rf, rp)
+    rng = random.Random(100 * t + alpha)
+    states = [[0] + [rng.randrange(p) for _ in range(t - 1)] for _ in range(3)] + [[0] * t, [0] + [p - 1] * (t - 1)]
+    want = [x for st in states for x in O.permute(cfg, st)]
+    limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), t, 4)
+    ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+    mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+    c = PmxConfig()
+    c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = rf, rp, alpha, t - 1, 1
+    for i, l in enumerate(O.to_limbs(p)):
+        c.modulus[i] = l
+    c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+    out = limbs.copy()
+    assert hc.hc_permute_hybrid_mfma(ctypes.byref(c), out.ctypes.data, len(states)) == 0
+    assert cref.limbs_to_elems(out, p) == want
 
 
 @pytest.mark.parametrize("K", [6, 1, 4, 9])
