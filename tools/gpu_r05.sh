@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_r05.sh <tag> [stages]
-# stages: any of  test testlib smoke bench widths prof slots pmc hostpath rehearsal rates   (default: "test smoke bench")
+# stages: any of  test testlib fuzz smoke bench widths prof slots pmc hostpath rehearsal rates stalls   (default: "test smoke bench")
 TAG=${1:-r05z}
 STAGES=${2:-"test smoke bench"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -18,6 +18,7 @@ if has testlib; then   # the same suite once more with libposeidon_mi355x_test.s
   ( time timeout 3000 python -m pytest tests -x -q -m gpu --pmx-test-library ) > $OUT/pytest_gpu_test_library.log 2>&1
   echo "pytest exit: $?" >> $OUT/pytest_gpu_test_library.log
 fi
+if has fuzz; then ( timeout 1500 python tools/diag/fuzz_configs.py 600 501; timeout 900 python tools/diag/alpha1_widths.py | grep -c "pairs: 0 of" ) > $OUT/fuzz_configs.txt 2>&1; fi
 if has smoke; then timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; fi
 B() { local name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
 if has bench; then
@@ -73,6 +74,7 @@ if has pmc; then
     timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$w -- python3 $R/bench.py $(PMC_ARGS $w) --steps $steps --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_write_$w.log 2>&1
   done
 fi
+if has stalls; then bash $R/tools/pmc_c3_stalls.sh c3 $OUT/stalls_c3 > $OUT/pmc_c3_stalls.txt 2>&1; bash $R/tools/pmc_c3_stalls.sh c2 $OUT/stalls_c2 > $OUT/pmc_c2_stalls.txt 2>&1; fi
 cd $R
 if has slots; then
   J=$OUT/valu_instructions.json; rm -f $J
