@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Seeded random Poseidon configurations on the GPU against the C port (oracle/): every exponent class (0, 1, small, the usual, 64-bit),
 odd and zero round counts, every rate / capacity split of widths 2 ... 12, both fields; per config whole permutations at several batch
-sizes (both sides of the engine thresholds at t = 3), the fixed-shape hash and a small tree.  Prints one line per failing case and a
+sizes (both sides of the engine thresholds at t = 3), the fixed-shape hash, a small tree and (every other config) the duplex driver on sponges in mixed modes.  Prints one line per failing case and a
 summary; exit code 1 if anything differs.      usage: tools/diag/fuzz_configs.py [n_configs] [seed]"""
 import os, sys, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -67,6 +67,34 @@ for k in range(N):
         if not np.array_equal(nodes, cr.merkle(leaves, threads=0)):
             bad += 1
             print("MERKLE differs: %s" % what, flush=True)
+    # the duplex driver: sponges in random modes and positions advance together, checked sponge by sponge
+    if k % 2 == 0 and rate >= 1:
+        n, r = 90, rate
+        nrng = np.random.default_rng(k)
+        batch = S.BatchPoseidonSponge.new(cfg, n)
+        batch.state = synth.random_elements(f, n * t, seed=k + 11).reshape(n, t, 4)
+        batch.mode_tag = nrng.integers(0, 2, n).astype(np.uint32)
+        batch.mode_index = nrng.integers(0, r + 1, n).astype(np.uint32)
+        ref = [(batch.state[i].copy(), int(batch.mode_tag[i]), int(batch.mode_index[i])) for i in range(n)]
+        for (op, length) in [("absorb", rng.randint(1, 2 * r + 1)), ("squeeze", rng.randint(1, 2 * r + 1)), ("squeeze", 1), ("absorb", 1)]:
+            ok = True
+            if op == "absorb":
+                elems = synth.random_elements(f, n * length, seed=length + k).reshape(n, length, 4)
+                batch.absorb(elems)
+                ref = [cr.sponge_absorb(st, m, i, elems[j]) for j, (st, m, i) in enumerate(ref)]
+            else:
+                out = batch.squeeze_native_field_elements(length)
+                nxt = []
+                for j, (st, m, i) in enumerate(ref):
+                    s2, m2, i2, o = cr.sponge_squeeze(st, m, i, length)
+                    ok = ok and np.array_equal(out[j], o)
+                    nxt.append((s2, m2, i2))
+                ref = nxt
+            for j, (st, m, i) in enumerate(ref):
+                ok = ok and np.array_equal(batch.state[j], st) and (batch.mode_tag[j], batch.mode_index[j]) == (m, i)
+            if not ok:
+                bad += 1
+                print("SPONGE %s(%d) differs: %s" % (op, length, what), flush=True)
     ctx.close() if hasattr(ctx, "close") else None
 print("fuzz_configs: %d configurations, %d failing cases, %.0f s" % (N, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
