@@ -6,10 +6,11 @@
 // of the wave (one per lane), whose K dimension is the bytes of the state and whose M dimension is the bytes of the result:
 //
 //   * every element z_j a layer takes in is an S-box output (a Montgomery product: below 1.3 p) or a row of the layer before
-//     (below 2^243 + p), so with p < 2^255 it is below 2^256: it is re-cut into 32 bytes u_{j,b} - eight words, exactly ONE k-step of
+//     (below 2^240 + p), so with p < 2^255 it is below 2^256: it is re-cut into 32 bytes u_{j,b} - eight words, exactly ONE k-step of
 //     the matrix-core instruction per element (round 5; rounds 3-4 carried 36 bytes per element, 33 used, for values up to 2^261:
-//     -12 ... -25 % products per row, 16 registers fewer at t = 9).  the bound holds for every exponent: alpha = 1 is formed as the product x * 1 and alpha = 0 is the constant 1 (pmx_field.hpp: fe_sbox));
-//   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 29) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
+//     -12 ... -25 % products per row, 16 registers fewer at t = 9; the bound holds for every exponent: alpha = 1 is formed as the
+//     product x * 1, alpha = 0 is the constant 1 - pmx_field.hpp: fe_sbox);
+//   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 32) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
 //     (pmx_prepare.hpp: put_mfma_layer; the modulus' top byte must be <= 126 for 32 of them to do), laid out as the A
 //     operand: 16 bytes per lane and k-step, lane l = row e (l & 31) and half (l >> 5) of the k-step;
 //   * MFMA bytes are signed, state bytes are not: they enter as u - 128 (one v_xor per register) and the host adds the
@@ -19,8 +20,10 @@
 //     half of its byte registers its partner lane (+-32) must feed to that partner (v_permlane32_swap, once per layer);
 //     afterwards the 32 sums of a state sit half on its own lane and half on the partner: sixteen more swaps per row;
 //   * the 32 sums S_e (|S_e| < 2^25) are the integer V = sum_e S_e 2^(8e) = sum u Y < 2^272: eight 64-bit word sums, a
-//     carry pass, a re-cut into ten 29-bit limbs and ONE Montgomery step (division by 2^29, which the table carries: round 3
-//     took two, but V / 2^29 + p already fits nine limbs) give the row below 2^243 + p - 9 multiplies instead of 810.
+//     carry pass, ONE Montgomery step in the word domain (division by 2^32, which the table carries: 8 multiplies, the quotient
+//     of each step the accumulator's high register as it stands) and a re-cut of the eight result words into nine 29-bit limbs give
+//     the row below 2^240 + p - instead of 810 multiplies.  (Rounds 3-4 re-cut first and divided by 2^29 in the limb domain: a 64-bit
+//     shift, a mask and a zero-extension per limb more.)
 //
 // The table of one row (n_in KiB: 9 for a dense row of t = 9, 14 for a row of its window layers) passes through an LDS tile once per
 // WORKGROUP, in stages (read per wave from L2 the L2 -> L1 path sets the time), which is why the engines that use this run several waves
@@ -39,7 +42,7 @@ namespace pmx {
 #endif
 #define PMX_MFMA_MAX_T 9   // (a row's mid-column budget and the 36 t / 32 k-steps are laid out for t <= 9)
 constexpr int kMfmaElemBytes = 32;   // K bytes per element: every input of a layer is below 2^256 (see above), one k-step each
-constexpr int kMfmaShift = 29;       // the tables hold c 2^(8 b + kMfmaShift): the row finish divides by 2^29 (one Montgomery step)
+constexpr int kMfmaShift = 32;       // the tables hold c 2^(8 b + kMfmaShift): the row finish divides by 2^32 (one Montgomery step in the word domain)
 PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32; }
 PMX_FN constexpr int mfma_row_words(int t) { return mfma_k_steps(t) * 64 * 4; }             // A operand of one output row
 PMX_FN constexpr int mfma_layer_words(int t) { return t * mfma_row_words(t) + t * 16; }     // t rows, then t x 8 int64 corrections
@@ -118,7 +121,7 @@ PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
 }
 
 // One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's
-// correction, as eight 64-bit word sums with carries, re-cut into ten 29-bit limbs, one Montgomery step: V 2^-29 mod p, below 2^243 + p.
+// correction, as eight 64-bit word sums with carries (V < 2^272); then one Montgomery step, V 2^-32 mod p (mfma_row_words below).
 PMX_FN void mfma_row_word_sums(const int32_t (&R)[8][4], const long long *corr, uint32_t (&wd)[9]) {
     // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from
     // registers the compiler cannot see through, or it would turn each into a sign extension, a 64-bit shift and a 64-bit add - and
@@ -147,33 +150,36 @@ PMX_FN void mfma_row_word_sums(const int32_t (&R)[8][4], const long long *corr, 
     }
     wd[8] = (uint32_t)carry;   // V >= 0: the top carry is not negative
 }
-PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
+// ONE Montgomery step in the word domain on the row's word sums: m = V (-p^-1) mod 2^32, r = (V + m p) / 2^32 < 2^240 + p < 2^256 as eight
+// words (the table carries the 2^32).  The quotient of a 32-bit step is the accumulator's high register as it stands, where the 29-bit
+// step of rounds 3-4 paid a 64-bit shift, a mask and a zero-extension per limb.
+PMX_FN void mfma_row_words(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f, uint32_t (&r)[8]) {
     uint32_t wd[9];
     mfma_row_word_sums(R, corr, wd);
-    // ten 29-bit limbs out of the nine words: one funnel shift and one mask each
-    uint32_t L[10];
+    const uint32_t m = wd[0] * f.io[kIoPinv32];
+    uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        const int bit = kW * k, wi = bit / 32, sh = bit % 32;
-        const uint32_t lo = wd[wi], hi = wi + 1 < 9 ? wd[wi + 1] : 0u;
-#if defined(__HIP_DEVICE_COMPILE__)
-        L[k] = (sh == 0 ? lo : __builtin_amdgcn_alignbit(hi, lo, sh)) & kMask;
-#else
-        L[k] = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & kMask;
-#endif
+    for (int k = 0; k < 8; ++k) {
+        acc = (uint64_t)m * f.io[kIoP32 + k] + wd[k] + (acc >> 32);   // (2^32 - 1)^2 + 2 (2^32 - 1) = 2^64 - 1: no overflow
+        if (k >= 1) r[k - 1] = (uint32_t)acc;
     }
-    // ONE Montgomery step: V < 2^272, so (V + m p) / 2^29 < 2^243 + p already fits nine limbs (the table carries the 2^29)
-    uint64_t acc = L[0];
-    const uint32_t m0 = ((uint32_t)acc * f.pinv) & kMask;
-    acc += (uint64_t)m0 * f.p[0];
-    acc >>= kW;
+    r[7] = wd[8] + (uint32_t)(acc >> 32);
+}
+// A row as a field ELEMENT: the eight words re-cut into nine 29-bit limbs, one funnel shift and one mask each (norm, below 2^240 + p).
+PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
+    uint32_t r[8];
+    mfma_row_words(R, corr, f, r);
     Fe row;
 #pragma unroll
-    for (int k = 1; k <= 9; ++k) {
-        acc += L[k];
-        if (k <= 8) acc += (uint64_t)m0 * f.p[k];
-        row.l[k - 1] = k < 9 ? ((uint32_t)acc & kMask) : (uint32_t)acc;
-        acc >>= kW;
+    for (int k = 0; k < kN; ++k) {
+        const int bit = kW * k, wi = bit / 32, sh = bit % 32;
+        const uint32_t lo = r[wi], hi = wi + 1 < 8 ? r[wi + 1] : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t v = sh == 0 ? lo : __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+        const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+        row.l[k] = k + 1 < kN ? (v & kMask) : v;   // (the top limb is what is left of the last word)
     }
     return row;
 }
@@ -181,22 +187,15 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
 #if defined(__HIPCC__)
 __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y);
 #endif
-// A row in OPERAND form (mfma_fe_rows): the table carries 2^32, the Montgomery step runs in the word domain - m = V (-p^-1) mod 2^32,
-// (V + m p) / 2^32 < 2^240 + p < 2^256 - and the eight result words, u - 128 per byte (and on the device the second half handed to the
-// partner lane), ARE the operand words of a layer input.  They travel in the first eight words of an Fe-sized container (the scratch
-// slots hold nine words either way).  95 VALU instructions instead of 125 for the element form and 27 for cutting it again.
+// A row in OPERAND form (mfma_fe_rows): the eight result words, u - 128 per byte (and on the device the second half handed to the partner
+// lane), ARE the operand words of a layer input - no re-cut into limbs, no byte cut.  They travel in the first eight words of an Fe-sized
+// container (the scratch slots hold nine words either way).
 PMX_FN Fe mfma_row_finish_operand(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
-    uint32_t wd[9];
-    mfma_row_word_sums(R, corr, wd);
-    const uint32_t m = wd[0] * f.io[kIoPinv32];
-    uint64_t acc = 0;
+    uint32_t r[8];
+    mfma_row_words(R, corr, f, r);
     Fe row;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        acc = (uint64_t)m * f.io[kIoP32 + k] + wd[k] + (acc >> 32);   // (2^32 - 1)^2 + 2 (2^32 - 1) = 2^64 - 1: no overflow
-        if (k >= 1) row.l[k - 1] = (uint32_t)acc ^ 0x80808080u;
-    }
-    row.l[7] = (wd[8] + (uint32_t)(acc >> 32)) ^ 0x80808080u;
+    for (int k = 0; k < 8; ++k) row.l[k] = r[k] ^ 0x80808080u;
     row.l[8] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll

@@ -66,19 +66,18 @@ struct Prepared {
 };
 
 // One dense layer as the A operands of pmx_mfma.hpp: `rows` = t rows of t constants (ABI Montgomery residues, row-major).
-// Row i, k-step q, lane l: 16 bytes = bytes e = l & 31 of the residues  Y = c_ij * 2^(8 b + 29) mod p  for the 16 positions
+// Row i, k-step q, lane l: 16 bytes = bytes e = l & 31 of the residues  Y = c_ij * 2^(8 b + 32) mod p  for the 16 positions
 // k = 32 q + 16 (l >> 5) + 0..15 of the state's byte string (k = 36 j + b), as balanced signed bytes; then per row the eight
 // word sums of 128 * sum_k Y_k (the state's bytes enter as u - 128).
 // General form: n_out rows of n_in constants; aff (may be null): one constant per row added to the row's value.
-// fe_rows: rows [0, fe_rows) are finished as field elements (one Montgomery step of 29 bits), the rest in OPERAND form (one of 32 bits:
-// pmx_mfma.hpp, mfma_row_finish_operand) - the table carries the power of two its row's finish divides by
-inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in, size_t n_out, const U256 *aff, uint32_t *dst, size_t fe_rows = (size_t)-1) {
+// (the table carries the 2^32 the row's finish divides by - element or operand form, the Montgomery step is the same: pmx_mfma.hpp, mfma_row_words)
+inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in, size_t n_out, const U256 *aff, uint32_t *dst) {
     const size_t nq = (size_t)mfma_k_steps((int)n_in), row_words = (size_t)mfma_row_words((int)n_in);
     int8_t *bytes = reinterpret_cast<int8_t *>(dst);
     long long *corr = reinterpret_cast<long long *>(dst + n_out * row_words);
     for (size_t i = 0; i < n_out; ++i) {
         long long colsum[32] = {0};
-        const int shift = i < fe_rows ? kMfmaShift : 32;
+        constexpr int shift = kMfmaShift;
         for (size_t j = 0; j < n_in; ++j) {
             U256 y = times_pow2(hf, hf.from_mont(rows[i * n_in + j]), shift);
             for (size_t b = 0; b < (size_t)kMfmaElemBytes; ++b) {   // (the inputs of a layer are below 2^256: pmx_mfma.hpp)
@@ -656,10 +655,10 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
             uint32_t *dst = &out.consts[out.win_offset];
             // (rows that only feed matrix-core inputs - every carried lane but the first, where the history terms are rows too - stay in
             // operand form between the layers: pmx_mfma.hpp, mfma_fe_rows; the last window's layer feeds S-boxes on every lane)
-            put_mfma_layer_io(hf, plan.entry_rows.data(), t, t, plan.entry_aff.data(), dst, (size_t)mfma_fe_rows((int)t));
+            put_mfma_layer_io(hf, plan.entry_rows.data(), t, t, plan.entry_aff.data(), dst);
             dst += mfma_layer_words((int)t);
             for (size_t w = 0; w < plan.n_win; ++w) {
-                put_mfma_layer_io(hf, plan.rows[w].data(), t - 1 + K, t, plan.aff[w].data(), dst, w + 1 < plan.n_win ? (size_t)mfma_fe_rows((int)t) : (size_t)t);
+                put_mfma_layer_io(hf, plan.rows[w].data(), t - 1 + K, t, plan.aff[w].data(), dst);
                 dst += lw_in;
                 if (mfma_hist_tab((int)t)) {
                     for (uint32_t k = 2; k < K; ++k)
