@@ -6,11 +6,11 @@
 // of the wave (one per lane), whose K dimension is the bytes of the state and whose M dimension is the bytes of the result:
 //
 //   * every element z_j a layer takes in is an S-box output (a Montgomery product: below 1.3 p) or a row of the layer before
-//     (below 2^240 + p), so with p < 2^255 it is below 2^256: it is re-cut into 32 bytes u_{j,b} - eight words, exactly ONE k-step of
+//     (below 2^248 + p), so with p < 2^255 it is below 2^256: it is re-cut into 32 bytes u_{j,b} - eight words, exactly ONE k-step of
 //     the matrix-core instruction per element (round 5; rounds 3-4 carried 36 bytes per element, 33 used, for values up to 2^261:
 //     -12 ... -25 % products per row, 16 registers fewer at t = 9; the bound holds for every exponent: alpha = 1 is formed as the
 //     product x * 1, alpha = 0 is the constant 1 - pmx_field.hpp: fe_sbox);
-//   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 32) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
+//   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 24) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
 //     (pmx_prepare.hpp: put_mfma_layer; the modulus' top byte must be <= 126 for 32 of them to do), laid out as the A
 //     operand: 16 bytes per lane and k-step, lane l = row e (l & 31) and half (l >> 5) of the k-step;
 //   * MFMA bytes are signed, state bytes are not: they enter as u - 128 (one v_xor per register) and the host adds the
@@ -20,10 +20,8 @@
 //     half of its byte registers its partner lane (+-32) must feed to that partner (v_permlane32_swap, once per layer);
 //     afterwards the 32 sums of a state sit half on its own lane and half on the partner: sixteen more swaps per row;
 //   * the 32 sums S_e (|S_e| < 2^25) are the integer V = sum_e S_e 2^(8e) = sum u Y < 2^272: eight 64-bit word sums, a
-//     carry pass, ONE Montgomery step in the word domain (division by 2^32, which the table carries: 8 multiplies, the quotient
-//     of each step the accumulator's high register as it stands) and a re-cut of the eight result words into nine 29-bit limbs give
-//     the row below 2^240 + p - instead of 810 multiplies.  (Rounds 3-4 re-cut first and divided by 2^29 in the limb domain: a 64-bit
-//     shift, a mask and a zero-extension per limb more.)
+//     carry pass with ONE Montgomery step of 24 bits inside it (the table carries the 2^24: one multiply-add per word on top of the
+//     word sum, mfma_row_acc) and a re-cut of the words into nine 29-bit limbs give the row below 2^248 + p - instead of 810 multiplies.
 //
 // The table of one row (n_in KiB: 9 for a dense row of t = 9, 14 for a row of its window layers) passes through an LDS tile once per
 // WORKGROUP, in stages (read per wave from L2 the L2 -> L1 path sets the time), which is why the engines that use this run several waves
@@ -42,7 +40,7 @@ namespace pmx {
 #endif
 #define PMX_MFMA_MAX_T 9   // (a row's mid-column budget and the 36 t / 32 k-steps are laid out for t <= 9)
 constexpr int kMfmaElemBytes = 32;   // K bytes per element: every input of a layer is below 2^256 (see above), one k-step each
-constexpr int kMfmaShift = 32;       // the tables hold c 2^(8 b + kMfmaShift): the row finish divides by 2^32 (one Montgomery step in the word domain)
+constexpr int kMfmaShift = 24;       // the tables hold c 2^(8 b + kMfmaShift): the row finish divides by 2^24 (one Montgomery step inside the word sums)
 PMX_FN constexpr int mfma_k_steps(int t) { return (t * kMfmaElemBytes + 31) / 32; }
 PMX_FN constexpr int mfma_row_words(int t) { return mfma_k_steps(t) * 64 * 4; }             // A operand of one output row
 PMX_FN constexpr int mfma_layer_words(int t) { return t * mfma_row_words(t) + t * 16; }     // t rows, then t x 8 int64 corrections
@@ -120,14 +118,19 @@ PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
     static_for<0, T>([&](auto jj) { mfma_cut_element(s[decltype(jj)::value], &W[8 * decltype(jj)::value]); });
 }
 
-// One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's
-// correction, as eight 64-bit word sums with carries (V < 2^272); then one Montgomery step, V 2^-32 mod p (mfma_row_words below).
-PMX_FN void mfma_row_word_sums(const int32_t (&R)[8][4], const long long *corr, uint32_t (&wd)[9]) {
+// One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's correction
+// (V < 2^272) is formed as eight 64-bit word sums with carries, and ONE Montgomery step of 24 bits runs in the SAME accumulators:
+// m = V (-p^-1) mod 2^24 is known after word 0, and every word takes m p_w (below 2^56) on top of its sum (|t| < 2^50) before its
+// carry leaves - one v_mad_u64_u32 per word, where a step of its own behind the carry pass paid four (two zero-extensions, the product,
+// a 64-bit add: round 5's first form, 2^32) and the 29-bit step of rounds 3-4 five per limb.  a[0 .. 8] are the words of V + m p: the low
+// 24 bits are zero, (V + m p) / 2^24 < 2^248 + p < 2^256 is the row (the table carries the 2^24), read out of a[] at bit 24.
+PMX_FN void mfma_row_acc(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f, uint32_t (&a)[9]) {
     // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from
     // registers the compiler cannot see through, or it would turn each into a sign extension, a 64-bit shift and a 64-bit add - and
     // from VECTOR registers, so that the row's correction, a wave-uniform 64-bit value in a scalar pair, can be the addend of the word's
     // first mad as it stands (an instruction takes one scalar operand: with the weights in SGPRs every correction word cost two
-    // v_mov, 16 per row).  |t| < 2^50, so the carry into the next word (t >> 32) is the high register as it stands.
+    // v_mov, 16 per row).  The accumulator stays inside the signed range (|t| < 2^57), so the carry into the next word (t >> 32) is the
+    // high register as it stands.
     int w1, w8, w16, w24;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("v_mov_b32 %0, 1" : "=v"(w1));
@@ -138,6 +141,7 @@ PMX_FN void mfma_row_word_sums(const int32_t (&R)[8][4], const long long *corr, 
     w1 = 1, w8 = 1 << 8, w16 = 1 << 16, w24 = 1 << 24;
 #endif
     int carry = 0;
+    uint32_t m = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
         long long t = corr[w] + (long long)carry * w1;
@@ -145,41 +149,32 @@ PMX_FN void mfma_row_word_sums(const int32_t (&R)[8][4], const long long *corr, 
         t += (long long)R[w][1] * w8;
         t += (long long)R[w][2] * w16;
         t += (long long)R[w][3] * w24;
-        wd[w] = (uint32_t)t;
+        if (w == 0) m = ((uint32_t)t * f.io[kIoPinv32]) & 0xffffffu;
+        t = (long long)((uint64_t)m * f.io[kIoP32 + w] + (uint64_t)t);
+        a[w] = (uint32_t)t;
         carry = (int)(t >> 32);
     }
-    wd[8] = (uint32_t)carry;   // V >= 0: the top carry is not negative
+    a[8] = (uint32_t)carry;   // V + m p >= 0: the top carry is not negative
 }
-// ONE Montgomery step in the word domain on the row's word sums: m = V (-p^-1) mod 2^32, r = (V + m p) / 2^32 < 2^240 + p < 2^256 as eight
-// words (the table carries the 2^32).  The quotient of a 32-bit step is the accumulator's high register as it stands, where the 29-bit
-// step of rounds 3-4 paid a 64-bit shift, a mask and a zero-extension per limb.
-PMX_FN void mfma_row_words(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f, uint32_t (&r)[8]) {
-    uint32_t wd[9];
-    mfma_row_word_sums(R, corr, wd);
-    const uint32_t m = wd[0] * f.io[kIoPinv32];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        acc = (uint64_t)m * f.io[kIoP32 + k] + wd[k] + (acc >> 32);   // (2^32 - 1)^2 + 2 (2^32 - 1) = 2^64 - 1: no overflow
-        if (k >= 1) r[k - 1] = (uint32_t)acc;
-    }
-    r[7] = wd[8] + (uint32_t)(acc >> 32);
+// 32 bits of the row from bit `bit` of a[] on (a funnel shift on the device)
+PMX_FN uint32_t mfma_row_bits(const uint32_t (&a)[9], int bit) {
+    const int wi = bit / 32, sh = bit % 32;
+    const uint32_t lo = a[wi], hi = wi + 1 < 9 ? a[wi + 1] : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return sh == 0 ? lo : __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
 }
-// A row as a field ELEMENT: the eight words re-cut into nine 29-bit limbs, one funnel shift and one mask each (norm, below 2^240 + p).
+// A row as a field ELEMENT: nine 29-bit limbs, one funnel shift and one mask each (norm, below 2^248 + p).
 PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
-    uint32_t r[8];
-    mfma_row_words(R, corr, f, r);
+    uint32_t a[9];
+    mfma_row_acc(R, corr, f, a);
     Fe row;
 #pragma unroll
     for (int k = 0; k < kN; ++k) {
-        const int bit = kW * k, wi = bit / 32, sh = bit % 32;
-        const uint32_t lo = r[wi], hi = wi + 1 < 8 ? r[wi + 1] : 0u;
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t v = sh == 0 ? lo : __builtin_amdgcn_alignbit(hi, lo, sh);
-#else
-        const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
-#endif
-        row.l[k] = k + 1 < kN ? (v & kMask) : v;   // (the top limb is what is left of the last word)
+        const uint32_t v = mfma_row_bits(a, kMfmaShift + kW * k);
+        row.l[k] = k + 1 < kN ? (v & kMask) : v;   // (the top limb is the top carry)
     }
     return row;
 }
@@ -187,15 +182,15 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
 #if defined(__HIPCC__)
 __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y);
 #endif
-// A row in OPERAND form (mfma_fe_rows): the eight result words, u - 128 per byte (and on the device the second half handed to the partner
+// A row in OPERAND form (mfma_fe_rows): its eight words, u - 128 per byte (and on the device the second half handed to the partner
 // lane), ARE the operand words of a layer input - no re-cut into limbs, no byte cut.  They travel in the first eight words of an Fe-sized
 // container (the scratch slots hold nine words either way).
 PMX_FN Fe mfma_row_finish_operand(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
-    uint32_t r[8];
-    mfma_row_words(R, corr, f, r);
+    uint32_t a[9];
+    mfma_row_acc(R, corr, f, a);
     Fe row;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) row.l[k] = r[k] ^ 0x80808080u;
+    for (int k = 0; k < 8; ++k) row.l[k] = mfma_row_bits(a, kMfmaShift + 32 * k) ^ 0x80808080u;
     row.l[8] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
