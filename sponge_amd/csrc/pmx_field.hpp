@@ -112,9 +112,9 @@ struct FieldRt {
     uint32_t p[kN];       // modulus, 29-bit limbs
     uint32_t pinv;        // -p^-1 mod 2^29
     uint32_t unit;        // 1, as a run-time value: x * unit + acc is a single v_mad_u64_u32 (mont_mul_add, tab_dot)
-    const uint32_t *io;   // kIoWords words: [p as 8 x 32-bit limbs | 2^266 mod p | 2^256 mod p (9 x 29-bit limbs each) | -p^-1 mod 2^32]
+    const uint32_t *io;   // kIoWords words: [p as 8 x 32-bit limbs | 2^266 mod p | 2^256 mod p (9 x 29-bit limbs each)]
 };
-constexpr int kIoP32 = 0, kIoToInt = 8, kIoToAbi = 8 + kN, kIoPinv32 = 8 + 2 * kN, kIoWords = 28;   // (kIoPinv32: -p^-1 mod 2^32, pmx_mfma.hpp)
+constexpr int kIoP32 = 0, kIoToInt = 8, kIoToAbi = 8 + kN, kIoWords = 28;
 
 #if defined(PMX_HOSTCHECK) && !defined(__HIPCC__)
 void hostcheck_track(int tag, const Fe &x, const FieldRt &f);   // defined in tests/hostcheck/pmx_hostcheck.cpp

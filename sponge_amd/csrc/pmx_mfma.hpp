@@ -149,7 +149,7 @@ PMX_FN void mfma_row_acc(const int32_t (&R)[8][4], const long long *corr, const 
         t += (long long)R[w][1] * w8;
         t += (long long)R[w][2] * w16;
         t += (long long)R[w][3] * w24;
-        if (w == 0) m = ((uint32_t)t * f.io[kIoPinv32]) & 0xffffffu;
+        if (w == 0) m = ((uint32_t)t * f.pinv) & 0xffffffu;   // (-1/p mod 2^29 serves modulo 2^24 - and lives in a scalar register for the S-boxes anyway)
         t = (long long)((uint64_t)m * f.io[kIoP32 + w] + (uint64_t)t);
         a[w] = (uint32_t)t;
         carry = (int)(t >> 32);

@@ -692,7 +692,6 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
     std::memcpy(&out.consts[out.io_offset + kIoP32], hf.p.l, 32);
     to_limbs29(times_pow2(hf, hf.r, 10), &out.consts[out.io_offset + kIoToInt]);   // 2^266 mod p
     to_limbs29(hf.r, &out.consts[out.io_offset + kIoToAbi]);                       // 2^256 mod p
-    out.consts[out.io_offset + kIoPinv32] = (uint32_t)hf.inv;                      // -p^-1 mod 2^32
     f.io = out.consts.data() + out.io_offset;   // host view; valid while `out` is neither copied nor resized
     to_limbs29(times_pow2(hf, hf.r, 5), out.one.l);     // 2^261 mod p
     out.c.rate = cfg->rate;
