@@ -71,13 +71,13 @@ PMX_FN constexpr int mfma_window_hist(int k) { return (k - 1) * (k - 2) / 2; }  
 PMX_FN constexpr bool mfma_hist_tab(int t) { return t <= PMX_MFMA_HIST_TAB_MAX_T; }
 // ROWS ON THE MATRIX CORES (round 5): the history term is itself a product by constants of values that are cut into bytes for the window's
 // layer anyway - one row of k inputs (z_1 .. z_{k-1}, u_k), its A operand read straight from global memory a whole S-box ahead (k KiB per
-// wave: no tile, no barrier), its 2 k products issued right behind S-box k.  125 VALU instructions + 2 k products instead of the
+// wave: no tile, no barrier), its 2 k products issued right behind S-box k.  One row finish + 2 k products instead of the
 // 81 (k - 1) + 90 multiplies of the element form (t = 9: 4 rows and 28 products per window instead of 1170 multiplies).
 PMX_FN constexpr bool mfma_hist_rows(int t) { return !mfma_hist_tab(t); }
 // With the history terms as rows, the only outputs of a layer inside the partial section that are ever needed as field ELEMENTS are row 0
 // (x_1, the first S-box input) and row 1 (u_1: x_2 = z_1 + u_1); the other carried lanes only ever enter matrix-core rows again.  Those
-// rows are finished in OPERAND form (mfma_row_finish_operand: one Montgomery step of 32 bits in the word domain, the result - below
-// 2^240 + p - IS the eight operand words) and travel between the layers as such: no re-cut into limbs, no 29-bit step, no byte cut.
+// rows are finished in OPERAND form (mfma_row_finish_operand: the row - below 2^248 + p - read out of the accumulators as eight 32-bit
+// words IS the eight operand words) and travel between the layers as such: no re-cut into limbs, no byte cut.
 PMX_FN constexpr int mfma_fe_rows(int t) { return mfma_hist_rows(t) ? 2 : t; }
 PMX_FN constexpr int mfma_hist_row_words(int k) { return mfma_k_steps(k) * 64 * 4 + 16; }          // the row of x_{k+1}: k inputs, eight correction words
 PMX_FN constexpr int mfma_hist_rows_offset(int k) {                                               // words in front of it
