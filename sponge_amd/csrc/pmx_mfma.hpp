@@ -33,8 +33,8 @@
 
 namespace pmx {
 
-// Widths whose dense layers go to the matrix cores.  A row costs ~155 VALU instructions of finish plus its share of the state's
-// re-cut (26 per element) and 2 x ceil(36 t / 32) MFMA issue slots, against 81 t + 81 multiplies and their carries on the VALU.
+// Widths whose dense layers go to the matrix cores.  A row costs ~85 VALU instructions of finish plus its share of the state's
+// re-cut (27 per element) and 2 t MFMA issue slots (58 clocks of the matrix pipe each), against 81 t + 81 multiplies and their carries on the VALU.
 #ifndef PMX_MFMA_MIN_T
 #define PMX_MFMA_MIN_T 3   // (10: the library never selects these engines nor builds their tables - INTEGRATION.md section 8)
 #endif
