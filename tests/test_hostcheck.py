@@ -387,6 +387,34 @@ def test_small_exponents_on_every_schedule(hc, t, alpha):
         assert cref.limbs_to_elems(out, p) == want, (name, t, alpha)
 
 
+@pytest.mark.parametrize("bits,p", [(225, 0x1882ad8ca6a206c7cd20288177a3a38f73c4ab461bf14fa62af9de87b),
+                                    (240, 0xeb9797ba8095d06d76ced8af9057c675cc48793c0a7424fffabd8db081d7),
+                                    (250, 0x2ca0806c3cccc1b9c01d4041d309b8d3b3806aefb11c60086a765dae8b3ccc5)])
+@pytest.mark.parametrize("t", [3, 9])
+def test_small_moduli_on_every_schedule(hc, bits, p, t):
+    """The library takes primes of 225 ... 255 bits (pmx_prepare.hpp).  The bounds of the matrix-core rows are stated for the largest
+    (a row is below 2^248 + p) but scale with the modulus - V < (bytes of the inputs) * 255 * p - so the exit's two conditional
+    subtractions also do for the smallest.  Every host schedule against the oracle over three primes far below the benchmarked sizes."""
+    for name in ("hc_permute_hybrid_mfma", "hc_permute_hybrid", "hc_permute_rt", "hc_permute"):
+        getattr(hc, name).argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    cfg = O.make_config(p, bits, t - 1, 5, 8, 22)
+    rng = random.Random(bits + t)
+    states = [[rng.randrange(p) for _ in range(t)] for _ in range(3)] + [[p - 1] * t, [0] * t]
+    want = [x for st in states for x in O.permute(cfg, st)]
+    limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), t, 4)
+    ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+    mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+    c = PmxConfig()
+    c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = 8, 22, 5, t - 1, 1
+    for i, l in enumerate(O.to_limbs(p)):
+        c.modulus[i] = l
+    c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+    for name in ("hc_permute_hybrid_mfma", "hc_permute_hybrid", "hc_permute_rt", "hc_permute"):
+        out = limbs.copy()
+        assert getattr(hc, name)(ctypes.byref(c), out.ctypes.data, len(states)) == 0, (name, bits, t)
+        assert cref.limbs_to_elems(out, p) == want, (name, bits, t)
+
+
 @pytest.mark.parametrize("t,alpha", [(3, 5), (3, 17), (4, 5), (9, 5)])
 def test_a_zero_capacity_lane_skips_its_first_sbox(hc, t, alpha):
     """pmx_permute.hpp (lane0_zero): compress and the first permutation of a hash row know lane 0 is zero, so round 0 puts the config's

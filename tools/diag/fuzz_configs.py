@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Seeded random Poseidon configurations on the GPU against the C port (oracle/): every exponent class (0, 1, small, the usual, 64-bit),
-odd and zero round counts, every rate / capacity split of widths 2 ... 12, both fields; per config whole permutations at several batch
+odd and zero round counts, every rate / capacity split of widths 2 ... 12, both benchmarked fields and (every fourth config) a random prime of 225 ... 255 bits; per config whole permutations at several batch
 sizes (both sides of the engine thresholds at t = 3), the fixed-shape hash, a small tree and (every other config) the duplex driver on sponges in mixed modes.  Prints one line per failing case and a
 summary; exit code 1 if anything differs.      usage: tools/diag/fuzz_configs.py [n_configs] [seed]"""
 import os, sys, random, time
@@ -14,13 +14,48 @@ from oracle import cref, poseidon_oracle as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 FIELDS = {"bls12_381_fr": (O.BLS12_381_FR, 255), "bn254_fr": (O.BN254_FR, 254)}
+
+
+def _is_prime(n):
+    for q in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % q == 0:
+            return n == q
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def random_prime(bits):
+    """a prime of exactly `bits` bits (the library takes 225 ... 255: pmx_prepare.hpp)"""
+    while True:
+        c = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        if _is_prime(c):
+            return c
 ALPHAS = [0, 1, 1, 2, 3, 4, 5, 5, 5, 6, 7, 11, 17, 17, 257, 65537, (1 << 32) + 1, (1 << 63) + 1, (1 << 64) - 1]
 bad = 0
 t0 = time.time()
 for k in range(N):
-    fname = rng.choice(list(FIELDS))
-    p, bits = FIELDS[fname]
-    f = S.FIELDS[fname]
+    if k % 4 == 3:                       # every fourth config over a random prime: any size the library takes, any top byte
+        bits = rng.choice([225, 226, 233, 240, 247, 248, 249, 253, 254, 255])
+        p = random_prime(bits)
+        fname = "prime%d_%x" % (bits, p >> (bits - 16))
+        f = S.Field(fname, p)
+    else:
+        fname = rng.choice(list(FIELDS))
+        p, bits = FIELDS[fname]
+        f = S.FIELDS[fname]
     t = rng.choice([2, 3, 3, 3, 4, 5, 6, 7, 8, 9, 9, 10, 12])
     capacity = rng.choice([1, 1, 1, 0, 2, 3])
     capacity = min(capacity, t - 1)
