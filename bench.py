@@ -76,7 +76,8 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     costs 81 N + 18 instead of 81 N + 81 (`row_tables`) and an identity-lane update 81 + 18 + 9 instead of 162 + 9
     (`lane_tables`).  The optimised schedule carries the state scaled lane by lane so that one entry per row of every
     matrix but the last round's is exactly one (pmx_prepare.hpp: derive_opt_tables).  `mfma_dense`: the rows of the DENSE
-    layers come from the matrix cores (pmx_mfma.hpp) - 9 multiplies each, the Montgomery step of the row's finish.
+    layers come from the matrix cores (pmx_mfma.hpp) - 8 multiplies each, the Montgomery step inside the word sums of the row's finish
+    (the 40 v_mad_i64_i32 of the word sums themselves are not counted: the figure is about v_mad_u64_u32).
     `window` = K > 0: the partial rounds as windows of K S-boxes (the first window takes the remainder), each closed by one
     matrix-core layer of t rows; on the VALU a window keeps its S-boxes and the history products of its later S-box inputs
     (x_{k+1} = z_k + u_k + sum_{i<k} h_{k,i} z_i: a (k-1)-term dot product with an addend, element form); the layer after the
@@ -91,18 +92,19 @@ def mads_per_permutation(t, alpha, rf, rp, optimised, row_tables=False, lane_tab
     norm = 81 * (t - 1) + red + 9                           # a normalised row: t - 1 terms + 9 multiply-by-one injections of the addend
     lane = (81 + 18 + 9) if lane_tables else (mul + 9)
     sparse = norm + (t - 1) * lane                          # a sparse layer: row 0 and the identity lanes
+    row_finish = 8
     if mfma_dense:
-        dot = norm_dense = 9
+        dot = norm_dense = row_finish
     else:
         norm_dense = norm
     if optimised and mfma_dense and window > 0:
         n_win = -(-rp // window)
         sizes = [rp - (n_win - 1) * window] + [window] * (n_win - 1)
         if row_tables == 2:      # the history terms as rows on the matrix cores too (pmx_mfma.hpp: mfma_hist_rows): a row finish each
-            hist = sum(9 for kw in sizes for k in range(2, kw))
+            hist = sum(row_finish for kw in sizes for k in range(2, kw))
         else:
             hist = sum(81 * (k - 1) + red + 9 for kw in sizes for k in range(2, kw))     # (`row_tables`: their constants as shifted tables)
-        return (rf * t + rp) * chain + (rf + n_win) * t * 9 + hist
+        return (rf * t + rp) * chain + (rf + n_win) * t * row_finish + hist
     if optimised:
         # S-box layers: RF full, RP partial.  Linear layers: RF - 2 normalised dense (every full round but the entrance and the
         # last one) + 1 dense (last round) + RP sparse (after the entrance round and after every partial round but the last)
