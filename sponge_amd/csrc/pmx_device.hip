@@ -210,7 +210,7 @@ struct RegEngine {
 // waves per SIMD, +3.8 %; t = 5, 6 three waves (t = 6, 176 VGPRs left alone, +6 % when held to 168); t = 7, 8, 9 spill and lose
 // 23 / 46 / 68 % when held to three (round 3 A/B).
 constexpr int kHybWaves = 1, kHyb4WaveMaxT = 4, kHyb3WaveMaxT = 6;
-// MFMA: every product by a constant runs on the matrix cores (pmx_mfma.hpp) - the dense layers and, as windows of up to six S-boxes
+// MFMA: every product by a constant runs on the matrix cores (pmx_mfma.hpp) - the dense layers and, as windows of t S-boxes
 // per layer, the linear part of the partial rounds; the kMfmaWaves waves of a workgroup share one LDS tile of the layer's table
 // rows.  Wave-uniform kernels only (permute, hash, compress, and the passes of the absorb / squeeze driver, which ARE permutation
 // launches: inside a per-lane loop not every lane is active, and the lane exchange of this path needs both lanes of a pair).

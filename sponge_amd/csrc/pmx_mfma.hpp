@@ -53,8 +53,11 @@ PMX_FN constexpr int mfma_layer_words_io(int n_in, int n_out) { return n_out * m
 // constants - and the whole linear part of the K rounds (2t-1 products by constants each on the VALU) is ONE layer on the
 // matrix cores: inputs (u_1 .. u_{t-1}, z_1 .. z_K), outputs (x_1, u_1 .. u_{t-1}) of the next window, or the state the full
 // rounds after the partial section expect.  The first window is the short one when K does not divide the number of partial rounds.
+// K = the width (capped at 9, the widest state of these engines): with the history terms as rows on the matrix cores a longer window
+// costs one row finish per S-box more and saves a whole layer of t rows per window fewer - 6 was the optimum of round 4, when a history
+// term was 81 (k - 1) + 90 multiplies on the VALU (profiles/r05/u_ab_window_as_long_as_the_width.txt: C3 +2.3 %, t = 8 +1.4 %, d9 +2.4 %).
 #ifndef PMX_MFMA_WINDOW
-#define PMX_MFMA_WINDOW 6
+#define PMX_MFMA_WINDOW 9
 #endif
 // window size of a width (0: its partial rounds keep their sparse layers on the VALU)
 PMX_FN constexpr int mfma_window_for(int t) {

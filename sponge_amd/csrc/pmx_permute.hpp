@@ -330,7 +330,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                             else mfma_copy_operand(s[i], &W[8 * (i - 1)]);
                         });
                         MfmaHistRow<T> hr;
-                        constexpr bool kFetchAhead = T != 5;   // (t = 5 sits on the 168 registers of three waves per SIMD: the 16 of a fetched-ahead table spill)
+                        constexpr bool kFetchAhead = T != 5 && T != 9;   // (t = 5 sits on the 168 registers of three waves per SIMD, t = 9 carries 136 operand words: the 16 of a fetched-ahead table spill)
                         if constexpr (K > 2 && kFetchAhead) hr.template load<2>(hist);
                         Fe z = fe_sbox<ALPHA>(s[0], c.alpha, one, f);                 // z_1 = x_1^alpha: x_1 came whole out of the layer before
                         mfma_cut_operand(z, &W[8 * (T - 1)]);

@@ -440,15 +440,15 @@ def test_a_zero_capacity_lane_skips_its_first_sbox(hc, t, alpha):
     assert cref.limbs_to_elems(out, p) == want
 
 
-@pytest.mark.parametrize("K", [6, 1, 4, 9])
+@pytest.mark.parametrize("K", [9, 1, 4, 6])
 def test_partial_rounds_as_windows_every_size_and_width(K):
     """pmx_mfma.hpp / pmx_prepare.hpp (derive_window_layers): the matrix-core engines of t = 3..9 run their partial rounds as windows
     of K S-boxes closed by ONE layer each - an exact rewrite derived on the host (basis of the carried lanes chosen so that later
     S-box inputs are sums of an earlier output, a carried coordinate and K - 2 products at most; the first window takes RP mod K).
-    Host build of the same templates and tables against the big-integer oracle: the shipped size 6 (57 = 3 + 9 x 6), 1 (every
-    round its own window), 4 (first window of ONE round), 9 = t (first window of 3; at t = 7, 8 clamped to t); t = 3 .. 9;
+    Host build of the same templates and tables against the big-integer oracle: the shipped size 9 = the width at most (57 = 3 + 6 x 9
+    at t = 9; at t < 9 clamped to t), 1 (every round its own window), 4 (first window of ONE round), 6 (round 4's size); t = 3 .. 9;
     RP = 57, 56, 5, 1; alpha = 5 and the generic-exponent build; both fields of BASELINE."""
-    name = "libpmx_hostcheck.so" if K == 6 else "libpmx_hostcheck_k%d.so" % K
+    name = "libpmx_hostcheck.so" if K == 9 else "libpmx_hostcheck_k%d.so" % K
     subprocess.check_call(["make", "-C", HERE, name], stdout=subprocess.DEVNULL)
     hc = ctypes.CDLL(os.path.join(HERE, name))
     hc.hc_permute_hybrid_mfma.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]

@@ -82,14 +82,14 @@ if has slots; then
   : > $OUT/valu_count.log
   V $OUT/slots_c2 permute_kernel c2 1048576 "HybridEngine<3,5,mfma,windows of 3>" 4 $J "profiles/r05"
   V $OUT/slots_k3 permute_kernel k3 1048576 "HybridEngine<3,0,mfma,windows of 3>" 4 $J "profiles/r05"
-  V $OUT/slots_c3 permute_kernel c3 262144 "HybridEngine<9,5,mfma,windows of 6>" 2 $J "profiles/r05"
+  V $OUT/slots_c3 permute_kernel c3 262144 "HybridEngine<9,5,mfma,windows of 9>" 2 $J "profiles/r05"
   V $OUT/slots_w4 permute_kernel w4 524288 "HybridEngine<4,5,mfma,windows of 4>" 3 $J "profiles/r05"
   V $OUT/slots_w5 permute_kernel w5 524288 "HybridEngine<5,5,mfma,windows of 5>" 3 $J "profiles/r05"
   V $OUT/slots_w6 permute_kernel w6 262144 "HybridEngine<6,5,mfma,windows of 6>" 2 $J "profiles/r05"
-  V $OUT/slots_w7 permute_kernel w7 262144 "HybridEngine<7,5,mfma,windows of 6>" 2 $J "profiles/r05"
-  V $OUT/slots_w8 permute_kernel w8 262144 "HybridEngine<8,5,mfma,windows of 6>" 2 $J "profiles/r05"
+  V $OUT/slots_w7 permute_kernel w7 262144 "HybridEngine<7,5,mfma,windows of 7>" 2 $J "profiles/r05"
+  V $OUT/slots_w8 permute_kernel w8 262144 "HybridEngine<8,5,mfma,windows of 8>" 2 $J "profiles/r05"
   V $OUT/slots_h3 hash_kernel h3 2097152 "HybridEngine<3,5,mfma,windows of 3>" 4 $J "profiles/r05" 2
-  V $OUT/slots_h9 hash_kernel h9 262144 "HybridEngine<9,5,mfma,windows of 6>" 2 $J "profiles/r05"
+  V $OUT/slots_h9 hash_kernel h9 262144 "HybridEngine<9,5,mfma,windows of 9>" 2 $J "profiles/r05"
   cat $OUT/valu_count.log
   for w in d3 d9 c5_2e21; do echo "== $w (every kernel of the step)"; python3 tools/pmc_kernel_summary.py $OUT/slots_$w 2>&1 | head -60; done > $OUT/valu_driver_and_tree_kernels.txt
 fi
