@@ -181,7 +181,7 @@ int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64
  * absorb: CryptographicSponge::absorb for in_len native elements per sponge (mod.rs:232-254, 121-150).
  * squeeze: FieldBasedCryptographicSponge::squeeze_native_field_elements(out_len) (mod.rs:321-341,
  * 153-182, including the `!= rate` test of :175).  Sponges in one call may be in different modes.
- * Widths 4..9 (and width 3 from 2^17 sponges up) run a call as PASSES on the permutation engine of the width (one launch per
+ * Widths 4..9 (and width 3 from 32769 sponges up) run a call as PASSES on the permutation engine of the width (one launch per
  * permutation a sponge of the batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would
  * permute it).  EVERY absorb / squeeze call moves at most 65536 rates of elements per sponge, whatever the width and the batch
  * size (PMX_ERR_ARG beyond: split the call - to a duplex sponge two calls are the same as one).

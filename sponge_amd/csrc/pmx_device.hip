@@ -1569,15 +1569,17 @@ static constexpr size_t kQuadMaxSponges = 32768;
     } while (0)
 
 // t = 3 on the matrix cores as well (round 4): HybridEngine<3, alpha, mfma, windows of 3> - the dense layers and the partial rounds'
-// linear part as int8 GEMM layers, 46.1 k instead of 53.0 k VALU instructions per permutation at alpha = 5 - for configs that have the
-// tables (modulus rule of pmx_mfma.hpp) and launches that fill the device (the engine runs four-wave workgroups with a shared
-// table tile; below PMX_T3_MFMA_MIN units the register engine's lower latency wins).  permute, hash, compress, and the absorb /
-// squeeze drivers as passes on that engine (like the wider states); smaller calls keep the register engine's kernels.
+// linear part as int8 GEMM layers, 42.1 k instead of 53.0 k VALU instructions per permutation at alpha = 5 - for configs that have the
+// tables (modulus rule of pmx_mfma.hpp): permute, hash, compress, and the absorb / squeeze drivers as passes on that engine (like the
+// wider states).  From PMX_T3_MFMA_MIN units up, i.e. everything above the quad kernels' range: since round 5's row finish the engine
+// has the shorter dependent chain as well - a lone wave per SIMD finishes a permutation in 0.114 ms against the register engine's
+// 0.129 (hash rows 0.219 / 0.265, the absorb(4) + squeeze(3) driver 0.48 / 0.55, a tree level of 65536 compressions 0.108 / 0.126:
+// profiles/r05/v_ab_t3_engine_threshold_32769.txt; the threshold was 2^17 while the register engine was the faster one alone on a SIMD).
 // Every exponent (round 5): the window rewrite does not depend on alpha, only the S-box does - alpha = 5 on its dedicated chain,
 // anything else (17: the reference's own rate-2 default, src/test.rs:15; 257: its weights table, :23-31) on the generic S-box,
 // like the wider states.  If the engine's LDS does not fit the device the register engine keeps the call (launch and describe alike).
 #ifndef PMX_T3_MFMA_MIN
-#define PMX_T3_MFMA_MIN ((size_t)1 << 17)
+#define PMX_T3_MFMA_MIN ((size_t)32769)
 #endif
 static bool t3_mfma(const DevConfig &c, uint32_t t, size_t n) {
     return PMX_MFMA_MIN_T <= 3 && t == 3 && c.has_opt && c.mfma_dense && n >= PMX_T3_MFMA_MIN && lds_fits<HybridEngine<3, 5, true>>(c, t);

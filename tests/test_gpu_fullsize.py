@@ -128,8 +128,8 @@ def test_c5_merkle_2e20_leaves_root_and_decomposition():
 
 
 def test_wide_and_narrow_compression_kernels_agree_at_the_switch():
-    """A 2^17-leaf tree: level 1 (65536 parents) runs on the one-lane-per-state kernel, level 2 (32768) and above on
-    the cooperative kernel; both against the C restatement."""
+    """A 2^17-leaf tree: level 1 (65536 parents) runs on the window engine, level 2 (32768) and above on the cooperative
+    kernel; both against the C restatement."""
     name = "bls_t3_a5_8_31"
     cfg = product_config(name)
     m = 1 << 17
@@ -141,11 +141,10 @@ def test_wide_and_narrow_compression_kernels_agree_at_the_switch():
 
 @pytest.mark.parametrize("alpha,rf,rp", [(5, 8, 31), (17, 8, 31), (257, 8, 13)])
 def test_every_large_batch_kernel_of_t3_vs_c_oracle(alpha, rf, rp):
-    """t = 3 launches of 2^17 units and more run the shifted-table form of the kernels (pmx_device.hip: kTabMinPermute /
-    kTabMinCompress), smaller ones the element form; the small-batch tests therefore never reach the table kernels.
-    Here every entry point is driven at the switch-over size, for the two exponents with a dedicated chain and a
-    generic one, against the C port: permute, hash, mid-stream absorb + squeeze with mixed modes, and a Merkle tree
-    whose widest level (2^18 compressions) is a table launch."""
+    """t = 3 launches that fill the device (2^17 units and more; the small-batch tests stay below): every entry point for the
+    exponent with a dedicated chain and two on the generic S-box, against the C port: permute, hash, mid-stream absorb +
+    squeeze with mixed modes, and a Merkle tree whose widest level has 2^18 compressions.  (The register engine's table form,
+    which ran these sizes until round 4, is kept for moduli without int8 tables: tests/test_gpu_parity.py.)"""
     from oracle import cref
     from oracle import poseidon_oracle as O
     f = S.BLS12_381_FR

@@ -575,10 +575,37 @@ def test_sponge_driver_at_the_quad_kernel_switch(n):
         assert (int(b.mode_tag[i]), int(b.mode_index[i])) == (m, x), i
 
 
+@pytest.mark.parametrize("alpha", [5, 17, 3])
+def test_register_engine_kernels_of_a_modulus_without_matrix_core_tables(alpha):
+    """Since round 5 every t = 3 call of a config WITH the int8 tables runs on the quad kernels (<= 32768 units) or the window engine
+    (above).  The one-lane-per-state register engine - element form below 2^17 units (2^18 for compress), shifted tables from there -
+    keeps the configs whose modulus has no tables (top byte > 126: pmx_mfma.hpp): 2^255 - 19 here.  40000 units (element form) and
+    2^17 + 77 (table form) through permute, the hash driver and a tree, whole batches against the C port."""
+    from oracle import cref
+    from oracle import poseidon_oracle as O
+    import ctypes
+    p = (1 << 255) - 19
+    f = S.Field("p25519", p)
+    cfg = S.poseidon_config_from_lfsr(f, 2, alpha, 8, 31)
+    cr = cref.CRef(O.make_config(p, 255, 2, alpha, 8, 31))
+    ctx = cfg.context()
+    for n in (40000, (1 << 17) + 77):
+        info = _lib.PmxEngineInfo()
+        _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, _lib.OP_PERMUTE, n, 0, ctypes.byref(info)))
+        assert info.engine.startswith(b"RegEngine<3,") and info.mfma_dense == 0, info.engine
+        states = synth.random_elements(f, n * 3, seed=0x5EED0060 + alpha).reshape(n, 3, 4)
+        assert np.array_equal(ctx.permute_batch(states), cr.permute_batch(states, threads=0)), n
+        msgs = synth.random_elements(f, n * 5, seed=0x5EED0061 + alpha).reshape(n, 5, 4)
+        assert np.array_equal(ctx.hash_batch(msgs, 5, 3), cr.hash_batch(msgs, 5, 3, threads=0)), n
+    leaves = synth.random_elements(f, 1 << 19, seed=alpha)          # levels of 2^18 (table form) and 2^17, 2^16 (element form) compressions
+    nodes, _ = ctx.merkle_2to1(leaves)
+    assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
+
+
 @pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31"])
-def test_one_lane_element_form_kernels_between_the_switches(name):
-    """t = 3 launches of 32769 .. 2^17 - 1 units take the one-lane-per-state kernels in their element form (below: the
-    quad kernels, above: the table form).  40000 units through permute and the hash driver, whole batch against the C port."""
+def test_t3_calls_just_above_the_quad_range(name):
+    """t = 3 launches of 32769 units and more run on the window engine (below: the quad kernels): 40000 units - less than one wave per
+    SIMD - through permute and the hash driver, whole batch against the C port."""
     cfg = product_config(name)
     cr = c_oracle(name)
     n = 40000

@@ -190,25 +190,27 @@ def test_a_call_longer_than_65536_rates_is_refused_not_launched():
 
 
 @pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31", "bls_t3_a257_8_13"])
-def test_t3_device_filling_calls_run_on_the_matrix_core_engine_and_agree_with_the_register_engine(name):
+def test_t3_calls_above_the_quad_range_run_on_the_matrix_core_engine_and_agree_with_the_quad_kernels(name):
     """t = 3 - alpha = 5 (BASELINE configs[1]'s shape), alpha = 17 (the reference's own rate-2 default and the config of its only
     permutation KAT, src/test.rs:15, src/poseidon/mod.rs:376-399), alpha = 257 (its weights table, src/test.rs:23-31): calls of at
-    least 2^17 units run on HybridEngine<3,alpha,mfma,windows of 3> (alpha = 5 specialised, the others on the generic S-box: "0") -
-    permute, hash, compress, and absorb / squeeze as passes -, smaller ones on the register engine (pmx_device.hip: t3_mfma).
+    least 32769 units run on HybridEngine<3,alpha,mfma,windows of 3> (alpha = 5 specialised, the others on the generic S-box: "0") -
+    permute, hash, compress, and absorb / squeeze as passes -, smaller ones on the quad kernels (pmx_device.hip: t3_mfma).
     pmx_ctx_engine_info says which; the SAME sponges through both sides of the threshold must agree limb for limb (the first
-    2^17 - 1 of them in a second call), and a sample of the large call - the first and the last workgroup in full, 1500 at
+    32768 of them in a second call), and a sample of the large call - the first and the last workgroup in full, 1500 at
     random - is checked against the C restatement sponge by sponge, in mixed modes, through absorbs and squeezes that take
     zero, one, two and three permutations."""
     from gpu_helpers import c_oracle, product_config
     cfg, cr = product_config(name), c_oracle(name)
     f, t, r = cfg.field, 3, 2
-    big, small = (1 << 17) + 333, (1 << 17) - 1
-    a_hyb, a_reg = {5: (b"5", b"5"), 17: (b"0", b"17")}.get(cfg.alpha, (b"0", b"0"))
+    big, small = (1 << 17) + 333, 32768
+    a_hyb, a_quad = {5: (b"5", b"5"), 17: (b"0", b"17")}.get(cfg.alpha, (b"0", b"0"))
     for op in (_lib.OP_PERMUTE, _lib.OP_HASH, _lib.OP_COMPRESS, _lib.OP_ABSORB, _lib.OP_SQUEEZE):
-        hi, lo = _engine_info(cfg, op, big, 4), _engine_info(cfg, op, small, 4)
-        assert hi.engine.startswith(b"HybridEngine<3," + a_hyb + b",mfma,windows of 3>") and hi.mfma_dense == 1 and hi.partial_window == 3, hi.engine
-        assert lo.engine.startswith(b"RegEngine<3," + a_reg) and lo.mfma_dense == 0 and lo.partial_window == 0, lo.engine
-        assert (b"passes" in hi.engine) == (op in (_lib.OP_ABSORB, _lib.OP_SQUEEZE))
+        lo = _engine_info(cfg, op, small, 4)
+        assert lo.engine.startswith(b"QuadEngine<" + a_quad) and lo.mfma_dense == 0 and lo.partial_window == 0, lo.engine
+        for n in (small + 1, big):
+            hi = _engine_info(cfg, op, n, 4)
+            assert hi.engine.startswith(b"HybridEngine<3," + a_hyb + b",mfma,windows of 3>") and hi.mfma_dense == 1 and hi.partial_window == 3, hi.engine
+            assert (b"passes" in hi.engine) == (op in (_lib.OP_ABSORB, _lib.OP_SQUEEZE))
     rng = np.random.default_rng(33)
     state0 = synth.random_elements(f, big * t, seed=91).reshape(big, t, 4)
     tag0 = rng.integers(0, 2, big).astype(np.uint32)

@@ -1,0 +1,4 @@
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; cp sponge_amd/libposeidon_mi355x.so /tmp/orig.so
+for round in 1 2; do for v in head t3min15; do cp tools/ab/libposeidon_$v.so sponge_amd/libposeidon_mi355x.so; echo "== $v round $round"
+for n in 33000 40000 49152 60000 65535; do for w in c2 h3; do python bench.py --workload $w --total-units $n --steps 50 --warmup 5 --no-cpu-baseline --no-verify 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$w $n: %.4e'%d['value'], '%.4f ms'%d['ms_per_step'], d['engine']['name'])"; done; done; done; done
+cp /tmp/orig.so sponge_amd/libposeidon_mi355x.so
