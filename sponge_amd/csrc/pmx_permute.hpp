@@ -301,9 +301,9 @@ PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, con
 // here together, and `tile` is its shared LDS tile.
 // MFMA_WINDOW = K > 0 (with MFMA_THREADS > 0): the partial rounds run as windows of K (pmx_mfma.hpp) - the layer after the entrance
 // round is the windows' entry layer on the matrix cores, and the sparse layers are not in the kernel at all.
-template <int T, int ALPHA, class Scratch, int MFMA_THREADS = 0, int MFMA_TILE_STEPS = 0, int MFMA_WINDOW = 0>
 // lane0_zero (window engines): the caller knows that s[0] is zero on entry - the capacity lane of a fresh sponge - so the S-box of that
 // lane in round 0 is a constant of the config, stored behind the window tables: one S-box of 55 fewer per 2-to-1 compression at t = 3.
+template <int T, int ALPHA, class Scratch, int MFMA_THREADS = 0, int MFMA_TILE_STEPS = 0, int MFMA_WINDOW = 0>
 PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
                            const FieldRt &f, uint32_t want_lo = 0, uint32_t want_hi = T, void *tile = nullptr, bool lane0_zero = false) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;

@@ -67,7 +67,7 @@ struct Prepared {
 
 // One dense layer as the A operands of pmx_mfma.hpp: `rows` = t rows of t constants (ABI Montgomery residues, row-major).
 // Row i, k-step q, lane l: 16 bytes = bytes e = l & 31 of the residues  Y = c_ij * 2^(8 b + 24) mod p  for the 16 positions
-// k = 32 q + 16 (l >> 5) + 0..15 of the state's byte string (k = 36 j + b), as balanced signed bytes; then per row the eight
+// k = 32 q + 16 (l >> 5) + 0..15 of the state's byte string (k = 32 j + b), as balanced signed bytes; then per row the eight
 // word sums of 128 * sum_k Y_k (the state's bytes enter as u - 128).
 // General form: n_out rows of n_in constants; aff (may be null): one constant per row added to the row's value.
 // (the table carries the 2^24 the row's finish divides by - element or operand form, the Montgomery step is the same: pmx_mfma.hpp, mfma_row_acc)
