@@ -72,6 +72,9 @@ PMX_FN constexpr int mfma_window_hist(int k) { return (k - 1) * (k - 2) / 2; }  
 #define PMX_MFMA_HIST_TAB_MAX_T 3
 #endif
 PMX_FN constexpr bool mfma_hist_tab(int t) { return t <= PMX_MFMA_HIST_TAB_MAX_T; }
+// first word of a window's history table when its single constant is a small integer (second word) and there is no table: the host
+// picks the window's free scale for that where it can (pmx_prepare.hpp: derive_window_layers; a table's first word is a 29-bit limb)
+constexpr uint32_t kMfmaHistSmallMarker = 0xffffffffu;
 // ROWS ON THE MATRIX CORES (round 5): the history term is itself a product by constants of values that are cut into bytes for the window's
 // layer anyway - one row of k inputs (z_1 .. z_{k-1}, u_k), its A operand read straight from global memory a whole S-box ahead (k KiB per
 // wave: no tile, no barrier), its 2 k products issued right behind S-box k.  One row finish + 2 k products instead of the

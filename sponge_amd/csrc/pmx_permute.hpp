@@ -370,17 +370,31 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                         constexpr int k = decltype(kk)::value;                        // z_{k+1} from x_{k+1} = z_k + u_k + sum_{i<k} h_{k,i} z_i
                         if ((uint32_t)k < kw) {
                             Fe x = s[k];
+                            bool small_sum = false;                    // (wave-uniform)
                             if constexpr (k == 2) {                    // one constant: the compact single-constant table
-                                PMX_SCHED_FENCE();
-                                tab_lanes_stream<1>(in[T - 1], hist, &x, f);
-                                PMX_SCHED_FENCE();
+                                // ... or no product at all: where the host found a scale of the window under which the constant is 1 .. 4
+                                // (pmx_prepare.hpp: the window's free scale) the term is that many lazy additions, normalised with the rest
+                                const uint32_t small = hist[0] == kMfmaHistSmallMarker ? hist[1] : 0u;
+                                if (small) {
+                                    small_sum = true;
+                                    x = fe_add_lazy(x, in[T - 1]);
+                                    if (small >= 2) x = fe_add_lazy(x, in[T - 1]);
+                                    if (small >= 3) x = fe_add_lazy(x, in[T - 1]);
+                                    if (small >= 4) x = fe_add_lazy(x, in[T - 1]);     // limbs < 5 * 2^29; with z_k below: < 2^32 - 8 (fe_normalize)
+                                } else {
+                                    PMX_SCHED_FENCE();
+                                    tab_lanes_stream<1>(in[T - 1], hist, &x, f);
+                                    PMX_SCHED_FENCE();
+                                }
                             } else if constexpr (k >= 3) {
                                 const Fe x0 = x;
                                 PMX_SCHED_FENCE();
                                 x = tab_dot_stream<k - 1, true>(&in[T - 1], hist + mfma_hist_tab_offset(k), f, &x0);
                                 PMX_SCHED_FENCE();
                             }
-                            in[T - 1 + k] = fe_sbox<ALPHA>(fe_add_lazy(x, in[T - 2 + k]), c.alpha, one, f);
+                            x = fe_add_lazy(x, in[T - 2 + k]);
+                            if (small_sum) x = fe_normalize(x);        // (below 7.6 p: (7.6 p)^2 < p 2^261 for every p < 2^255)
+                            in[T - 1 + k] = fe_sbox<ALPHA>(x, c.alpha, one, f);
                         } else {
                             in[T - 1 + k] = fe_zero();
                         }

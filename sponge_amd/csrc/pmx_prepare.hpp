@@ -350,6 +350,7 @@ struct WindowPlan {
     std::vector<U256> entry_rows, entry_aff;                 // t x t, t
     std::vector<std::vector<U256>> rows, aff;                // per window: t x (t - 1 + K), t
     std::vector<U256> hist;                                  // per window mfma_window_hist(K) constants
+    std::vector<uint32_t> hist_small;                        // per window: h_{2,1} as a small integer (1 .. 4), or 0 (derive_window_layers: the window's free scale)
 };
 
 inline size_t mat_rank(const HostField &f, HostMat a) {
@@ -371,6 +372,97 @@ inline size_t mat_rank(const HostField &f, HostMat a) {
     return rank;
 }
 
+// ---- a window's free scale ------------------------------------------------------------------------------------------
+// x^_1 of a window may be carried scaled by any lambda (the layer in front multiplies row 0 by it): with alpha = 5 the single history
+// constant of a window of three S-boxes becomes h lambda^20, and where s / h has a 20th root for a small integer s the product h z^_1
+// - 81 + 18 multiplies from a shifted table - is s lazy additions (pmx_permute.hpp).  20 = 5 * 4 and gcd(5, p - 1) = 1 for a config
+// whose S-box is a permutation: a fifth root always exists, a fourth root for one value in four.
+inline U256 host_pow_u256(const HostField &f, const U256 &x, const U256 &e) {
+    U256 acc = f.r;
+    for (int bit = 255; bit >= 0; --bit) {
+        acc = f.mul(acc, acc);
+        if ((e.l[bit / 64] >> (bit % 64)) & 1) acc = f.mul(acc, x);
+    }
+    return acc;
+}
+inline uint64_t u256_divmod_small(U256 &q, const U256 &a, uint64_t d) {   // q = a / d, returns a % d
+    u128 rem = 0;
+    for (int i = 3; i >= 0; --i) {
+        const u128 cur = (rem << 64) | a.l[i];
+        q.l[i] = (uint64_t)(cur / d);
+        rem = cur % d;
+    }
+    return (uint64_t)rem;
+}
+inline U256 u256_shr(const U256 &a, unsigned k) {   // k < 64
+    U256 r;
+    for (int i = 0; i < 4; ++i) r.l[i] = k ? ((a.l[i] >> k) | (i + 1 < 4 ? a.l[i + 1] << (64 - k) : 0)) : a.l[i];
+    return r;
+}
+inline bool u256_eq(const U256 &a, const U256 &b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+// square root in the Montgomery domain (Tonelli-Shanks); false: a is not a square
+inline bool host_sqrt(const HostField &f, const U256 &a, U256 &root) {
+    if (u256_is_zero(a)) { root = a; return true; }
+    U256 pm1 = f.p;
+    pm1.l[0] -= 1;                                   // p odd: no borrow
+    unsigned S = 0;
+    U256 q = pm1;
+    while (!(q.l[0] & 1)) {
+        q = u256_shr(q, 1);
+        ++S;
+    }
+    const U256 half = u256_shr(pm1, 1), minus_one = f.neg(f.r);
+    if (!u256_eq(host_pow_u256(f, a, half), f.r)) return false;
+    U256 z = f.r;                                    // a non-residue: 2, 3, 4 ... in the Montgomery domain
+    for (int tries = 0; tries < 200; ++tries) {
+        z = f.add(z, f.r);
+        if (u256_eq(host_pow_u256(f, z, half), minus_one)) break;
+        if (tries == 199) return false;
+    }
+    U256 qp1 = q;                                    // (q + 1) / 2
+    qp1.l[0] += 1;                                   // q odd: q + 1 even; no carry unless q = 2^64k - 1 (not for a 225 .. 255-bit p - 1 with S >= 1)
+    qp1 = u256_shr(qp1, 1);
+    U256 c = host_pow_u256(f, z, q), r = host_pow_u256(f, a, qp1), tt = host_pow_u256(f, a, q);
+    unsigned m = S;
+    while (!u256_eq(tt, f.r)) {
+        unsigned i = 0;
+        U256 t2 = tt;
+        while (!u256_eq(t2, f.r)) {
+            t2 = f.mul(t2, t2);
+            if (++i == m) return false;
+        }
+        U256 b = c;
+        for (unsigned k = 0; k + i + 1 < m; ++k) b = f.mul(b, b);
+        r = f.mul(r, b);
+        c = f.mul(b, b);
+        tt = f.mul(tt, c);
+        m = i;
+    }
+    root = r;
+    return true;
+}
+// lambda with lambda^20 = y (alpha = 5: 20 = alpha^2 - alpha), or false
+inline bool host_root20(const HostField &f, const U256 &y, U256 &lambda) {
+    U256 pm1 = f.p, Q;
+    pm1.l[0] -= 1;
+    const uint64_t R = u256_divmod_small(Q, pm1, 5);
+    if (R == 0) return false;                        // 5 | p - 1: x^5 is no permutation of this field
+    uint64_t k = 1;
+    while ((1 + k * R) % 5) ++k;                     // d = (1 + k (p - 1)) / 5 = k Q + (1 + k R) / 5: the inverse of 5 modulo p - 1
+    U256 d = {{0, 0, 0, 0}};
+    for (uint64_t i = 0; i < k; ++i) u256_add(d, d, Q);
+    const U256 small = {{(1 + k * R) / 5, 0, 0, 0}};
+    u256_add(d, d, small);
+    const U256 u = host_pow_u256(f, y, d);           // u^5 = y
+    U256 r1;
+    if (!host_sqrt(f, u, r1)) return false;
+    U256 r2;
+    if (!host_sqrt(f, r1, r2) && !host_sqrt(f, f.neg(r1), r2)) return false;
+    lambda = r2;
+    U256 chk = host_pow(f, lambda, 20);
+    return u256_eq(chk, y);
+}
+
 inline bool derive_window_layers(const HostField &f, uint32_t t, uint32_t half, uint32_t rp, uint64_t alpha, uint32_t K,
                                  const std::vector<U256> &ark, const HostMat &M, const std::vector<U256> &entrance_scale,
                                  const std::vector<U256> &exit_scale, const U256 *arkopt_exit, WindowPlan &plan) {
@@ -385,6 +477,8 @@ inline bool derive_window_layers(const HostField &f, uint32_t t, uint32_t half, 
     plan.rows.resize(n_win);
     plan.aff.resize(n_win);
     plan.hist.assign(n_win * (size_t)mfma_window_hist((int)K), zero);
+    plan.hist_small.assign(n_win, 0u);
+    std::vector<U256> lane0(n_win, f.r);                     // delta_1 of each window: x^_1 = lane0 x_1 (1 unless a better one exists, below)
     // what the layer BEFORE window w has to produce, from the true state at the window's start: x^_1 = s_0 + c, u^ = Psi s_1.. + psi
     std::vector<HostMat> Psi(n_win), PsiInv(n_win);
     std::vector<std::vector<U256>> psi(n_win);
@@ -410,24 +504,51 @@ inline bool derive_window_layers(const HostField &f, uint32_t t, uint32_t half, 
             }
         }
         Send[w] = S;
-        std::vector<U256> delta(kw + 1, f.r), dpow(kw + 1, f.r);   // delta_j, delta_j^alpha (delta_1 = 1)
-        zscale[w].assign(K, zero);
-        zscale[w][0] = f.r;
-        Psi[w].assign(n, std::vector<U256>(n, zero));
-        psi[w].assign(n, zero);
-        for (uint32_t j = 2; j <= kw; ++j) {
-            const U256 a = X[j][n + j - 2];                  // coefficient of z_{j-1} in x_j
-            if (u256_is_zero(a)) return false;
-            delta[j] = f.mul(dpow[j - 1], f.inverse(a));
-            dpow[j] = host_pow(f, delta[j], alpha);
-            if (u256_is_zero(dpow[j])) return false;
-            zscale[w][j - 1] = f.inverse(dpow[j]);
-            const size_t k = j - 1;                          // x_{k+1}: coordinate u^_k, history h_{k,i}
-            for (size_t g = 0; g < n; ++g) Psi[w][k - 1][g] = f.mul(delta[j], X[j][g]);
-            psi[w][k - 1] = f.mul(delta[j], X[j][G]);
-            for (size_t i = 1; i < k; ++i)
-                plan.hist[w * (size_t)mfma_window_hist((int)K) + (size_t)mfma_window_hist((int)k) + (i - 1)] =
-                    f.mul(f.mul(delta[j], X[j][n + i - 1]), zscale[w][i - 1]);
+        // the scales of the S-box inputs, x^_j = delta_j x_j, for a given delta_1 (the window's free scale: lane0[w])
+        auto scales = [&](const U256 &delta1) -> bool {
+            std::vector<U256> delta(kw + 1, f.r), dpow(kw + 1, f.r);   // delta_j, delta_j^alpha
+            delta[1] = delta1;
+            dpow[1] = host_pow(f, delta1, alpha);
+            if (u256_is_zero(dpow[1])) return false;
+            zscale[w].assign(K, zero);
+            zscale[w][0] = f.inverse(dpow[1]);
+            Psi[w].assign(n, std::vector<U256>(n, zero));
+            psi[w].assign(n, zero);
+            for (uint32_t j = 2; j <= kw; ++j) {
+                const U256 a = X[j][n + j - 2];                  // coefficient of z_{j-1} in x_j
+                if (u256_is_zero(a)) return false;
+                delta[j] = f.mul(dpow[j - 1], f.inverse(a));
+                dpow[j] = host_pow(f, delta[j], alpha);
+                if (u256_is_zero(dpow[j])) return false;
+                zscale[w][j - 1] = f.inverse(dpow[j]);
+                const size_t k = j - 1;                          // x_{k+1}: coordinate u^_k, history h_{k,i}
+                for (size_t g = 0; g < n; ++g) Psi[w][k - 1][g] = f.mul(delta[j], X[j][g]);
+                psi[w][k - 1] = f.mul(delta[j], X[j][G]);
+                for (size_t i = 1; i < k; ++i)
+                    plan.hist[w * (size_t)mfma_window_hist((int)K) + (size_t)mfma_window_hist((int)k) + (i - 1)] =
+                        f.mul(f.mul(delta[j], X[j][n + i - 1]), zscale[w][i - 1]);
+            }
+            return true;
+        };
+        lane0[w] = f.r;
+        if (!scales(f.r)) return false;
+        // a window of three S-boxes whose history term is a table product (t = 3): delta_1 with h_{2,1} = 1 .. 4 where one exists
+        if (alpha == 5 && K == 3 && kw == 3 && mfma_hist_tab((int)t)) {
+            const U256 h1 = plan.hist[w * (size_t)mfma_window_hist((int)K)];
+            if (!u256_is_zero(h1)) {
+                const U256 h1_inv = f.inverse(h1);
+                U256 small = zero;
+                for (uint32_t sm = 1; sm <= 4 && !plan.hist_small[w]; ++sm) {
+                    small = f.add(small, f.r);                   // sm in the Montgomery domain
+                    U256 lambda;
+                    if (host_root20(f, f.mul(small, h1_inv), lambda) && scales(lambda) &&
+                        u256_eq(plan.hist[w * (size_t)mfma_window_hist((int)K)], small)) {
+                        lane0[w] = lambda;
+                        plan.hist_small[w] = sm;
+                    }
+                }
+                if (!plan.hist_small[w] && !scales(f.r)) return false;
+            }
         }
         // the other coordinates: lanes of sigma themselves, chosen so that Psi stays invertible
         size_t have = kw - 1, cand = 0;
@@ -449,8 +570,8 @@ inline bool derive_window_layers(const HostField &f, uint32_t t, uint32_t half, 
     auto emit = [&](const std::vector<Form> &P, size_t n_in, size_t w, uint32_t first_round, std::vector<U256> &rows, std::vector<U256> &aff) {
         rows.assign((size_t)t * n_in, zero);
         aff.assign(t, zero);
-        for (size_t g = 0; g < n_in; ++g) rows[g] = P[0][g];
-        aff[0] = f.add(P[0][n_in], ark[(size_t)first_round * t]);
+        for (size_t g = 0; g < n_in; ++g) rows[g] = f.mul(lane0[w], P[0][g]);
+        aff[0] = f.mul(lane0[w], f.add(P[0][n_in], ark[(size_t)first_round * t]));
         for (size_t k = 0; k < n; ++k) {
             for (size_t g = 0; g <= n_in; ++g) {
                 U256 acc = zero;
@@ -661,8 +782,14 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
                 put_mfma_layer_io(hf, plan.rows[w].data(), t - 1 + K, t, plan.aff[w].data(), dst);
                 dst += lw_in;
                 if (mfma_hist_tab((int)t)) {
-                    for (uint32_t k = 2; k < K; ++k)
+                    for (uint32_t k = 2; k < K; ++k) {
+                        if (k == 2 && plan.hist_small[w]) {   // h_{2,1} = 1 .. 4: no table - a marker no limb can be, and the integer (pmx_permute.hpp)
+                            dst[mfma_hist_tab_offset(2)] = kMfmaHistSmallMarker;
+                            dst[mfma_hist_tab_offset(2) + 1] = plan.hist_small[w];
+                            continue;
+                        }
                         put_shifted_row(hf, &plan.hist[w * nh + (size_t)mfma_window_hist((int)k)], k - 1, dst + mfma_hist_tab_offset((int)k));
+                    }
                 } else {   // the history terms as matrix-core rows: the row of x_{k+1} over (z_1 .. z_{k-1}, u_k), coefficients (h_{k,.}, ONE)
                     for (uint32_t k = 2; k < K; ++k) {
                         std::vector<U256> row(&plan.hist[w * nh + (size_t)mfma_window_hist((int)k)], &plan.hist[w * nh + (size_t)mfma_window_hist((int)k)] + (k - 1));

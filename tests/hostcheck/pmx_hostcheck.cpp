@@ -204,6 +204,25 @@ extern "C" int hc_permute_hybrid_mfma(const pmx_config *cfg, uint64_t *states, s
         default: return PMX_ERR_UNSUPPORTED;
     }
 }
+// how many windows of a t = 3 config carry their history constant as a small integer (pmx_prepare.hpp: the window's free scale);
+// out[0] = windows with a history term, out[1 .. 4] = those with the constant 1 .. 4
+extern "C" int hc_window_small_history(const pmx_config *cfg, uint32_t out[5]) {
+    Prepared pp;
+    std::string err;
+    int rc = prepare(cfg, pp, err);
+    if (rc) return rc;
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    if (!pp.mfma_dense || pp.t != 3 || pp.mfma_window != 3) return PMX_ERR_UNSUPPORTED;
+    const size_t kLayer = (size_t)mfma_layer_words_io(3 - 1 + 3, 3), kPer = kLayer + (size_t)mfma_window_hist_words(3, 3);
+    const uint32_t n_win = (pp.c.partial_rounds + 2) / 3, first = pp.c.partial_rounds - (n_win - 1) * 3;
+    for (uint32_t w = 0; w < n_win; ++w) {
+        if ((w == 0 ? first : 3u) < 3) continue;
+        out[0] += 1;
+        const uint32_t *hist = pp.consts.data() + pp.win_offset + mfma_layer_words(3) + (size_t)w * kPer + kLayer;
+        if (hist[0] == kMfmaHistSmallMarker && hist[1] >= 1 && hist[1] <= 4) out[hist[1]] += 1;
+    }
+    return PMX_OK;
+}
 // the window size this library was compiled with (tests build one library per size)
 extern "C" int hc_mfma_window(int t) { return mfma_window_for(t); }
 

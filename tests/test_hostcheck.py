@@ -440,6 +440,35 @@ def test_a_zero_capacity_lane_skips_its_first_sbox(hc, t, alpha):
     assert cref.limbs_to_elems(out, p) == want
 
 
+@pytest.mark.parametrize("p,bits,rf,rp,alpha,want", [(O.BLS12_381_FR, 255, 8, 31, 5, [10, 10, 0, 0, 0]), (O.BN254_FR, 254, 8, 57, 5, [19, 0, 19, 0, 0]),
+                                                     (O.BLS12_381_FR, 255, 8, 57, 5, [19, 0, 0, 0, 0]), (O.BLS12_381_FR, 255, 8, 31, 17, [10, 0, 0, 0, 0])])
+def test_a_windows_free_scale_turns_its_history_constant_into_a_small_integer(hc, p, bits, rf, rp, alpha, want):
+    """pmx_prepare.hpp (derive_window_layers): x^_1 of a window may be carried scaled by any lambda; with alpha = 5 the one history
+    constant of a t = 3 window becomes h lambda^20, and where s / h has a 20th root for s in 1 .. 4 the kernel adds z^_1 s times instead of
+    multiplying by a table (pmx_permute.hpp).  The constant depends on the MDS matrix only, so a config's windows all get the same s or
+    none: BASELINE's C2 config gets 1, BN254 t = 3 (8, 57) gets 2, BLS (8, 57) and any alpha != 5 keep the table.  The permutation
+    itself is checked against the oracle for these configs by test_partial_rounds_as_windows_every_size_and_width and below."""
+    hc.hc_window_small_history.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p]
+    hc.hc_permute_hybrid_mfma.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
+    cfg = O.make_config(p, bits, 2, alpha, rf, rp)
+    ark = cref.elems_to_limbs([v for row in cfg.ark for v in row], p)
+    mds = cref.elems_to_limbs([v for row in cfg.mds for v in row], p)
+    c = PmxConfig()
+    c.full_rounds, c.partial_rounds, c.alpha, c.rate, c.capacity = rf, rp, alpha, 2, 1
+    for i, l in enumerate(O.to_limbs(p)):
+        c.modulus[i] = l
+    c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
+    out = np.zeros(5, dtype=np.uint32)
+    assert hc.hc_window_small_history(ctypes.byref(c), out.ctypes.data) == 0
+    assert out.tolist() == want
+    rng = random.Random(rp + alpha)
+    states = [[rng.randrange(p) for _ in range(3)] for _ in range(6)] + [[p - 1] * 3, [0] * 3]
+    want_states = [x for st in states for x in O.permute(cfg, st)]
+    limbs = cref.elems_to_limbs([x for st in states for x in st], p).reshape(len(states), 3, 4)
+    assert hc.hc_permute_hybrid_mfma(ctypes.byref(c), limbs.ctypes.data, len(states)) == 0
+    assert cref.limbs_to_elems(limbs, p) == want_states
+
+
 @pytest.mark.parametrize("K", [9, 1, 4, 6])
 def test_partial_rounds_as_windows_every_size_and_width(K):
     """pmx_mfma.hpp / pmx_prepare.hpp (derive_window_layers): the matrix-core engines of t = 3..9 run their partial rounds as windows
