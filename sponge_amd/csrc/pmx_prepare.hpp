@@ -373,10 +373,10 @@ inline size_t mat_rank(const HostField &f, HostMat a) {
 }
 
 // ---- a window's free scale ------------------------------------------------------------------------------------------
-// x^_1 of a window may be carried scaled by any lambda (the layer in front multiplies row 0 by it): with alpha = 5 the single history
-// constant of a window of three S-boxes becomes h lambda^20, and where s / h has a 20th root for a small integer s the product h z^_1
-// - 81 + 18 multiplies from a shifted table - is s lazy additions (pmx_permute.hpp).  20 = 5 * 4 and gcd(5, p - 1) = 1 for a config
-// whose S-box is a permutation: a fifth root always exists, a fourth root for one value in four.
+// x^_1 of a window may be carried scaled by any lambda (the layer in front multiplies row 0 by it): the single history constant of a
+// window of three S-boxes becomes h lambda^(alpha^2 - alpha), and where s / h has such a root for a small integer s the product h z^_1
+// - 81 + 18 multiplies from a shifted table - is s lazy additions (pmx_permute.hpp).  alpha = 5: 20 = 5 * 4 and gcd(5, p - 1) = 1 for
+// a config whose S-box is a permutation - a fifth root always exists, a fourth root for one value in four; alpha = 17: one in sixteen.
 inline U256 host_pow_u256(const HostField &f, const U256 &x, const U256 &e) {
     U256 acc = f.r;
     for (int bit = 255; bit >= 0; --bit) {
@@ -441,25 +441,65 @@ inline bool host_sqrt(const HostField &f, const U256 &a, U256 &root) {
     root = r;
     return true;
 }
-// lambda with lambda^20 = y (alpha = 5: 20 = alpha^2 - alpha), or false
-inline bool host_root20(const HostField &f, const U256 &y, U256 &lambda) {
+// x^(1/e) for a 64-bit e prime to p - 1 (the map is a bijection): x^d with d = e^-1 mod (p - 1) = (1 + k (p - 1)) / e
+inline bool host_root_coprime(const HostField &f, const U256 &x, uint64_t e, U256 &root) {
+    if (e == 1) { root = x; return true; }
     U256 pm1 = f.p, Q;
     pm1.l[0] -= 1;
-    const uint64_t R = u256_divmod_small(Q, pm1, 5);
-    if (R == 0) return false;                        // 5 | p - 1: x^5 is no permutation of this field
-    uint64_t k = 1;
-    while ((1 + k * R) % 5) ++k;                     // d = (1 + k (p - 1)) / 5 = k Q + (1 + k R) / 5: the inverse of 5 modulo p - 1
-    U256 d = {{0, 0, 0, 0}};
-    for (uint64_t i = 0; i < k; ++i) u256_add(d, d, Q);
-    const U256 small = {{(1 + k * R) / 5, 0, 0, 0}};
-    u256_add(d, d, small);
-    const U256 u = host_pow_u256(f, y, d);           // u^5 = y
-    U256 r1;
-    if (!host_sqrt(f, u, r1)) return false;
-    U256 r2;
-    if (!host_sqrt(f, r1, r2) && !host_sqrt(f, f.neg(r1), r2)) return false;
-    lambda = r2;
-    U256 chk = host_pow(f, lambda, 20);
+    const uint64_t R = u256_divmod_small(Q, pm1, e);
+    // k = -R^-1 mod e (extended Euclid on 64-bit values; no inverse: e shares a factor with p - 1)
+    __int128 r0 = (__int128)e, r1 = (__int128)R, t0 = 0, t1 = 1;
+    while (r1 != 0) {
+        const __int128 q = r0 / r1, r2 = r0 - q * r1, t2 = t0 - q * t1;
+        r0 = r1; r1 = r2; t0 = t1; t1 = t2;
+    }
+    if (r0 != 1) return false;
+    __int128 inv = t0 % (__int128)e;
+    if (inv < 0) inv += (__int128)e;
+    const uint64_t k = (uint64_t)(((__int128)e - inv) % (__int128)e);      // k R = -1 (mod e)
+    U256 d = {{0, 0, 0, 0}};                                               // d = k Q + (1 + k R) / e   (k Q < p - 1: no overflow)
+    u128 carry = 0;
+    for (int i = 0; i < 4; ++i) {
+        const u128 v = (u128)Q.l[i] * k + carry;
+        d.l[i] = (uint64_t)v;
+        carry = v >> 64;
+    }
+    const u128 rest = ((u128)k * R + 1) / e;
+    const U256 add = {{(uint64_t)rest, (uint64_t)(rest >> 64), 0, 0}};
+    u256_add(d, d, add);
+    root = host_pow_u256(f, x, d);
+    return true;
+}
+// is x a 2^a-th power?  (the 2-part of p - 1 is 2^S: x^((p - 1) / 2^min(a, S)) = 1)
+inline bool host_is_2power_residue(const HostField &f, const U256 &x, unsigned a) {
+    if (a == 0 || u256_is_zero(x)) return true;
+    U256 e = f.p;
+    e.l[0] -= 1;
+    for (unsigned i = 0; i < a && !(e.l[0] & 1); ++i) e = u256_shr(e, 1);
+    return u256_eq(host_pow_u256(f, x, e), f.r);
+}
+// lambda with lambda^(alpha (alpha - 1)) = y, or false: the alpha-th root and the odd part of alpha - 1 by inverting the exponent, the
+// power of two in alpha - 1 by square roots (alpha = 5: 20 = 5 * 4, alpha = 17: 272 = 17 * 16, alpha = 257: 257 * 256)
+inline bool host_root_window_scale(const HostField &f, const U256 &y, uint64_t alpha, U256 &lambda) {
+    if (alpha < 2 || alpha > ((uint64_t)1 << 32)) return false;
+    uint64_t m = alpha - 1;
+    unsigned a = 0;
+    while (!(m & 1)) {
+        m >>= 1;
+        ++a;
+    }
+    U256 u;
+    if (!host_root_coprime(f, y, alpha, u) || !host_root_coprime(f, u, m, u)) return false;
+    if (!host_is_2power_residue(f, u, a)) return false;
+    for (unsigned left = a; left > 0; --left) {            // of the two square roots the one that is still a 2^(left-1)-th power
+        U256 r;
+        if (!host_sqrt(f, u, r)) return false;
+        if (!host_is_2power_residue(f, r, left - 1)) r = f.neg(r);
+        if (!host_is_2power_residue(f, r, left - 1)) return false;
+        u = r;
+    }
+    lambda = u;
+    U256 chk = host_pow(f, host_pow(f, lambda, alpha), alpha - 1);
     return u256_eq(chk, y);
 }
 
@@ -478,6 +518,9 @@ inline bool derive_window_layers(const HostField &f, uint32_t t, uint32_t half, 
     plan.aff.resize(n_win);
     plan.hist.assign(n_win * (size_t)mfma_window_hist((int)K), zero);
     plan.hist_small.assign(n_win, 0u);
+    bool memo_valid = false;                                 // the last history constant searched for a small multiple, and what was found
+    U256 memo_h1 = zero, memo_lambda = zero;
+    uint32_t memo_small = 0;
     std::vector<U256> lane0(n_win, f.r);                     // delta_1 of each window: x^_1 = lane0 x_1 (1 unless a better one exists, below)
     // what the layer BEFORE window w has to produce, from the true state at the window's start: x^_1 = s_0 + c, u^ = Psi s_1.. + psi
     std::vector<HostMat> Psi(n_win), PsiInv(n_win);
@@ -533,21 +576,30 @@ inline bool derive_window_layers(const HostField &f, uint32_t t, uint32_t half, 
         lane0[w] = f.r;
         if (!scales(f.r)) return false;
         // a window of three S-boxes whose history term is a table product (t = 3): delta_1 with h_{2,1} = 1 .. 4 where one exists
-        if (alpha == 5 && K == 3 && kw == 3 && mfma_hist_tab((int)t)) {
+        if (alpha >= 2 && K == 3 && kw == 3 && mfma_hist_tab((int)t)) {
             const U256 h1 = plan.hist[w * (size_t)mfma_window_hist((int)K)];
             if (!u256_is_zero(h1)) {
-                const U256 h1_inv = f.inverse(h1);
-                U256 small = zero;
-                for (uint32_t sm = 1; sm <= 4 && !plan.hist_small[w]; ++sm) {
-                    small = f.add(small, f.r);                   // sm in the Montgomery domain
-                    U256 lambda;
-                    if (host_root20(f, f.mul(small, h1_inv), lambda) && scales(lambda) &&
-                        u256_eq(plan.hist[w * (size_t)mfma_window_hist((int)K)], small)) {
-                        lane0[w] = lambda;
-                        plan.hist_small[w] = sm;
+                if (!memo_valid || !u256_eq(memo_h1, h1)) {      // (the constant depends on M and alpha only: one search per config)
+                    memo_valid = true;
+                    memo_h1 = h1;
+                    memo_small = 0;
+                    const U256 h1_inv = f.inverse(h1);
+                    U256 small = zero;
+                    for (uint32_t sm = 1; sm <= 4 && !memo_small; ++sm) {
+                        small = f.add(small, f.r);               // sm in the Montgomery domain
+                        if (host_root_window_scale(f, f.mul(small, h1_inv), alpha, memo_lambda)) memo_small = sm;
                     }
                 }
-                if (!plan.hist_small[w] && !scales(f.r)) return false;
+                if (memo_small) {
+                    U256 small = zero;
+                    for (uint32_t i = 0; i < memo_small; ++i) small = f.add(small, f.r);
+                    if (scales(memo_lambda) && u256_eq(plan.hist[w * (size_t)mfma_window_hist((int)K)], small)) {
+                        lane0[w] = memo_lambda;
+                        plan.hist_small[w] = memo_small;
+                    } else if (!scales(f.r)) {
+                        return false;
+                    }
+                }
             }
         }
         // the other coordinates: lanes of sigma themselves, chosen so that Psi stays invertible

@@ -441,13 +441,14 @@ def test_a_zero_capacity_lane_skips_its_first_sbox(hc, t, alpha):
 
 
 @pytest.mark.parametrize("p,bits,rf,rp,alpha,want", [(O.BLS12_381_FR, 255, 8, 31, 5, [10, 10, 0, 0, 0]), (O.BN254_FR, 254, 8, 57, 5, [19, 0, 19, 0, 0]),
-                                                     (O.BLS12_381_FR, 255, 8, 57, 5, [19, 0, 0, 0, 0]), (O.BLS12_381_FR, 255, 8, 31, 17, [10, 0, 0, 0, 0])])
+                                                     (O.BLS12_381_FR, 255, 8, 57, 5, [19, 0, 0, 0, 0]), (O.BLS12_381_FR, 255, 8, 31, 17, [10, 0, 0, 0, 0]),
+                                                     (O.BN254_FR, 254, 8, 31, 17, [10, 10, 0, 0, 0]), (O.BLS12_381_FR, 255, 8, 13, 257, [4, 0, 0, 0, 0])])
 def test_a_windows_free_scale_turns_its_history_constant_into_a_small_integer(hc, p, bits, rf, rp, alpha, want):
-    """pmx_prepare.hpp (derive_window_layers): x^_1 of a window may be carried scaled by any lambda; with alpha = 5 the one history
-    constant of a t = 3 window becomes h lambda^20, and where s / h has a 20th root for s in 1 .. 4 the kernel adds z^_1 s times instead of
-    multiplying by a table (pmx_permute.hpp).  The constant depends on the MDS matrix only, so a config's windows all get the same s or
-    none: BASELINE's C2 config gets 1, BN254 t = 3 (8, 57) gets 2, BLS (8, 57) and any alpha != 5 keep the table.  The permutation
-    itself is checked against the oracle for these configs by test_partial_rounds_as_windows_every_size_and_width and below."""
+    """pmx_prepare.hpp (derive_window_layers): x^_1 of a window may be carried scaled by any lambda; the one history constant of a t = 3
+    window becomes h lambda^(alpha^2 - alpha), and where s / h has such a root for s in 1 .. 4 the kernel adds z^_1 s times instead of
+    multiplying by a table (pmx_permute.hpp).  The constant depends on the MDS matrix and the exponent only, so a config's windows all
+    get the same s or none: BASELINE's C2 config gets 1, BN254 t = 3 (8, 57) gets 2, BN254 with alpha = 17 gets 1; BLS (8, 57), the
+    reference's own alpha = 17 and 257 defaults have no such root and keep the table.  The permutation itself against the oracle below."""
     hc.hc_window_small_history.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p]
     hc.hc_permute_hybrid_mfma.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     cfg = O.make_config(p, bits, 2, alpha, rf, rp)
