@@ -18,6 +18,7 @@ for TAG in "$@"; do
   [ -f $S/traffic.log ] && strip $S/traffic.log $D/${P}_hbm_traffic.txt
   if [ -d $S/group_rehearsal ]; then rm -rf $D/${P}_group_rehearsal; mkdir -p $D/${P}_group_rehearsal; cp $S/group_rehearsal/*.json $S/group_rehearsal/*.txt $D/${P}_group_rehearsal/ 2>/dev/null || true; [ -f $S/group_rehearsal.txt ] && strip $S/group_rehearsal.txt $D/${P}_group_rehearsal/summary.txt; fi
 done
+# (profiles/r05/<prefix>_pmc_fetch_smem_lds_levels_c3_c2.txt is made by hand from tools/pmc_fetch_levels.sh: see profiles/r05/README.md)
 # the counter JSONs bench.py quotes: say where they were taken
 python3 - "$P" <<PY
 import json, sys
