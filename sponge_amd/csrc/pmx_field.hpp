@@ -560,7 +560,8 @@ PMX_FN Fe cols_redc(Cols &t, const FieldRt &f, const Fe *s = nullptr) {
 
 // x^alpha on the internal form.  5 and 17 use the shortest chains; anything else is MSB-first
 // square-and-multiply seeded with x (alpha is wave-uniform, so the branches are scalar).
-// x may be lazy with B <= 4; the result is norm with B < 1.3.  `one` = 2^261 mod p.
+// x may be lazy with B <= 4, or norm with B < 7.6 (a window S-box input with a small-integer history term, pmx_permute.hpp: B^2 < 2^261 / p);
+// the result is norm with B < 1.3 (alpha >= 4; pmx_prepare.hpp: opt_schedule_lane_headroom has the smaller exponents).  `one` = 2^261 mod p.
 template <int ALPHA>
 PMX_FN Fe fe_sbox(const Fe &x, uint64_t alpha, const Fe &one, const FieldRt &f) {
     if constexpr (ALPHA == 5) {
