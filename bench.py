@@ -275,7 +275,7 @@ def main_single_process(args):
     cfg = S.poseidon_config_from_lfsr(field, rate, alpha, rf, rp)
 
     peak = _lib.PmxValuPeak()
-    _lib.check(_lib.lib().pmx_diag_int_valu_peak(devices[0], 0.1, peak))
+    _lib.check_diag(_lib.diag_lib().pmx_diag_int_valu_peak(devices[0], 0.1, peak))
     group = mgpu.DeviceGroup.single_process(cfg, devices=devices)
     info = group.info()
     rccl = {"ranks": info["comm_ranks"], "version": info["rccl_version_str"], "rank0_is": info["comm_first_rank"],
@@ -289,7 +289,7 @@ def main_single_process(args):
     early = _lib.PmxEngineInfo()
     _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, _lib.OP_COMPRESS if merkle else _lib.OP_PERMUTE, (n // 2 if merkle else n), 0, early))
     r = _lib.PmxIssueSlot()
-    _lib.check(_lib.lib().pmx_diag_issue_slot(devices[0], max(1, min(8, early.waves_per_simd)), 0.06, r))
+    _lib.check_diag(_lib.diag_lib().pmx_diag_issue_slot(devices[0], max(1, min(8, early.waves_per_simd)), 0.06, r))
     slot[max(1, min(8, early.waves_per_simd))] = r
     devs = [torch.device("cuda", d) for d in devices]
     streams = [torch.cuda.ExternalStream(group.stream(l), device=devs[l]) for l in range(world)]
@@ -513,13 +513,13 @@ def main():
 
     # ---- per-run integer-VALU roofline of THIS device, before anything is timed -----------------------------------------
     peak = _lib.PmxValuPeak()
-    _lib.check(_lib.lib().pmx_diag_int_valu_peak(local_rank, 0.1, peak))
+    _lib.check_diag(_lib.diag_lib().pmx_diag_int_valu_peak(local_rank, 0.1, peak))
     slot = {}          # waves per SIMD -> in-run issue-slot measurement (pmx_diag_issue_slot), filled for the kernel's occupancy below
 
     def issue_slot(waves):
         if waves not in slot:
             r = _lib.PmxIssueSlot()
-            _lib.check(_lib.lib().pmx_diag_issue_slot(local_rank, waves, 0.06, r))
+            _lib.check_diag(_lib.diag_lib().pmx_diag_issue_slot(local_rank, waves, 0.06, r))
             slot[waves] = r
         return slot[waves]
 
@@ -754,7 +754,7 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
                                 lane_tables=bool(info.lane_tables), mfma_dense=mfma_dense, window=int(info.partial_window))
     # the last round of a permutation whose caller reads only some lanes computes only those rows (pmx_permute.hpp:
     # want_lo / want_hi): the digest lane of a 2-to-1 compression, the out_len lanes of a hash row's last permutation
-    last_row = 9 if mfma_dense else 81 * t + (18 if info.row_tables == 1 else 81)
+    last_row = 8 if mfma_dense else 81 * t + (18 if info.row_tables == 1 else 81)   # (8: the row finish of mads_per_permutation)
     if merkle:
         mads -= (t - 1) * last_row
     elif hashing:
@@ -792,16 +792,37 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
         "int_valu": {"bound": "v_mad_u64_u32 issue", "achieved": mad_rate, "peak": peak.lane_mads_per_s,
                      "unit": "lane-instr/s", "frac": mad_rate / peak.lane_mads_per_s, "mads_per_permutation": mads,
                      "dense_layers": "v_mfma_i32_32x32x32_i8 (pmx_mfma.hpp): not counted as multiplies" if mfma_dense else "VALU",
+                     "model_note": ("an UPPER bound of the multiplies a permutation executes: pmx_ctx_engine_info does not say which t = 3 windows take their history "
+                                    "term as additions instead of a table product (all ten of BASELINE's C2 / C5 config do: 108 multiplies each) nor that the first "
+                                    "permutation of a compression / hash row takes lane 0's round-0 S-box from a constant - this rate and `frac` are up to 5 % high "
+                                    "at t = 3; valu_issue (a counter, not a model) is the figure that binds"),
                      "peak_source": "pmx_diag_int_valu_peak on this device just before the warm-up (%d launches of a dense v_mad_u64_u32 loop, two forms, median of the later half of each)" % peak.launches,
                      "peak_best_launch": peak.best_lane_mads_per_s,
                      "peak_by_carry_destination": {"vcc": peak.lane_mads_per_s_vcc, "sgpr_pair": peak.lane_mads_per_s_sgpr}, "shader_clock_hz": peak.shader_clock_hz,
                      "theoretical_peak": peak.theoretical_lane_mads_per_s, "compute_units": peak.compute_units,
                      "frac_of_theoretical": mad_rate / peak.theoretical_lane_mads_per_s if peak.theoretical_lane_mads_per_s else None},
         "valu_issue": valu_issue,
+        # the same run in units that do not move with the clock a box happens to hold (boxes of this pool hold 2.11 ... 2.25 GHz under this load):
+        # shader clocks one SIMD spends per permutation, and - where the instruction count is known - clocks per VALU instruction and SIMD
+        # (the issue slot is 4: one wave instruction per 16 lanes x 4 passes)
+        "clock_normalised": clock_normalised(kernel_s, peak.shader_clock_hz, peak.compute_units, units_per_step / max(world, 1), valu_issue),
         "gather_ms": 1e3 * (dev_s - steps_s) if world > 1 else None,
     }
     if launcher:
         out["config"]["launcher"] = launcher
+    return out
+
+
+def clock_normalised(kernel_s, clock_hz, compute_units, permutations_per_gpu_step, valu_issue):
+    if not clock_hz or not compute_units or not permutations_per_gpu_step:
+        return None
+    simd_clocks = kernel_s * clock_hz * compute_units * 4          # SIMD-clocks the step's kernels had, over the whole chip
+    out = {"shader_clock_hz": clock_hz, "clock_source": "pmx_diag_int_valu_peak's s_memtime / wall-clock ratio under a dense multiply stream, just before the warm-up",
+           "simd_clocks_per_permutation": simd_clocks / permutations_per_gpu_step,
+           "permutations_per_s_at_2.2GHz": permutations_per_gpu_step / kernel_s * (2.2e9 / clock_hz), "kernel_ms_at_2.2GHz": 1e3 * kernel_s * clock_hz / 2.2e9}
+    per = (valu_issue or {}).get("valu_instructions_per_permutation")
+    if per:
+        out["clocks_per_valu_instruction_and_simd"] = simd_clocks / (permutations_per_gpu_step * per)     # 4.0 = every issue slot taken
     return out
 
 
@@ -934,6 +955,18 @@ def run_verification(env):
     return res
 
 
+def evidence_stale(recs):
+    """The committed counter figures belong to the device code they were taken on: tools/source_hash.py's hash of sponge_amd/csrc is stored
+    with them.  A tree whose kernels have changed since must not quote them (tests/test_evidence_fresh.py fails on such a tree)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import kernel_source_hash
+        have, want = recs.get("_kernel_source_hash"), kernel_source_hash()
+        return None if have == want else "stale: taken on kernel sources %s, this tree is %s - re-run the counter passes (tools/gpu_r06.sh slots pmc)" % (have, want)
+    except Exception as e:   # (a missing helper is not a reason to quote unverifiable figures)
+        return "stale: cannot hash the kernel sources (%s)" % e
+
+
 def load_traffic(workload, per_gpu_units):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json); it
     cannot be collected inside a timed run (counter collection serialises the kernels).  Only quoted when the profile was
@@ -941,7 +974,10 @@ def load_traffic(workload, per_gpu_units):
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         recs = json.load(open(path))
-        rec = next((r for k, r in recs.items() if k.split("_")[0] == workload and abs(r.get("units_per_launch", per_gpu_units) - per_gpu_units) <= 1), None)
+        stale = evidence_stale(recs)
+        if stale:
+            return None, stale
+        rec = next((r for k, r in recs.items() if isinstance(r, dict) and k.split("_")[0] == workload and abs(r.get("units_per_launch", per_gpu_units) - per_gpu_units) <= 1), None)
         if rec is None:
             return None, "not measured for this workload at this size"
         return rec["bytes_per_launch"], ("profiles/hbm_traffic.json: a committed constant, not a measurement of this run (separate rocprofv3 --pmc "
@@ -966,7 +1002,12 @@ def load_valu_issue(workload, per_gpu_units, kernel_s, compute_units, mads, info
         out["floor_ns_per_instruction_and_simd"] = r.ns_floor
         out["floor_source"] = "pmx_diag_issue_slot on this device before the warm-up, %d launches, exactly %d waves resident per SIMD; floor = the fastest stream" % (r.launches, waves)
     try:
-        w = json.load(open(os.path.join(ROOT, "profiles", "valu_instructions.json")))[workload]
+        recs = json.load(open(os.path.join(ROOT, "profiles", "valu_instructions.json")))
+        stale = evidence_stale(recs)
+        if stale:
+            out.update({"valu_instructions_per_permutation": None, "frac": None, "count_source": stale})
+            return out
+        w = recs[workload]
         # (the count per permutation is a property of the kernel, not of the batch size: quoted whenever the engine is the one the pass was taken on)
         if not compute_units or w.get("engine", info.engine.decode()) != info.engine.decode():
             raise KeyError(workload)

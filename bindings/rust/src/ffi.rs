@@ -31,18 +31,6 @@ pub struct pmx_mgpu_info {
     pub devices: [c_int; PMX_MAX_LOCAL_DEVICES],
 }
 #[repr(C)]
-pub struct pmx_valu_peak {
-    pub lane_mads_per_s: f64,
-    pub lane_mads_per_s_vcc: f64,
-    pub lane_mads_per_s_sgpr: f64,
-    pub best_lane_mads_per_s: f64,
-    pub shader_clock_hz: f64,
-    pub theoretical_lane_mads_per_s: f64,
-    pub compute_units: c_int,
-    pub launches: c_int,
-}
-
-#[repr(C)]
 pub struct pmx_engine_info {
     pub engine: [c_char; 64],
     pub width: c_int,
@@ -55,16 +43,6 @@ pub struct pmx_engine_info {
     pub mfma_dense: c_int,
     pub launches: c_int,
     pub partial_window: c_int,
-}
-#[repr(C)]
-pub struct pmx_issue_slot {
-    pub ns_12mad_4simple: f64,
-    pub ns_4mad_12simple: f64,
-    pub ns_16mad: f64,
-    pub ns_floor: f64,
-    pub waves_per_simd: c_int,
-    pub compute_units: c_int,
-    pub launches: c_int,
 }
 pub const PMX_OP_PERMUTE: c_int = 0;
 pub const PMX_OP_HASH: c_int = 1;
@@ -144,7 +122,4 @@ extern "C" {
                                    row_elems: usize) -> c_int;
     pub fn pmx_mgpu_merkle_2to1_dev(g: *mut pmx_mgpu, d_nodes: *const *mut u64, d_top: *const *mut u64, n_leaves: usize) -> c_int;
     pub fn pmx_mgpu_merkle_2to1(g: *mut pmx_mgpu, leaves: *const u64, n_leaves: usize, root: *mut u64) -> c_int;
-    // diagnostics
-    pub fn pmx_diag_int_valu_peak(device: c_int, seconds: f64, out: *mut pmx_valu_peak) -> c_int;
-    pub fn pmx_diag_issue_slot(device: c_int, waves_per_simd: c_int, seconds: f64, out: *mut pmx_issue_slot) -> c_int;
 }

@@ -39,9 +39,10 @@ extern "C" {
 #endif
 
 /* 3: PMX_ERR_HOST, pmx_merkle_verify_paths_dev, indices >= 2^depth fail verification, pmx_ctx_engine_info,
- *    pmx_diag_issue_slot, pmx_merkle_2to1_forest[_dev];
- *    the test hooks left this header (poseidon_mi355x_testing.h). */
-#define PMX_ABI_VERSION 3
+ *    pmx_merkle_2to1_forest[_dev]; the test hooks left this header (poseidon_mi355x_testing.h).
+ * 4: the benchmark diagnostics (pmx_diag_*) left the library for libposeidon_mi355x_diag.so (poseidon_mi355x_diag.h); the host-buffer
+ *    absorb / squeeze take any length (they cut a call longer than 65536 rates into pieces). */
+#define PMX_ABI_VERSION 4
 #define PMX_LIMBS 4        /* uint64_t limbs per field element */
 #define PMX_MAX_WIDTH 16   /* largest rate+capacity accepted (reference default table uses 3..9) */
 
@@ -183,8 +184,10 @@ int pmx_hash_batch_dev(pmx_ctx *ctx, const uint64_t *d_in, size_t in_len, uint64
  * 153-182, including the `!= rate` test of :175).  Sponges in one call may be in different modes.
  * Widths 4..9 (and width 3 from 32769 sponges up) run a call as PASSES on the permutation engine of the width (one launch per
  * permutation a sponge of the batch can need, ceil(len / rate); a sponge is permuted exactly as often as the reference would
- * permute it).  EVERY absorb / squeeze call moves at most 65536 rates of elements per sponge, whatever the width and the batch
- * size (PMX_ERR_ARG beyond: split the call - to a duplex sponge two calls are the same as one).
+ * permute it).  A _dev call moves at most 65536 rates of elements per sponge, whatever the width and the batch size (PMX_ERR_ARG
+ * beyond: split the call - to a duplex sponge two calls are the same as one, except that a squeeze must not be cut so that a piece of
+ * exactly `rate` elements meets a sponge inside its rate, mod.rs:175).  The HOST-buffer entry points take any length, as the reference
+ * does: they cut a longer call into such pieces themselves.
  * The _dev variants only enqueue on the caller's stream, with two provisos for the pass form: (1) the pass lists live in device
  * blocks the context keeps in a pool (a call takes the block its stream used last, or one whose earlier use has completed - the
  * context's own event says so -, or allocates one: calls on different streams stay independent; concurrent calls of ONE context
@@ -307,38 +310,8 @@ int pmx_mgpu_merkle_2to1(pmx_mgpu *g, const uint64_t *leaves, size_t n_leaves, u
  * named collective library - are declared in poseidon_mi355x_testing.h and exist only in libposeidon_mi355x_test.so, a
  * second build of the same objects; this library neither exports nor contains them.) */
 
-/* ---- diagnostics ---------------------------------------------------------------------------------------
- * The binding roofline of these kernels is the issue rate of v_mad_u64_u32 (one per 32x32-bit limb product), not
- * HBM.  It depends on the clock the chip holds under load, so it is measured, per device and per run: a dense loop
- * of that instruction on every SIMD for about `seconds` (default 0.02).  lane_mads_per_s = median of the later
- * launches; shader_clock_hz from s_memtime / s_memrealtime inside the kernel; theoretical = CUs x 4 SIMDs x 16
- * lanes per clock (a half-rate instruction) x that clock. */
-typedef struct pmx_valu_peak {
-    double lane_mads_per_s;             /* the faster of the two forms below */
-    double lane_mads_per_s_vcc;         /* carry-out of every multiply written to VCC */
-    double lane_mads_per_s_sgpr;        /* ... to an allocator-chosen SGPR pair (what compiled kernels do) */
-    double best_lane_mads_per_s;
-    double shader_clock_hz;
-    double theoretical_lane_mads_per_s;
-    int compute_units;
-    int launches;
-} pmx_valu_peak;
-int pmx_diag_int_valu_peak(int device, double seconds, pmx_valu_peak *out);
-
-/* The VALU issue slot: nanoseconds per VALU instruction and SIMD of three calibration streams (12 multiplies + 4 simple
- * instructions - the permutation kernels' own mix -, 4 + 12, multiplies only) with exactly `waves_per_simd` waves resident
- * on every SIMD, measured on this device for about `seconds` (default 0.03).  A kernel's issue floor is its VALU instruction
- * count x ns_floor (the fastest of the three: no stream that holds multiplies was seen to issue faster in this run). */
-typedef struct pmx_issue_slot {
-    double ns_12mad_4simple;
-    double ns_4mad_12simple;
-    double ns_16mad;
-    double ns_floor;
-    int waves_per_simd;
-    int compute_units;
-    int launches;
-} pmx_issue_slot;
-int pmx_diag_issue_slot(int device, int waves_per_simd, double seconds, pmx_issue_slot *out);
+/* (The benchmark diagnostics - the multiply-issue peak and the issue slot bench.py prices its kernels against - are NOT part of this
+ * library: include/poseidon_mi355x_diag.h, libposeidon_mi355x_diag.so.) */
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ PMX_ERR_UNSUPPORTED = -4
 PMX_ERR_RCCL = -5
 PMX_ERR_HOST = -6
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 UNIQUE_ID_BYTES = 128
 MAX_LOCAL_DEVICES = 16
 
@@ -145,7 +145,12 @@ SIGNATURES = {
     "pmx_mgpu_all_gather_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
     "pmx_mgpu_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz]),
     "pmx_mgpu_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p]),
-    # diagnostics
+}
+
+# include/poseidon_mi355x_diag.h: libposeidon_mi355x_diag.so, the benchmark diagnostics (bench.py) - not part of the shipped library
+DIAG_LIB_PATH = os.path.join(HERE, "libposeidon_mi355x_diag.so")
+DIAG_SIGNATURES = {
+    "pmx_diag_last_error": (ctypes.c_char_p, []),
     "pmx_diag_int_valu_peak": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.POINTER(PmxValuPeak)]),
     "pmx_diag_issue_slot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(PmxIssueSlot)]),
 }
@@ -199,6 +204,29 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+_diag = None
+
+
+def diag_lib() -> ctypes.CDLL:
+    """libposeidon_mi355x_diag.so (benchmark diagnostics; a library of its own)."""
+    global _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise ImportError(f"{DIAG_LIB_PATH} is missing: build it with `make -C sponge_amd/csrc`")
+        handle = ctypes.CDLL(DIAG_LIB_PATH)
+        for name, (restype, argtypes) in DIAG_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _diag = handle
+    return _diag
+
+
+def check_diag(rc: int) -> None:
+    if rc != PMX_OK:
+        raise PmxError(rc, diag_lib().pmx_diag_last_error().decode("utf-8", "replace"))
 
 
 def check(rc: int) -> None:

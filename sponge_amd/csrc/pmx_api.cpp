@@ -61,8 +61,34 @@ struct StreamDrain {
     ~StreamDrain() {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamSynchronize(ctx->stream3);
     }
 };
+
+// The host-buffer pipeline of a batch whose buffers are page-locked: chunk i is uploaded on `stream`, computed on `stream2` behind the
+// upload's event and downloaded on `stream3` behind the kernel's - the two copy directions have a stream (and a DMA engine) each, so chunk
+// i + 1 goes up while chunk i - 1 comes down (with a stream per LANE, round 5, each lane's download stood in front of its next upload and
+// the link carried one direction at a time: 61 GB/s for both together, profiles/r05/z_host_path.txt).  Pageable buffers: one chunk.
+template <class Up, class Run, class Down>
+static int host_pipeline(pmx_ctx *ctx, size_t n, size_t step, Up &&up, Run &&run, Down &&down) {
+    int rc = PMX_OK;
+    size_t first = 0;
+    for (int i = 0; first < n; first += step, ++i) {
+        const size_t cnt = n - first < step ? n - first : step;
+        const int slot = i % pmx_ctx::kPipeChunks;   // (at most kPipeChunks chunks: pipeline_rows)
+        if ((rc = up(first, cnt, ctx->stream))) return rc;
+        PMX_HIP(hipEventRecord(ctx->pipe_up[slot], ctx->stream));
+        PMX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->pipe_up[slot], 0));
+        if ((rc = run(first, cnt, ctx->stream2))) return rc;
+        PMX_HIP(hipEventRecord(ctx->pipe_done[slot], ctx->stream2));
+        PMX_HIP(hipStreamWaitEvent(ctx->stream3, ctx->pipe_done[slot], 0));
+        if ((rc = down(first, cnt, ctx->stream3))) return rc;
+    }
+    PMX_HIP(hipStreamSynchronize(ctx->stream3));
+    PMX_HIP(hipStreamSynchronize(ctx->stream2));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
 
 // n * elems_per_row * 32 bytes, or an error if that does not fit size_t / the launch grid
 static int batch_bytes(size_t n, size_t elems_per_row, size_t *bytes) {
@@ -108,7 +134,18 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     if (e == hipSuccess) e = hipMemcpy(ctx->d_consts, pp.consts.data(), bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking);
+    for (int i = 0; i < pmx_ctx::kPipeChunks && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&ctx->pipe_up[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipe_done[i], hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
+        for (hipStream_t st : {ctx->stream, ctx->stream2, ctx->stream3})
+            if (st) (void)hipStreamDestroy(st);
+        for (int i = 0; i < pmx_ctx::kPipeChunks; ++i) {
+            if (ctx->pipe_up[i]) (void)hipEventDestroy(ctx->pipe_up[i]);
+            if (ctx->pipe_done[i]) (void)hipEventDestroy(ctx->pipe_done[i]);
+        }
         if (ctx->d_consts) (void)hipFree(ctx->d_consts);
         delete ctx;
         return hip_fail(e, "pmx_ctx_create: device setup");
@@ -146,11 +183,15 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
 
 static int ctx_free(pmx_ctx *ctx) {
     DeviceGuard guard(ctx->device);
-    for (hipStream_t st : {ctx->stream, ctx->stream2}) {
+    for (hipStream_t st : {ctx->stream, ctx->stream2, ctx->stream3}) {
         if (st) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
         }
+    }
+    for (int i = 0; i < pmx_ctx::kPipeChunks; ++i) {
+        if (ctx->pipe_up[i]) (void)hipEventDestroy(ctx->pipe_up[i]);
+        if (ctx->pipe_done[i]) (void)hipEventDestroy(ctx->pipe_done[i]);
     }
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
@@ -443,19 +484,18 @@ extern "C" int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n) {
     void *d = nullptr;
     if ((rc = ctx_scratch(ctx, 0, bytes, &d))) return rc;
     StreamDrain drain{ctx};
-    const size_t step = is_pinned(states) ? pipeline_rows(n) : n;   // pinned: overlap H2D / kernel / D2H
-    int lane = 0;
-    for (size_t first = 0; first < n; first += step, lane ^= 1) {
-        const size_t cnt = n - first < step ? n - first : step;
-        hipStream_t st = lane ? ctx->stream2 : ctx->stream;
-        char *h = (char *)states + first * row, *dd = (char *)d + first * row;
-        PMX_HIP(hipMemcpyAsync(dd, h, cnt * row, hipMemcpyHostToDevice, st));
-        if ((rc = pmx_permute_batch_dev(ctx, (uint64_t *)dd, cnt, st))) return rc;
-        PMX_HIP(hipMemcpyAsync(h, dd, cnt * row, hipMemcpyDeviceToHost, st));
-    }
-    PMX_HIP(hipStreamSynchronize(ctx->stream));
-    PMX_HIP(hipStreamSynchronize(ctx->stream2));
-    return PMX_OK;
+    const size_t step = is_pinned(states) ? pipeline_rows(n) : n;   // pinned: upload / kernel / download overlap, both directions at once
+    return host_pipeline(
+        ctx, n, step,
+        [&](size_t first, size_t cnt, hipStream_t st) -> int {
+            PMX_HIP(hipMemcpyAsync((char *)d + first * row, (char *)states + first * row, cnt * row, hipMemcpyHostToDevice, st));
+            return PMX_OK;
+        },
+        [&](size_t first, size_t cnt, hipStream_t st) -> int { return pmx_permute_batch_dev(ctx, (uint64_t *)((char *)d + first * row), cnt, st); },
+        [&](size_t first, size_t cnt, hipStream_t st) -> int {
+            PMX_HIP(hipMemcpyAsync((char *)states + first * row, (char *)d + first * row, cnt * row, hipMemcpyDeviceToHost, st));
+            return PMX_OK;
+        });
     PMX_ABI_END
 }
 
@@ -492,19 +532,19 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
     StreamDrain drain{ctx};
     const size_t in_row = in_len * 32, out_row = out_len * 32;
     const size_t step = ((!in_bytes || is_pinned(in)) && (!out_bytes || is_pinned(out))) ? pipeline_rows(n) : n;
-    int lane = 0;
-    for (size_t first = 0; first < n; first += step, lane ^= 1) {
-        const size_t cnt = n - first < step ? n - first : step;
-        hipStream_t st = lane ? ctx->stream2 : ctx->stream;
-        const char *h_in = (const char *)in + first * in_row;
-        char *dd_in = (char *)d_in + first * in_row, *dd_out = (char *)d_out + first * out_row;
-        if (in_bytes) PMX_HIP(hipMemcpyAsync(dd_in, h_in, cnt * in_row, hipMemcpyHostToDevice, st));
-        if ((rc = pmx_hash_batch_dev(ctx, (const uint64_t *)dd_in, in_len, (uint64_t *)dd_out, out_len, cnt, st))) return rc;
-        if (out_bytes) PMX_HIP(hipMemcpyAsync((char *)out + first * out_row, dd_out, cnt * out_row, hipMemcpyDeviceToHost, st));
-    }
-    PMX_HIP(hipStreamSynchronize(ctx->stream));
-    PMX_HIP(hipStreamSynchronize(ctx->stream2));
-    return PMX_OK;
+    return host_pipeline(
+        ctx, n, step,
+        [&](size_t first, size_t cnt, hipStream_t st) -> int {
+            if (in_bytes) PMX_HIP(hipMemcpyAsync((char *)d_in + first * in_row, (const char *)in + first * in_row, cnt * in_row, hipMemcpyHostToDevice, st));
+            return PMX_OK;
+        },
+        [&](size_t first, size_t cnt, hipStream_t st) -> int {
+            return pmx_hash_batch_dev(ctx, (const uint64_t *)((char *)d_in + first * in_row), in_len, (uint64_t *)((char *)d_out + first * out_row), out_len, cnt, st);
+        },
+        [&](size_t first, size_t cnt, hipStream_t st) -> int {
+            if (out_bytes) PMX_HIP(hipMemcpyAsync((char *)out + first * out_row, (char *)d_out + first * out_row, cnt * out_row, hipMemcpyDeviceToHost, st));
+            return PMX_OK;
+        });
     PMX_ABI_END
 }
 
@@ -533,7 +573,7 @@ static hipError_t ctx_pass_scratch(void *owner, hipStream_t st, size_t bytes, ui
         if (b.recorded && b.stream == st && b.bytes >= bytes) { pick = &b; break; }
     if (!pick) {
         for (pmx_ctx::PassBlock &b : ctx->pass_pool) {      // the smallest idle block that is large enough
-            if (b.bytes < bytes || (pick && pick->bytes <= b.bytes)) continue;
+            if (b.poisoned || b.bytes < bytes || (pick && pick->bytes <= b.bytes)) continue;
             if (b.recorded && hipEventQuery(b.done) != hipSuccess) {
                 (void)hipGetLastError();                    // not ready - or not queryable (recorded into a capture): not idle
                 continue;
@@ -566,7 +606,12 @@ static void ctx_pass_done(void *owner, hipStream_t st, uint32_t *block) {
     pmx_ctx *ctx = static_cast<pmx_ctx *>(owner);
     for (pmx_ctx::PassBlock &b : ctx->pass_pool) {
         if (b.ptr != block) continue;
-        if (hipEventRecord(b.done, st) != hipSuccess) (void)hipGetLastError();   // (then only this stream takes the block again)
+        // a record that failed leaves `done` unrecorded (or holding an older, completed record): a query would call the block idle while
+        // this call's launches may still read it - such a block is never handed to another stream again (its own stream orders the reuse)
+        if (hipEventRecord(b.done, st) != hipSuccess) {
+            (void)hipGetLastError();
+            b.poisoned = true;
+        }
         b.recorded = true;
         return;
     }
@@ -623,6 +668,32 @@ static int sponge_host(pmx_ctx *ctx, uint64_t *states, uint32_t *tag, uint32_t *
     if ((absorb && !in) || (!absorb && !out && len)) return set_error(PMX_ERR_ARG, "pmx_sponge_*_batch: null data pointer");
     int rc = check_modes(ctx, tag, index, n);
     if (rc) return rc;
+    // The reference takes any length (mod.rs:232-254, 321-341); a device call moves at most kMaxPasses rates per sponge (check_pass_count).
+    // To a duplex sponge `absorb(a ++ b)` is `absorb(a); absorb(b)`, and `squeeze(k1 + k2)` is `squeeze(k1); squeeze(k2)` unless the
+    // second call asks for exactly `rate` elements from a sponge that stands inside its rate (the test of mod.rs:175 then skips a
+    // permutation the long call performs): a longer call is cut into pieces of kMaxPasses rates, never leaving a last piece of one rate.
+    const size_t rate = ctx->dev.rounds.rate, max_len = kMaxPasses * rate;
+    if (rate != 0 && len > max_len) {
+        std::vector<uint64_t> rows;   // n > 1: the piece of every sponge, packed [n][piece]
+        for (size_t done = 0; done < len;) {
+            size_t piece = len - done < max_len ? len - done : max_len;
+            if (len - done - piece == rate) piece -= rate;   // (kMaxPasses > 1: the piece stays positive and is not `rate` itself)
+            const uint64_t *in_piece = in ? in + done * 4 : nullptr;
+            uint64_t *out_piece = out ? out + done * 4 : nullptr;
+            if (n > 1) {
+                if (n > (SIZE_MAX / 32) / piece) return set_error(PMX_ERR_ARG, "batch byte size overflows size_t");
+                rows.resize(n * piece * 4);
+                if (absorb)
+                    for (size_t i = 0; i < n; ++i) std::memcpy(rows.data() + i * piece * 4, in + (i * len + done) * 4, piece * 32);
+                in_piece = out_piece = rows.data();
+            }
+            if ((rc = sponge_host(ctx, states, tag, index, absorb ? in_piece : nullptr, absorb ? nullptr : out_piece, piece, n, absorb))) return rc;
+            if (!absorb && n > 1)
+                for (size_t i = 0; i < n; ++i) std::memcpy(out + (i * len + done) * 4, rows.data() + i * piece * 4, piece * 32);
+            done += piece;
+        }
+        return PMX_OK;
+    }
     PMX_BIND(ctx);
     std::lock_guard<std::mutex> lock(ctx->host_lock);
     size_t st_bytes = 0, io_bytes = 0;

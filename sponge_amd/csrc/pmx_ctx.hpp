@@ -16,7 +16,10 @@ struct pmx_ctx {
     pmx::DevConfig dev{};            // kernel-argument block (points at d_consts)
     uint32_t *d_consts = nullptr;    // device: constant table (pmx_prepare.hpp layout)
     hipStream_t stream = nullptr;    // used by the host-buffer entry points (and by a device group for this device)
-    hipStream_t stream2 = nullptr;   // second lane of the pinned-memory pipeline
+    hipStream_t stream2 = nullptr;   // the pinned-memory pipeline: `stream` only uploads, `stream2` only computes, `stream3` only downloads
+    hipStream_t stream3 = nullptr;
+    static constexpr int kPipeChunks = 8;
+    hipEvent_t pipe_up[kPipeChunks] = {}, pipe_done[kPipeChunks] = {};   // chunk i uploaded / computed (created with the context)
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // grow-only device staging for the host-buffer entry points
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     void *pinned = nullptr;          // page-locked host block for small host-buffer calls (allocated on first use)
@@ -30,7 +33,7 @@ struct pmx_ctx {
     // has completed, else a new one; nothing is ever freed or queried through a caller's stream handle on the enqueue path - the
     // blocks go when the context goes.  pass_lock is held while a driver call enqueues, which also keeps two threads from
     // interleaving their launches on one stream of this context.
-    struct PassBlock { void *ptr = nullptr; size_t bytes = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool recorded = false; };
+    struct PassBlock { void *ptr = nullptr; size_t bytes = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool recorded = false; bool poisoned = false; };
     std::mutex pass_lock;
     std::vector<PassBlock> pass_pool;
     // pmx_ctx_acquire / pmx_ctx_release bookkeeping (0 for contexts made by pmx_ctx_create)

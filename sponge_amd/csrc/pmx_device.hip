@@ -211,8 +211,7 @@ struct RegEngine {
 // 23 / 46 / 68 % when held to three (round 3 A/B).
 constexpr int kHybWaves = 1, kHyb4WaveMaxT = 4, kHyb3WaveMaxT = 6;
 // MFMA: every product by a constant runs on the matrix cores (pmx_mfma.hpp) - the dense layers and, as windows of t S-boxes
-// per layer, the linear part of the partial rounds; the kMfmaWaves waves of a workgroup share one LDS tile of the layer's table
-// rows.  Wave-uniform kernels only (permute, hash, compress, and the passes of the absorb / squeeze driver, which ARE permutation
+// per layer, the linear part of the partial rounds.  Wave-uniform kernels only (permute, hash, compress, and the passes of the absorb / squeeze driver, which ARE permutation
 // launches: inside a per-lane loop not every lane is active, and the lane exchange of this path needs both lanes of a pair).
 // Register bounds of the matrix-core engines (their byte strings and sums want registers), measured per width:
 #ifndef PMX_MFMA_4WAVE_MAX_T
@@ -221,12 +220,10 @@ constexpr int kHybWaves = 1, kHyb4WaveMaxT = 4, kHyb3WaveMaxT = 6;
 #ifndef PMX_MFMA_3WAVE_MAX_T
 #define PMX_MFMA_3WAVE_MAX_T 5
 #endif
-// Four waves per workgroup, two workgroups per CU.  The tile holds a whole row of the layer with the longest rows (the window layers:
-// t - 1 + K elements) where two workgroups per CU still fit (t <= 8), as much as fits at t = 9 (8 KiB: two stages per row): +0.4 ...
-// +2 % over a tile sized for the dense layers (profiles/r04).  At t = 9 (8 x 18 KiB of scratch per CU) that is two workgroups of
-// four waves per CU - their phases drift apart, so one's MFMAs run under the other's carries - against one workgroup of eight waves
-// with a whole row, whose waves all multiply and all carry at the same time (6 % slower, round 3).
-constexpr int kMfmaWaves = 4, kMfmaMinTileSteps = 6;
+// Four waves per workgroup (one per SIMD), two workgroups per CU at t = 9 (8 x 18 KiB of scratch).  Since round 6 the rows' tables are
+// streamed by every wave for itself (pmx_mfma.hpp: no LDS tile, no workgroup barrier inside the permutation); the workgroup only shares
+// the barriers of the state load / store staging.  (One wave per workgroup was measured: +-0, profiles/r06/b_ab_*.)
+constexpr int kMfmaWaves = 4;
 template <int T, int ALPHA, bool MFMA = false>
 struct HybridEngine {
     static constexpr int kWaves = MFMA ? kMfmaWaves : kHybWaves;
@@ -235,9 +232,9 @@ struct HybridEngine {
     static constexpr int kMinWaves = MFMA ? (T <= PMX_MFMA_4WAVE_MAX_T ? 4 : T <= PMX_MFMA_3WAVE_MAX_T ? 3 : 2)
                                           : (T <= kHyb4WaveMaxT ? 4 : T <= kHyb3WaveMaxT ? 3 : 2);
     static constexpr int kMinWavesDriver = 2;   // absorb / squeeze kernels (per-lane modes: more live state) spill under the tighter bounds
-    // the matrix-core rows exchange operands between the lanes of a pair (l, l + 32) and share an LDS tile behind workgroup
-    // barriers: permute() must be reached by every lane of the workgroup - never from a per-lane loop (absorb_kernel /
-    // squeeze_kernel static_assert on this; the drivers of these widths run as passes, sponge_first_kernel)
+    // the matrix-core rows exchange operands between the lanes of a pair (l, l + 32): permute() must be reached by every lane of the
+    // wave - never from a per-lane loop (absorb_kernel / squeeze_kernel static_assert on this; the drivers of these widths run as
+    // passes, sponge_first_kernel)
     static constexpr bool kWaveUniformOnly = MFMA;
     static constexpr int kChunks = 2 * T;
     // one wave's LDS region: scratch slots for elements 0..T-2 (2304 B each) or the ABI staging of its 64 states
@@ -268,14 +265,7 @@ struct HybridEngine {
     uint4 *region;    // this wave's LDS region
     uint32_t lane;
 
-    // the stage of a row's table the workgroup shares, behind the waves' regions: a whole row of the longest layer (the window layers:
-    // t - 1 + K elements) where two workgroups per CU still fit, else as many k-steps as fit
-    static constexpr int kTileFit = (int)((80 * 1024 - kMfmaWaves * kWaveBytes) / 1024);
-    static constexpr int kWinSteps = (MFMA && mfma_window_for(T) > 0) ? mfma_k_steps(T - 1 + mfma_window_for(T)) : 0;
-    static constexpr int kNeedSteps = kWinSteps > mfma_k_steps(T) ? kWinSteps : mfma_k_steps(T);
-    static constexpr int kTileSteps = kNeedSteps <= kTileFit ? kNeedSteps : (kTileFit > kMfmaMinTileSteps ? kTileFit : kMfmaMinTileSteps);
-    static constexpr size_t kTileBytes = MFMA ? (size_t)kTileSteps * 1024 : 0;
-    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes + kTileBytes; }
+    static size_t lds_bytes(const DevConfig & /*d*/, uint32_t /*t*/) { return kWaves * kWaveBytes; }
 
     __device__ __forceinline__ HybridEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
         f.io = consts + d.io_offset;
@@ -469,8 +459,7 @@ struct HybridEngine {
 
     // lane0_zero: the caller knows lane 0 of the state is zero (pmx_permute.hpp: the window engines skip its round-0 S-box)
     __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T, bool lane0_zero = false) {
-        permute_hybrid<T, ALPHA, Scratch, MFMA ? kThreads : 0, kTileSteps, MFMA ? mfma_window_for(T) : 0>(s, sc, tb, c, one, f, want_lo, want_hi,
-                                                                                                          pmx_lds + kWaves * (kWaveBytes / 16), lane0_zero);
+        permute_hybrid<T, ALPHA, Scratch, MFMA, MFMA ? mfma_window_for(T) : 0>(s, sc, tb, c, one, f, want_lo, want_hi, lane0_zero);
     }
 };
 
@@ -1126,7 +1115,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
     const bool due = sponge_walk<SQUEEZE>(d.rounds, p32, states, mode_tag, mode_index, io, len, gid, gid < n, 0, last_pass);
     const uint64_t due_mask = __builtin_amdgcn_ballot_w64(due);       // wave-uniform: the only thing live across the permutation
     {   // workgroup vote through the first word of the DYNAMIC LDS (free until the engine is built): __syncthreads_or keeps a static
-        // word of its own, and at t = 9 the engine's 80 KiB are exactly half a CU - one word more and one workgroup fits instead of two
+        // word of its own, which would come on top of the engine's dynamic LDS (72 KiB at t = 9: two workgroups per CU)
         uint32_t *flag = reinterpret_cast<uint32_t *>(pmx_lds);
         if (threadIdx.x == 0) *flag = 0;
         __syncthreads();
@@ -1714,3 +1703,4 @@ hipError_t launch_path_check(const uint64_t *cur, const uint64_t *root, const ui
 #endif  // PMX_TU
 
 }  // namespace pmx
+

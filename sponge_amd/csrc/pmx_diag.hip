@@ -11,12 +11,60 @@
 #include <chrono>
 #include <vector>
 
-#include "../../include/poseidon_mi355x.h"
-#include "pmx_ctx.hpp"
+#include <cstdarg>
+#include <cstdio>
+#include <exception>
 
-using namespace pmx;
+#include "../../include/poseidon_mi355x.h"        // (the status codes only)
+#include "../../include/poseidon_mi355x_diag.h"
 
+// libposeidon_mi355x_diag.so: a library of its own (round 6) - the shipped libposeidon_mi355x.so carries no benchmark instrumentation.
 namespace {
+
+thread_local char g_diag_error[512] = "";
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(g_diag_error, sizeof g_diag_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) { return set_error(PMX_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); }
+#define PMX_HIP(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+// the caller's current device is put back on the way out
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+// nothing unwinds through the C ABI (std::vector below)
+template <class F>
+int guarded(const char *who, F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::exception &e) {
+        return set_error(PMX_ERR_HOST, "%s: %s", who, e.what());
+    } catch (...) {
+        return set_error(PMX_ERR_HOST, "%s: unknown exception", who);
+    }
+}
 
 // CARRY_IN_VCC: where the instruction's (unused) carry-out goes - VCC, or an SGPR pair the register allocator picks, which
 // is what compiled kernels use.  Both forms are timed; the faster one is the peak.
@@ -54,10 +102,13 @@ __global__ void __launch_bounds__(256) mad_chain_kernel(unsigned *out, unsigned 
 
 }  // namespace
 
+extern "C" const char *pmx_diag_last_error(void) { return g_diag_error; }
+
 extern "C" int pmx_diag_int_valu_peak(int device, double seconds, pmx_valu_peak *out) {
+    return guarded("pmx_diag_int_valu_peak", [&]() -> int {
     if (!out) return set_error(PMX_ERR_ARG, "pmx_diag_int_valu_peak: null pointer");
     *out = pmx_valu_peak{};
-    const int ndev = pmx_device_count();
+    const int ndev = device_count();
     if (ndev == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= ndev) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
     if (!(seconds > 0)) seconds = 0.02;
@@ -129,6 +180,7 @@ extern "C" int pmx_diag_int_valu_peak(int device, double seconds, pmx_valu_peak 
     // 4 SIMDs per CU, each retiring 16 lanes of this half-rate instruction per clock
     out->theoretical_lane_mads_per_s = (double)n_cu * 4 * 16 * out->shader_clock_hz;
     return PMX_OK;
+    });
 }
 
 // ---- the VALU issue slot, measured in the run ----------------------------------------------------------------------------
@@ -169,10 +221,10 @@ __global__ void __launch_bounds__(256) issue_stream_kernel(unsigned *out, int tr
 }  // namespace
 
 extern "C" int pmx_diag_issue_slot(int device, int waves_per_simd, double seconds, pmx_issue_slot *out) {
-    PMX_ABI_BEGIN("pmx_diag_issue_slot")      // (std::vector below: nothing may unwind through the C ABI)
+    return guarded("pmx_diag_issue_slot", [&]() -> int {
     if (!out) return set_error(PMX_ERR_ARG, "pmx_diag_issue_slot: null pointer");
     *out = pmx_issue_slot{};
-    const int ndev = pmx_device_count();
+    const int ndev = device_count();
     if (ndev == 0) return set_error(PMX_ERR_HIP, "no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= ndev) return set_error(PMX_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
     if (waves_per_simd < 1 || waves_per_simd > 8) return set_error(PMX_ERR_ARG, "waves_per_simd %d out of range [1,8]", waves_per_simd);
@@ -239,5 +291,5 @@ extern "C" int pmx_diag_issue_slot(int device, int waves_per_simd, double second
     out->compute_units = n_cu;
     out->launches = launches;
     return PMX_OK;
-    PMX_ABI_END
+    });
 }

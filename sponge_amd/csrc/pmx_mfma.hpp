@@ -6,7 +6,7 @@
 // of the wave (one per lane), whose K dimension is the bytes of the state and whose M dimension is the bytes of the result:
 //
 //   * every element z_j a layer takes in is an S-box output (a Montgomery product: below 1.3 p) or a row of the layer before
-//     (below 2^248 + p), so with p < 2^255 it is below 2^256: it is re-cut into 32 bytes u_{j,b} - eight words, exactly ONE k-step of
+//     (below 2^248.1 + p), so with p < 2^255 it is below 2^256: it is re-cut into 32 bytes u_{j,b} - eight words, exactly ONE k-step of
 //     the matrix-core instruction per element (round 5; rounds 3-4 carried 36 bytes per element, 33 used, for values up to 2^261:
 //     -12 ... -25 % products per row, 16 registers fewer at t = 9; the bound holds for every exponent: alpha = 1 is formed as the
 //     product x * 1, alpha = 0 is the constant 1 - pmx_field.hpp: fe_sbox);
@@ -19,14 +19,16 @@
 //     their own.  So a k-step is two MFMAs - states 0-31 and states 32-63 of the wave - and before them each lane hands the
 //     half of its byte registers its partner lane (+-32) must feed to that partner (v_permlane32_swap, once per layer);
 //     afterwards the 32 sums of a state sit half on its own lane and half on the partner: sixteen more swaps per row;
-//   * the 32 sums S_e (|S_e| < 2^25) are the integer V = sum_e S_e 2^(8e) = sum u Y < 2^272: eight 64-bit word sums, a
-//     carry pass with ONE Montgomery step of 24 bits inside it (the table carries the 2^24: one multiply-add per word on top of the
-//     word sum, mfma_row_acc) and a re-cut of the words into nine 29-bit limbs give the row below 2^248 + p - instead of 810 multiplies.
+//   * the 32 sums S_e (|S_e| <= 32 n_in * 128 * 128 < 2^24 for the n_in <= 17 inputs of the longest layer) are the integer
+//     V = sum_e S_e 2^(8e) + the row's correction = sum u Y < n_in * 32 * 255 * p (2^272.1 at n_in = 17, p near 2^255): eight 64-bit word
+//     sums, a carry pass with ONE Montgomery step of 24 bits inside it (the table carries the 2^24: one multiply-add per word on top of the
+//     word sum, mfma_row_acc) and a re-cut of the words into nine 29-bit limbs give the row (V + m p) / 2^24 < 2^248.1 + p < 2^256 -
+//     instead of 810 multiplies.  kMfmaMaxInputs below ties the window size and the widest state to these budgets.
 //
-// The table of one row (n_in KiB: 9 for a dense row of t = 9, 14 for a row of its window layers) passes through an LDS tile once per
-// WORKGROUP, in stages (read per wave from L2 the L2 -> L1 path sets the time), which is why the engines that use this run several waves
-// per workgroup (pmx_device.hip: kMfmaWaves, HybridEngine::kTileSteps).  tools/mfma_dense_proto.{py,hip} is the stand-alone form of the same code with its check against Python
-// integers; profiles/r03/g_mfma_dense_proto.txt its measurements.
+// The table of one row (n_in KiB: 9 for a dense row of t = 9, 17 for a row of its window layers) is streamed by every wave for itself,
+// from global memory (L2 / L1) into a ring of registers at least six k-steps ahead of its use (matrix_rows_mfma_w below; rounds 3-5 passed
+// it through an LDS tile shared by the workgroup, two barriers per stage).  tools/mfma_dense_proto.{py,hip} is the stand-alone form of the
+// first version with its check against Python integers; profiles/r03/g_mfma_dense_proto.txt its measurements.
 #pragma once
 
 #include "pmx_field.hpp"
@@ -64,6 +66,12 @@ PMX_FN constexpr int mfma_window_for(int t) {
     return (t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T) ? (PMX_MFMA_WINDOW < t ? PMX_MFMA_WINDOW : t) : 0;
 }
 PMX_FN constexpr int mfma_window_hist(int k) { return (k - 1) * (k - 2) / 2; }   // history constants per window
+// The longest row of any layer: t - 1 carried lanes + K S-box outputs.  Budgets that rest on it (pmx_mfma.hpp, head): a sum S_e of
+// 32 n_in byte products stays inside 2^25 (the row finish adds four of them, shifted by up to 24 bits, into a 64-bit word: |t| < 2^57), and
+// the row, (n_in * 32 * 255 * p + p) / 2^24 with p < 2^255, stays below 2^256 - what the 32-byte operand cut of the next layer needs.
+constexpr int kMfmaMaxInputs = PMX_MFMA_MAX_T - 1 + (PMX_MFMA_WINDOW < PMX_MFMA_MAX_T ? PMX_MFMA_WINDOW : PMX_MFMA_MAX_T);
+static_assert(32 * kMfmaMaxInputs * 128 * 128 < (1 << 25), "a sum of byte products must stay inside the accumulator budget of mfma_row_acc");
+static_assert((unsigned long long)kMfmaMaxInputs * 32 * 255 < (1ull << kMfmaShift), "a row must stay below 2^256: n_in * 32 * 255 * p / 2^24 + p < 2 p");
 // The history terms of a window's S-box inputs, x_{k+1} - z_k = u_k + sum_{i<k} h_{k,i} z_i (k = 2 .. K - 1): at t = 3 - ONE term per window -
 // a product by a shifted table on the VALU (pmx_field.hpp: tab_dot; profiles/r04/q_ab_history_tables.txt), from t = 4 rows on the matrix
 // cores (below; profiles/r05/k_ab_history_rows_on_the_matrix_cores.txt, l_ab_history_rows_t4_t5.txt: t = 4 +1.8 %, 5 +3.7 %, 6 +6.3 %, 7 +4.7 %,
@@ -82,7 +90,7 @@ constexpr uint32_t kMfmaHistSmallMarker = 0xffffffffu;
 PMX_FN constexpr bool mfma_hist_rows(int t) { return !mfma_hist_tab(t); }
 // With the history terms as rows, the only outputs of a layer inside the partial section that are ever needed as field ELEMENTS are row 0
 // (x_1, the first S-box input) and row 1 (u_1: x_2 = z_1 + u_1); the other carried lanes only ever enter matrix-core rows again.  Those
-// rows are finished in OPERAND form (mfma_row_finish_operand: the row - below 2^248 + p - read out of the accumulators as eight 32-bit
+// rows are finished in OPERAND form (mfma_row_finish_operand: the row - below 2^248.1 + p - read out of the accumulators as eight 32-bit
 // words IS the eight operand words) and travel between the layers as such: no re-cut into limbs, no byte cut.
 PMX_FN constexpr int mfma_fe_rows(int t) { return mfma_hist_rows(t) ? 2 : t; }
 PMX_FN constexpr int mfma_hist_row_words(int k) { return mfma_k_steps(k) * 64 * 4 + 16; }          // the row of x_{k+1}: k inputs, eight correction words
@@ -125,12 +133,18 @@ PMX_FN void mfma_state_words(const Fe *s, uint32_t (&W)[8 * mfma_k_steps(T)]) {
 }
 
 // One output row from its 32 sums: R[w][r] = S_{4w + r}, the sum for residue byte 4w + r.  V = sum_e S_e 2^(8e) + the row's correction
-// (V < 2^272) is formed as eight 64-bit word sums with carries, and ONE Montgomery step of 24 bits runs in the SAME accumulators:
+// (V < 2^272.1) is formed as eight 64-bit word sums with carries, and ONE Montgomery step of 24 bits runs in the SAME accumulators:
 // m = V (-p^-1) mod 2^24 is known after word 0, and every word takes m p_w (below 2^56) on top of its sum (|t| < 2^50) before its
 // carry leaves - one v_mad_u64_u32 per word, where a step of its own behind the carry pass paid four (two zero-extensions, the product,
 // a 64-bit add: round 5's first form, 2^32) and the 29-bit step of rounds 3-4 five per limb.  a[0 .. 8] are the words of V + m p: the low
-// 24 bits are zero, (V + m p) / 2^24 < 2^248 + p < 2^256 is the row (the table carries the 2^24), read out of a[] at bit 24.
+// 24 bits are zero, (V + m p) / 2^24 < 2^248.1 + p < 2^256 is the row (the table carries the 2^24), read out of a[] at bit 24.
+PMX_FN void mfma_row_acc_p(const int32_t (&R)[8][4], const long long *corr, const uint32_t *p32, uint32_t pinv, uint32_t (&a)[9]);
 PMX_FN void mfma_row_acc(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f, uint32_t (&a)[9]) {
+    mfma_row_acc_p(R, corr, f.io + kIoP32, f.pinv, a);
+}
+// (corr: the row's eight correction words, p32: the modulus as eight 32-bit words - both wave-uniform; the streamed rows fetch them in front of
+// their products, so that the finish does not open with a scalar-cache round trip)
+PMX_FN void mfma_row_acc_p(const int32_t (&R)[8][4], const long long *corr, const uint32_t *p32, uint32_t pinv, uint32_t (&a)[9]) {
     // Every term of a word sum is ONE v_mad_i64_i32: the weights (and the 1 that brings in the carry and the first byte) come from
     // registers the compiler cannot see through, or it would turn each into a sign extension, a 64-bit shift and a 64-bit add - and
     // from VECTOR registers, so that the row's correction, a wave-uniform 64-bit value in a scalar pair, can be the addend of the word's
@@ -155,8 +169,8 @@ PMX_FN void mfma_row_acc(const int32_t (&R)[8][4], const long long *corr, const 
         t += (long long)R[w][1] * w8;
         t += (long long)R[w][2] * w16;
         t += (long long)R[w][3] * w24;
-        if (w == 0) m = ((uint32_t)t * f.pinv) & 0xffffffu;   // (-1/p mod 2^29 serves modulo 2^24 - and lives in a scalar register for the S-boxes anyway)
-        t = (long long)((uint64_t)m * f.io[kIoP32 + w] + (uint64_t)t);
+        if (w == 0) m = ((uint32_t)t * pinv) & 0xffffffu;   // (-1/p mod 2^29 serves modulo 2^24 - and lives in a scalar register for the S-boxes anyway)
+        t = (long long)((uint64_t)m * p32[w] + (uint64_t)t);
         a[w] = (uint32_t)t;
         carry = (int)(t >> 32);
     }
@@ -172,10 +186,8 @@ PMX_FN uint32_t mfma_row_bits(const uint32_t (&a)[9], int bit) {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
 #endif
 }
-// A row as a field ELEMENT: nine 29-bit limbs, one funnel shift and one mask each (norm, below 2^248 + p).
-PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
-    uint32_t a[9];
-    mfma_row_acc(R, corr, f, a);
+// A row as a field ELEMENT: nine 29-bit limbs, one funnel shift and one mask each (norm, below 2^248.1 + p).
+PMX_FN Fe mfma_row_limbs(const uint32_t (&a)[9]) {
     Fe row;
 #pragma unroll
     for (int k = 0; k < kN; ++k) {
@@ -184,6 +196,11 @@ PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const
     }
     return row;
 }
+PMX_FN Fe mfma_row_finish(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
+    uint32_t a[9];
+    mfma_row_acc(R, corr, f, a);
+    return mfma_row_limbs(a);
+}
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y);
@@ -191,9 +208,13 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y);
 // A row in OPERAND form (mfma_fe_rows): its eight words, u - 128 per byte (and on the device the second half handed to the partner
 // lane), ARE the operand words of a layer input - no re-cut into limbs, no byte cut.  They travel in the first eight words of an Fe-sized
 // container (the scratch slots hold nine words either way).
+PMX_FN Fe mfma_row_operand(const uint32_t (&a)[9]);
 PMX_FN Fe mfma_row_finish_operand(const int32_t (&R)[8][4], const long long *corr, const FieldRt &f) {
     uint32_t a[9];
     mfma_row_acc(R, corr, f, a);
+    return mfma_row_operand(a);
+}
+PMX_FN Fe mfma_row_operand(const uint32_t (&a)[9]) {
     Fe row;
 #pragma unroll
     for (int k = 0; k < 8; ++k) row.l[k] = mfma_row_bits(a, kMfmaShift + 32 * k) ^ 0x80808080u;
@@ -232,8 +253,8 @@ inline Fe mfma_row_host(const uint32_t *W, const uint32_t *layer, size_t n_rows,
 // the operand form of an element (device: the second half of the words goes to the partner lane)
 inline void mfma_cut_operand(const Fe &x, uint32_t *w8) { mfma_cut_element(x, w8); }
 // rows [lo, hi) of NOUT over the operand words of NIN inputs (NOUT - 1 <= the scratch's slots)
-template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
-inline void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, void * /*tile*/, const FieldRt &f, uint32_t lo, uint32_t hi,
+template <int NIN, int NOUT, class Scratch>
+inline void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, const FieldRt &f, uint32_t lo, uint32_t hi,
                                uint32_t fe_rows = NOUT) {
     Fe last = out[NOUT - 1];
     for (uint32_t i = lo; i < hi; ++i) {
@@ -244,16 +265,16 @@ inline void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &s
     static_for<0, NOUT - 1>([&](auto i) { out[i] = sc.get(i); });
     out[NOUT - 1] = last;
 }
-template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
-inline void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi,
+template <int NIN, int NOUT, class Scratch>
+inline void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, const FieldRt &f, uint32_t lo, uint32_t hi,
                                 uint32_t fe_rows = NOUT) {
     uint32_t W[8 * NIN];
     mfma_state_words<NIN>(in, W);
-    matrix_rows_mfma_w<NIN, NOUT, THREADS, TILE_STEPS>(W, out, sc, layer, tile, f, lo, hi, fe_rows);
+    matrix_rows_mfma_w<NIN, NOUT>(W, out, sc, layer, f, lo, hi, fe_rows);
 }
-template <int T, int THREADS, int TILE_STEPS, class Scratch>
-inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, void *tile, const FieldRt &f, uint32_t lo, uint32_t hi, uint32_t fe_rows = T) {
-    matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi, fe_rows);
+template <int T, class Scratch>
+inline void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, const FieldRt &f, uint32_t lo, uint32_t hi, uint32_t fe_rows = T) {
+    matrix_rows_mfma_io<T, T>(s, s, sc, layer, f, lo, hi, fe_rows);
 }
 // one history row of a window (mfma_hist_rows): load / products / finish, as the device issues them around an S-box
 template <int T>
@@ -288,12 +309,8 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
 }
 
 // Rows [lo, hi) of the layer whose tables start at `layer` (global memory; mfma_layer_words(T) words); the other rows of s
-// come back unspecified, like matrix_rows_rolled.  s norm.  `tile`: TILE_STEPS KiB of LDS shared by the workgroup's THREADS
-// threads, all of which must arrive here together (two barriers per stage of a row) with every lane active.
+// come back unspecified, like matrix_rows_rolled.  s norm.  Every lane of the wave must be active.
 // General form: NIN input elements at `in`, rows [lo, hi) of NOUT into out (which may alias in: the inputs are consumed first).
-// k-steps of the A operand in flight between the tile and the matrix cores (4 registers each): as many as a stage has, up to 8 - 4 at
-// t = 5, whose kernels sit on the 168 registers of three waves per SIMD (8 ahead spilled there: -5.5 %, profiles/r05/d_ab_lds_tile_read_ahead.txt)
-PMX_FN constexpr int mfma_lds_ahead(int t) { return t == 5 ? 4 : 8; }
 // the operand form of an element: its eight words, the second half handed to the partner lane (+-32) - lanes 32-63 of a product feed
 // the second half of every k-step for the states of lanes 0-31
 __device__ __forceinline__ void mfma_cut_operand(const Fe &x, uint32_t *w8) {
@@ -304,102 +321,110 @@ __device__ __forceinline__ void mfma_cut_operand(const Fe &x, uint32_t *w8) {
 // the rows over the operand words W of the NIN inputs (mfma_cut_operand each)
 // (fe_rows < NOUT only where the width has operand-form rows at all - mfma_fe_rows: elsewhere the operand finish is not even compiled in,
 // or the t = 3 kernel, which has none, pays its registers: 32 bytes of scratch per lane at four waves per SIMD, HBM writes 1.34 x)
-template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
-__device__ __forceinline__ void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
+// Every wave streams the A operand of its rows straight from global memory (L2 / L1: a layer's table is one contiguous run of 1 KiB
+// k-steps, the same for every wave of the launch) into a ring of registers - no LDS tile, no workgroup barrier (round 6; rounds 3-5 passed
+// the table through a tile shared by the workgroup's four waves, two barriers per stage: C3 +5.8 %, h9 +6.6 %, d9 +7 %, t = 8 ... 4
+// +3.4 / +2.8 / +3.4 / +1.6 / +0.8 %, profiles/r06/c_ab_streamed_rows.txt).
+// Slots 0 .. R-1 serve k-steps [0, FULL) of a row (slot q % R, refilled R k-steps ahead; the last R of them with the NEXT row's first R),
+// the REM = NQ - FULL k-steps behind them have a slot each, refilled with the next row's same k-step: every load is issued at least R
+// k-steps (R pairs of products = 64 R clocks of the matrix pipe) before its use, and the assignment is the same for every row.
+// R for a row of nq k-steps: the whole row where it is short (nq <= 9: every k-step is fetched a row ahead), else the ring of 6 .. 9 slots
+// that leaves the fewest slots in all (R + nq % R; ties to the longer ring): 17 -> 8 + 1, 15 -> 7 + 1, 13 -> 6 + 1, 11 -> 9 + 2.
+PMX_FN constexpr int mfma_ring(int nq) {
+    if (nq <= 9) return nq;
+    int best = 6;
+    for (int r = 7; r <= 9; ++r)
+        if (r + nq % r <= best + nq % best) best = r;
+    return best;
+}
+template <int NIN, int NOUT, class Scratch>
+__device__ __forceinline__ void matrix_rows_mfma_w(const uint32_t (&W)[8 * NIN], Fe *out, Scratch &sc, const uint32_t *layer, const FieldRt &f,
                                                    uint32_t lo, uint32_t hi, uint32_t fe_rows = NOUT) {
     constexpr bool kOperandRows = mfma_fe_rows(NOUT) < NOUT;
     constexpr int T = NOUT;
     constexpr int NQ = mfma_k_steps(NIN);
-    constexpr int NS = (NQ + TILE_STEPS - 1) / TILE_STEPS;   // the tile holds TILE_STEPS k-steps: a row passes through it in NS stages
-    constexpr int SPS = (NQ + NS - 1) / NS;                  // ... of SPS k-steps each (the last one the remainder): balanced
+    constexpr int R = mfma_ring(NQ), FULL = NQ / R * R, REM = NQ - FULL, SLOTS = R + REM;
     const uint32_t lane = threadIdx.x & 63;
     const long long *corr = reinterpret_cast<const long long *>(layer + (size_t)T * mfma_row_words(NIN));
-    Fe last = out[T - 1];
-    // This thread's share of every stage of a row's table, one register buffer per stage: a buffer is refilled with the SAME stage of the
-    // NEXT row as soon as its contents are in the tile, so a fetch has a whole row's time to land.  (With one buffer refilled a stage
-    // ahead - round 4 - the fetch for the second stage of a two-stage row had the 16 products of the first to hide behind: 512 clocks
-    // against an L2 round trip of more; a lone workgroup spent 29 % of its time waiting, profiles/r05/f_c3_by_batch_size.txt.)
-    constexpr int kPer = (SPS * 64 + THREADS - 1) / THREADS;
-    mfma_v4i pre[NS][kPer];
-    auto fetch = [&](uint32_t row, auto st) {
-        constexpr int stage = decltype(st)::value;
-        const mfma_v4i *src = reinterpret_cast<const mfma_v4i *>(layer) + ((size_t)row * NQ + (size_t)stage * SPS) * 64;
-        constexpr uint32_t count = (uint32_t)((stage == NS - 1 ? NQ - stage * SPS : SPS) * 64);
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const uint32_t e = threadIdx.x + q * THREADS;
-            if (e < count) pre[stage][q] = src[e];
-        }
+    // k-step q of row i: the 1 KiB at layer + (i NQ + q) KiB, lane l its 16 bytes at 16 l.  Buffer loads: the table's base in a resource
+    // descriptor (four scalar registers), the row in the scalar offset, the k-step in the instruction's immediate where it fits, the lane
+    // in ONE vector register - the stream costs no vector registers for addresses (global loads took a 64-bit pair per 4 KiB of reach).
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(layer), 0, 0x7fffffff, 0x00020000);
+    const uint32_t lane_off = lane * 16u;
+    auto kstep = [&](uint32_t row, int q) -> mfma_v4i {
+        const uint32_t soff = (row * (uint32_t)NQ + (uint32_t)(q & ~3)) * 1024u;   // (wave-uniform: scalar arithmetic)
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + (uint32_t)(q & 3) * 1024u, soff, 0);
+        return mfma_v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
     };
-    if (lo < hi) static_for<0, NS>([&](auto st) { fetch(lo, st); });
+    Fe last = out[T - 1];
+    mfma_v4i a[SLOTS];
+    if (lo < hi) {   // (issued in the order the loop refills the slots: the compiler's wait counts at the top of the loop are the steady state's)
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            a[q] = kstep(lo, q);
+            PMX_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int e = 0; e < REM; ++e) {
+            a[R + e] = kstep(lo, FULL + e);
+            PMX_SCHED_FENCE();
+        }
+    }
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t nxt = i + 1 < hi ? i + 1 : i;   // (the last row refetches itself: no branch in the stream, the loads are never used)
         mfma_v16i d1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d2 = d1;
-        static_for<0, NS>([&](auto st) {
-            constexpr int stage = decltype(st)::value, steps = stage == NS - 1 ? NQ - stage * SPS : SPS;
-            __syncthreads();   // the readers of the stage before are done with the tile
+        // the row's correction words and the modulus words of its finish: fetched (scalar loads) in front of the products, so that the
+        // finish does not open with a scalar-cache round trip (t = 8 +2 %, h9 +1.2 %; it also lets the register allocation of the t = 9
+        // kernel come out without a spill)
+        long long cw[8];
+        uint32_t pw[8];
 #pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-                const uint32_t e = threadIdx.x + q * THREADS;
-                if (e < (uint32_t)steps * 64) tile[e] = pre[stage][q];
-            }
-            __syncthreads();
-            if (i + 1 < hi) fetch(i + 1, st);
-            // The A operand of up to kAhead k-steps is read out of the tile BEFORE the first product of the stage, and a slot is
-            // refilled as soon as its pair of products has been issued: left to itself the compiler reads one or two k-steps ahead
-            // and then waits the whole LDS round trip (~120 clocks, against the 64 a pair of products keeps the matrix pipe busy)
-            // in front of every pair - a wave spent 22 % of its cycles in s_waitcnt that way (profiles/r04/s_pmc_window_kernels_c3_c2.txt).
-            constexpr int kAhead = steps < mfma_lds_ahead(NOUT) ? steps : mfma_lds_ahead(NOUT);
-            mfma_v4i a[kAhead];
-#pragma unroll
-            for (int qq = 0; qq < kAhead; ++qq) a[qq] = tile[qq * 64 + lane];
-            PMX_SCHED_FENCE();   // (the reads stay in front: the scheduler would sink them next to their products again)
-#pragma unroll
-            for (int qq = 0; qq < steps; ++qq) {
-                constexpr int q0 = stage * SPS;
-                const int q = q0 + qq;
-                const mfma_v4i b1 = {(int)W[8 * q + 0], (int)W[8 * q + 1], (int)W[8 * q + 2], (int)W[8 * q + 3]};
-                const mfma_v4i b2 = {(int)W[8 * q + 4], (int)W[8 * q + 5], (int)W[8 * q + 6], (int)W[8 * q + 7]};
-                d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[qq % kAhead], b1, d1, 0, 0, 0);   // states 0-31 of the wave
-                d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[qq % kAhead], b2, d2, 0, 0, 0);   // states 32-63
-                if (qq + kAhead < steps) {
-                    PMX_SCHED_FENCE();
-                    a[qq % kAhead] = tile[(qq + kAhead) * 64 + lane];
-                    PMX_SCHED_FENCE();
-                }
-            }
+        for (int w = 0; w < 8; ++w) cw[w] = corr[(size_t)i * 8 + w], pw[w] = f.io[kIoP32 + w];
+        PMX_SCHED_FENCE();
+        static_for<0, NQ>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            constexpr int slot = q < FULL ? q % R : R + (q - FULL);
+            const mfma_v4i b1 = {(int)W[8 * q + 0], (int)W[8 * q + 1], (int)W[8 * q + 2], (int)W[8 * q + 3]};
+            const mfma_v4i b2 = {(int)W[8 * q + 4], (int)W[8 * q + 5], (int)W[8 * q + 6], (int)W[8 * q + 7]};
+            d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[slot], b1, d1, 0, 0, 0);   // states 0-31 of the wave
+            d2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[slot], b2, d2, 0, 0, 0);   // states 32-63
+            PMX_SCHED_FENCE();
+            if constexpr (q + R < FULL) a[slot] = kstep(i, q + R);
+            else if constexpr (q < FULL) a[slot] = kstep(nxt, q % R);
+            else a[slot] = kstep(nxt, q);
+            PMX_SCHED_FENCE();
         });
-        // register v of d1 / d2 holds row 8 (v / 4) + 4 (lane / 32) + v % 4 of the column lane % 32: after the exchange
-        // d1[4g + r] is row 8g + r and d2[4g + r] row 8g + 4 + r of THIS lane's state, i.e. word 2g of the row is d1[4g ..], word 2g + 1 d2[4g ..]
-        int32_t R[8][4];
+        int32_t R4[8][4];
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             uint32_t x = (uint32_t)d1[v], y = (uint32_t)d2[v];
             lane32_swap(x, y);
-            R[2 * (v / 4)][v % 4] = (int32_t)x;
-            R[2 * (v / 4) + 1][v % 4] = (int32_t)y;
+            R4[2 * (v / 4)][v % 4] = (int32_t)x;
+            R4[2 * (v / 4) + 1][v % 4] = (int32_t)y;
         }
-        // (rows from fe_rows on - wave-uniform - stay in operand form: they only ever enter matrix-core rows again, mfma_fe_rows)
         Fe row;
-        if (!kOperandRows || i < fe_rows) row = mfma_row_finish(R, corr + (size_t)i * 8, f);
-        else row = mfma_row_finish_operand(R, corr + (size_t)i * 8, f);
+        uint32_t acc9[9];
+        mfma_row_acc_p(R4, cw, pw, f.pinv, acc9);
+        if (!kOperandRows || i < fe_rows) row = mfma_row_limbs(acc9);
+        else row = mfma_row_operand(acc9);
         if (i + 1 < (uint32_t)T) sc.set(i, row);
         else last = row;
     }
     static_for<0, T - 1>([&](auto i) { out[i] = sc.get(i); });
     out[T - 1] = last;
 }
-template <int NIN, int NOUT, int THREADS, int TILE_STEPS, class Scratch>
-__device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f,
+template <int NIN, int NOUT, class Scratch>
+__device__ __forceinline__ void matrix_rows_mfma_io(const Fe *in, Fe *out, Scratch &sc, const uint32_t *layer, const FieldRt &f,
                                                     uint32_t lo, uint32_t hi, uint32_t fe_rows = NOUT) {
     uint32_t W[8 * NIN];
     static_for<0, NIN>([&](auto j) { mfma_cut_operand(in[decltype(j)::value], &W[8 * decltype(j)::value]); });
-    matrix_rows_mfma_w<NIN, NOUT, THREADS, TILE_STEPS>(W, out, sc, layer, tile, f, lo, hi, fe_rows);
+    matrix_rows_mfma_w<NIN, NOUT>(W, out, sc, layer, f, lo, hi, fe_rows);
 }
-template <int T, int THREADS, int TILE_STEPS, class Scratch>
-__device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, mfma_v4i *tile, const FieldRt &f, uint32_t lo,
+template <int T, class Scratch>
+__device__ __forceinline__ void matrix_rows_mfma(Fe (&s)[T], Scratch &sc, const uint32_t *layer, const FieldRt &f, uint32_t lo,
                                                  uint32_t hi, uint32_t fe_rows = T) {
-    matrix_rows_mfma_io<T, T, THREADS, TILE_STEPS>(s, s, sc, layer, tile, f, lo, hi, fe_rows);
+    matrix_rows_mfma_io<T, T>(s, s, sc, layer, f, lo, hi, fe_rows);
 }
 
 // One history row of a window (mfma_hist_rows): load<KK> fetches the row's A operand (KK k-steps, 16 bytes per lane each) straight from

@@ -297,19 +297,19 @@ PMX_FN void matrix_rows_rolled(Fe (&s)[T], Scratch &sc, const uint32_t *mat, con
 // a linear stage chosen by the round - sparse layer, normalised dense layer, the last round's dense layer - so that every
 // block of code exists once (the sparse layer is used by the entrance round and by the partial rounds alike; two inlined
 // copies would not fit the instruction cache at t = 9).
-// MFMA_THREADS > 0: the dense layers run on the matrix cores (pmx_mfma.hpp) - the workgroup has that many threads, all of them
-// here together, and `tile` is its shared LDS tile.
-// MFMA_WINDOW = K > 0 (with MFMA_THREADS > 0): the partial rounds run as windows of K (pmx_mfma.hpp) - the layer after the entrance
+// MFMA: the dense layers run on the matrix cores (pmx_mfma.hpp) - every lane of the wave must be here (the rows exchange operands between
+// the lanes of a pair).
+// MFMA_WINDOW = K > 0 (with MFMA): the partial rounds run as windows of K (pmx_mfma.hpp) - the layer after the entrance
 // round is the windows' entry layer on the matrix cores, and the sparse layers are not in the kernel at all.
 // lane0_zero (window engines): the caller knows that s[0] is zero on entry - the capacity lane of a fresh sponge - so the S-box of that
 // lane in round 0 is a constant of the config, stored behind the window tables: one S-box of 55 fewer per 2-to-1 compression at t = 3.
-template <int T, int ALPHA, class Scratch, int MFMA_THREADS = 0, int MFMA_TILE_STEPS = 0, int MFMA_WINDOW = 0>
+template <int T, int ALPHA, class Scratch, bool MFMA = false, int MFMA_WINDOW = 0>
 PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const Rounds &c, const Fe &one,
-                           const FieldRt &f, uint32_t want_lo = 0, uint32_t want_hi = T, void *tile = nullptr, bool lane0_zero = false) {
+                           const FieldRt &f, uint32_t want_lo = 0, uint32_t want_hi = T, bool lane0_zero = false) {
     const uint32_t first_partial = c.half_full, last_partial = c.half_full + c.partial_rounds - 1;
     uint32_t guard = 0;   // keeps table_touch's loads alive (see the end of the function)
     for (uint32_t r = 0; r < c.total_rounds; ++r) {
-        if constexpr (MFMA_THREADS > 0 && MFMA_WINDOW > 0) {
+        if constexpr (MFMA && MFMA_WINDOW > 0) {
             if (r == first_partial) {   // the whole partial section: windows, each closed by one layer on the matrix cores
                 constexpr int K = MFMA_WINDOW, NIN = T - 1 + K;
                 constexpr size_t kLayer = (size_t)mfma_layer_words_io(NIN, T), kPer = kLayer + (size_t)mfma_window_hist_words(T, K);
@@ -357,11 +357,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                             }
                         });
                         const uint32_t fe_rows = w + 1 < n_win ? (uint32_t)mfma_fe_rows(T) : (uint32_t)T;   // (the last layer feeds S-boxes on every lane)
-#if defined(__HIPCC__)
-                        matrix_rows_mfma_w<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(W, s, sc, wt, static_cast<mfma_v4i *>(tile), f, 0u, (uint32_t)T, fe_rows);
-#else
-                        matrix_rows_mfma_w<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(W, s, sc, wt, tile, f, 0u, (uint32_t)T, fe_rows);
-#endif
+                        matrix_rows_mfma_w<NIN, T>(W, s, sc, wt, f, 0u, (uint32_t)T, fe_rows);
                     } else {
                     Fe in[NIN];
                     static_for<1, T>([&](auto i) { in[i - 1] = s[i]; });
@@ -399,11 +395,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                             in[T - 1 + k] = fe_zero();
                         }
                     });
-#if defined(__HIPCC__)
-                    matrix_rows_mfma_io<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(in, s, sc, wt, static_cast<mfma_v4i *>(tile), f, 0u, (uint32_t)T);
-#else
-                    matrix_rows_mfma_io<NIN, T, MFMA_THREADS, MFMA_TILE_STEPS>(in, s, sc, wt, tile, f, 0u, (uint32_t)T);
-#endif
+                    matrix_rows_mfma_io<NIN, T>(in, s, sc, wt, f, 0u, (uint32_t)T);
                     }
                 }
                 r = last_partial;
@@ -417,7 +409,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
         if (full) {            // S-box on every lane
             static_for<0, T - 1>([&](auto i) { sc.set(i, s[i]); });
             uint32_t first = 0;
-            if constexpr (MFMA_THREADS > 0 && MFMA_WINDOW > 0) {
+            if constexpr (MFMA && MFMA_WINDOW > 0) {
                 if (r == 0 && lane0_zero && c.half_full > 0) {   // (wave-uniform) lane 0 came in as zero: its S-box output is a constant
                     const uint32_t n_win = (c.partial_rounds + MFMA_WINDOW - 1) / MFMA_WINDOW;
                     sc.set(0, fe_const(tb.win + mfma_window_words(T, MFMA_WINDOW, n_win)));
@@ -429,7 +421,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                 sc.set(i, fe_sbox<ALPHA>(fe_add_lazy(sc.get(i), fe_const(rk + i * kFeStride)), c.alpha, one, f));
             s[T - 1] = fe_sbox<ALPHA>(fe_add_lazy(s[T - 1], fe_const(rk + (T - 1) * kFeStride)), c.alpha, one, f);
             static_for<0, T - 1>([&](auto i) { s[i] = sc.get(i); });
-        } else if constexpr (!(MFMA_THREADS > 0 && MFMA_WINDOW > 0)) {   // partial round: S-box on lane 0; lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom)
+        } else if constexpr (!(MFMA && MFMA_WINDOW > 0)) {   // partial round: S-box on lane 0; lanes 1..T-1 stay norm (mont_mul_add, see opt_schedule_lane_headroom)
             if (sparse_layer) {   // warm the scalar cache for this round's tables, a whole S-box ahead of their use
                 const uint32_t *rt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
                 if constexpr (T <= kHybridTabMaxT) guard ^= table_touch<tab_row_words(T - 1)>(rt);
@@ -437,7 +429,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             }
             s[0] = fe_sbox<ALPHA>(fe_add_lazy(s[0], fe_const(rk)), c.alpha, one, f);
         }
-        constexpr bool kWindows = MFMA_THREADS > 0 && MFMA_WINDOW > 0;
+        constexpr bool kWindows = MFMA && MFMA_WINDOW > 0;
         if (sparse_layer && !kWindows) {
             const uint32_t *spt = tb.tab_sparse + (size_t)layer * sparse_tab_words(T);
             const Fe z0 = s[0];
@@ -461,7 +453,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
             // except the last round's, whose output is the permutation's
             const bool last = r + 1 == c.total_rounds;
             const uint32_t o = full ? full_ordinal(r, c) : 0;
-            if constexpr (MFMA_THREADS > 0) {
+            if constexpr (MFMA) {
                 const uint32_t n_full = c.total_rounds - c.partial_rounds - 1;   // the layer after the last partial round follows the full rounds' own
                 const uint32_t *lay = tb.mfma + (size_t)(full ? o : n_full) * mfma_layer_words(T);
                 uint32_t fe_rows = (uint32_t)T;
@@ -469,11 +461,7 @@ PMX_FN void permute_hybrid(Fe (&s)[T], Scratch &sc, const OptTables &tb, const R
                     lay = tb.win;
                     fe_rows = (uint32_t)mfma_fe_rows(T);
                 }
-#if defined(__HIPCC__)
-                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, static_cast<mfma_v4i *>(tile), f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T, fe_rows);
-#else
-                matrix_rows_mfma<T, MFMA_THREADS, MFMA_TILE_STEPS>(s, sc, lay, tile, f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T, fe_rows);
-#endif
+                matrix_rows_mfma<T>(s, sc, lay, f, last ? want_lo : 0u, last ? want_hi : (uint32_t)T, fe_rows);
             } else if constexpr (T <= kHybridTabMaxT) {
                 const uint32_t *mat = full ? tb.tab_full + (size_t)o * T * tab_row_words(T) : tb.tab_bdense;
                 if (last) matrix_rows_rolled_tab<T, false>(s, sc, mat, f, want_lo, want_hi);

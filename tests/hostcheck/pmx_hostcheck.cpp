@@ -181,8 +181,8 @@ static int permute_hybrid_mfma_t(const Prepared &pp, uint64_t *states, size_t n)
         // a state whose lane 0 is zero takes the shortcut the compress / hash kernels take for a fresh sponge (lane0_zero)
         const uint64_t *lane0 = states + (k * T) * 4;
         const bool z0 = KW > 0 && !(lane0[0] | lane0[1] | lane0[2] | lane0[3]);
-        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, 256, 6, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, nullptr, z0);
-        else permute_hybrid<T, 0, HostScratch<T>, 256, 6, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, nullptr, z0);
+        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, true, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, z0);
+        else permute_hybrid<T, 0, HostScratch<T>, true, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, z0);
         for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
     }
     return PMX_OK;

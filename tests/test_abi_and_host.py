@@ -30,7 +30,17 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.pmx_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.pmx_abi_version() == _lib.ABI_VERSION == 4
+    # the benchmark diagnostics are a library of their own (include/poseidon_mi355x_diag.h): nothing of them in the shipped one
+    diag = declared_functions("poseidon_mi355x_diag.h")
+    assert sorted(_lib.DIAG_SIGNATURES) == diag and len(diag) == 3 and not set(diag) & set(names)
+    for name in diag:
+        assert not hasattr(lib, name), f"{name}: a benchmark diagnostic is exported by the shipped library"
+    assert os.path.exists(_lib.DIAG_LIB_PATH), "make -C sponge_amd/csrc builds libposeidon_mi355x_diag.so"
+    import ctypes
+    d = ctypes.CDLL(_lib.DIAG_LIB_PATH)
+    for name in diag:
+        assert hasattr(d, name), name
     # the device-group test hooks have their own header and are NOT in the library that ships: not exported, not contained
     hooks = declared_functions("poseidon_mi355x_testing.h")
     assert sorted(_lib.TEST_HOOK_SIGNATURES) == hooks and not set(hooks) & set(names)

@@ -189,6 +189,42 @@ def test_a_call_longer_than_65536_rates_is_refused_not_launched():
     assert lib.pmx_sponge_squeeze_batch_dev(h, None, None, None, None, 8 * 65536, 0, None) == _lib.PMX_OK
 
 
+def test_host_calls_longer_than_65536_rates_are_cut_into_pieces_the_reference_takes_any_length():
+    """The reference's absorb / squeeze take any length (src/poseidon/mod.rs:232-254, 321-341) and the drop-in type passes a whole
+    input as one call with n = 1; the device call is limited to 65536 rates, so the host-buffer entry points cut a longer call into
+    pieces (pmx_api.cpp: sponge_host).  t = 3 (rate 2, the reference's default shape): absorb(65536 * 2 + 1) on one sponge, then a
+    squeeze whose LAST piece would be exactly one rate from a sponge standing inside its rate - the cut that would skip a permutation
+    through the test of mod.rs:175 - and the same on three sponges in different modes (n > 1: the pieces are packed row by row)."""
+    f, cfg, cr = _config("bls12_381_fr", None, 255, 2, 5, 8, 31)
+    r, t = 2, 3
+    long_in = 65536 * r + 1
+    for n in (1, 3):
+        batch = S.BatchPoseidonSponge.new(cfg, n)
+        batch.state = synth.random_elements(f, n * t, seed=61 + n).reshape(n, t, 4)
+        batch.mode_tag = np.array([0, 1, 1][:n], dtype=np.uint32)
+        batch.mode_index = np.array([1, 1, 2][:n], dtype=np.uint32)
+        ref = [(batch.state[i].copy(), int(batch.mode_tag[i]), int(batch.mode_index[i])) for i in range(n)]
+        elems = synth.random_elements(f, n * long_in, seed=62 + n).reshape(n, long_in, 4)
+        batch.absorb(elems)
+        ref = [cr.sponge_absorb(s_, m, i, elems[j]) for j, (s_, m, i) in enumerate(ref)]
+        for j, (s_, m, i) in enumerate(ref):
+            assert np.array_equal(batch.state[j], s_) and (int(batch.mode_tag[j]), int(batch.mode_index[j])) == (m, i), ("absorb", n, j)
+        # leave every sponge Squeezing inside its rate (index 1), then ask for 65536 rates + one rate
+        out = batch.squeeze_native_field_elements(1)
+        ref2 = []
+        for j, (s_, m, i) in enumerate(ref):
+            s2, m2, i2, o = cr.sponge_squeeze(s_, m, i, 1)
+            assert np.array_equal(out[j], o)
+            ref2.append((s2, m2, i2))
+        assert all(int(x) == 1 for x in batch.mode_index) and all(int(x) == 1 for x in batch.mode_tag)
+        long_out = 65536 * r + r
+        out = batch.squeeze_native_field_elements(long_out)
+        for j, (s_, m, i) in enumerate(ref2):
+            s2, m2, i2, o = cr.sponge_squeeze(s_, m, i, long_out)
+            assert np.array_equal(out[j], o), ("squeeze", n, j)
+            assert np.array_equal(batch.state[j], s2) and (int(batch.mode_tag[j]), int(batch.mode_index[j])) == (m2, i2), ("squeeze", n, j)
+
+
 @pytest.mark.parametrize("name", ["bls_t3_a5_8_31", "bls_t3_a17_8_31", "bls_t3_a257_8_13"])
 def test_t3_calls_above_the_quad_range_run_on_the_matrix_core_engine_and_agree_with_the_quad_kernels(name):
     """t = 3 - alpha = 5 (BASELINE configs[1]'s shape), alpha = 17 (the reference's own rate-2 default and the config of its only

@@ -22,5 +22,5 @@ for tu in 0 1 2 3 4; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC -shared -fPIC --offload-arch=gfx950 $B/pmx_device_0.o $B/pmx_device_1.o $B/pmx_device_2.o $B/pmx_device_3.o $B/pmx_device_4.o $C/build/pmx_api.o $C/build/pmx_mgpu.o $C/build/pmx_diag.o $C/build/pmx_params.o -ldl -o $R/tools/ab/libposeidon_$NAME.so
+$HIPCC -shared -fPIC --offload-arch=gfx950 $B/pmx_device_0.o $B/pmx_device_1.o $B/pmx_device_2.o $B/pmx_device_3.o $B/pmx_device_4.o $C/build/pmx_api.o $C/build/pmx_mgpu.o $C/build/pmx_params.o -ldl -o $R/tools/ab/libposeidon_$NAME.so
 ls -la $R/tools/ab/libposeidon_$NAME.so

@@ -19,5 +19,5 @@ if [ "${WITH_TU0:-0}" = "1" ]; then   # the public launchers as well (routing ex
 fi
 $HIPCC $FLAGS -x hip -c $C/pmx_api.cpp -o $B/pmx_api.o &
 wait
-$HIPCC -shared -fPIC --offload-arch=gfx950 $TU0 $B/pmx_device_1.o $B/pmx_device_3.o $C/build/pmx_device_hybg.o $C/build/pmx_device_hybgw.o $B/pmx_api.o $C/build/pmx_mgpu.o $C/build/pmx_diag.o $C/build/pmx_params.o -ldl -o $R/tools/ab/libposeidon_$NAME.so
+$HIPCC -shared -fPIC --offload-arch=gfx950 $TU0 $B/pmx_device_1.o $B/pmx_device_3.o $C/build/pmx_device_hybg.o $C/build/pmx_device_hybgw.o $B/pmx_api.o $C/build/pmx_mgpu.o $C/build/pmx_params.o -ldl -o $R/tools/ab/libposeidon_$NAME.so
 ls -la $R/tools/ab/libposeidon_$NAME.so

@@ -43,6 +43,9 @@ def main():
     if os.path.exists(out):
         data = json.load(open(out))
     data[workload] = rec
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from source_hash import kernel_source_hash
+    data["_kernel_source_hash"] = kernel_source_hash()     # the device code these figures were taken on (tools/source_hash.py)
     json.dump(data, open(out, "w"), indent=1)
     print(json.dumps(rec))
 

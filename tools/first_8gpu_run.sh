@@ -16,24 +16,29 @@ OUT=${2:-scale_out}
 mkdir -p "$OUT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 unset WORLD_SIZE RANK LOCAL_RANK MASTER_PORT
-have=$(python3 -c "from sponge_amd import _lib; print(_lib.lib().pmx_device_count())")
+PY=${PYTHON:-python}
+have=$($PY -c "from sponge_amd import _lib; print(_lib.lib().pmx_device_count())" 2> "$OUT/device_count.err")
+case "$have" in
+  ''|*[!0-9]*) echo "cannot count the devices (library missing or not importable: $(tail -1 "$OUT/device_count.err")); nothing run" | tee "$OUT/summary.txt"; exit 2;;
+esac
+[ "$have" -ge 1 ] || { echo "no HIP device visible; nothing run" | tee "$OUT/summary.txt"; exit 2; }
 [ "$have" -lt "$MAX" ] && MAX=$have
 echo "devices visible: $have, running up to N = $MAX" | tee "$OUT/summary.txt"
-( timeout 3000 python -m pytest tests/test_gpu_mgpu.py -x -q -m gpu ) > "$OUT/pytest_mgpu.log" 2>&1
+( timeout 3000 $PY -m pytest tests/test_gpu_mgpu.py -x -q -m gpu ) > "$OUT/pytest_mgpu.log" 2>&1
 echo "tests/test_gpu_mgpu.py: exit $? - $(tail -1 "$OUT/pytest_mgpu.log")" | tee -a "$OUT/summary.txt"
 for n in 1 2 4 8; do
   [ "$n" -le "$MAX" ] || break
   for w in c2 c5; do
     steps=20; [ "$w" = c5 ] && steps=5
-    timeout 1800 python bench.py --gpus $n --steps $steps --warmup 5 --workload $w --no-cpu-baseline > "$OUT/${w}_n${n}_ranks.json" 2> "$OUT/${w}_n${n}_ranks.err"
+    timeout 1800 $PY bench.py --gpus $n --steps $steps --warmup 5 --workload $w --no-cpu-baseline > "$OUT/${w}_n${n}_ranks.json" 2> "$OUT/${w}_n${n}_ranks.err"
     echo "rc $? ${w} N=$n ranks" >> "$OUT/rc.txt"
     if [ "$n" -gt 1 ]; then
-      timeout 1800 python bench.py --gpus $n --single-process --steps $steps --warmup 5 --workload $w > "$OUT/${w}_n${n}_single.json" 2> "$OUT/${w}_n${n}_single.err"
+      timeout 1800 $PY bench.py --gpus $n --single-process --steps $steps --warmup 5 --workload $w > "$OUT/${w}_n${n}_single.json" 2> "$OUT/${w}_n${n}_single.err"
       echo "rc $? ${w} N=$n single" >> "$OUT/rc.txt"
     fi
   done
 done
-python3 - "$OUT" <<'PY' | tee -a "$OUT/summary.txt"
+$PY - "$OUT" <<'PY' | tee -a "$OUT/summary.txt"
 import glob, json, os, sys
 out = sys.argv[1]
 print(open(os.path.join(out, "rc.txt")).read())

@@ -29,5 +29,8 @@ data = json.load(open(out)) if os.path.exists(out) else {}
 data.pop("floor_ns_per_instruction", None)      # the floor is measured in the run now (pmx_diag_issue_slot)
 data.pop("floor_source", None)
 data[workload] = rec
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import kernel_source_hash
+data["_kernel_source_hash"] = kernel_source_hash()     # the device code these figures were taken on (tools/source_hash.py)
 json.dump(data, open(out, "w"), indent=1)
 print(json.dumps(rec))
