@@ -126,9 +126,6 @@ def parse_args():
                     help="N>1 permutation batches: 'final' = one RCCL all-gather of the result shards after the K steps (inside "
                          "the timed region); 'step' = an all-gather after EVERY step")
     ap.add_argument("--spinup-seconds", type=float, default=0.25, help="untimed device spin-up before the W warmup steps")
-    ap.add_argument("--allow-torch-gather", action="store_true",
-                    help="N>1: if the C ABI's device group (RCCL through pmx_mgpu_*) cannot be formed, gather through torch.distributed "
-                         "instead of exiting non-zero (a second code path: off by default, and the line says so when taken)")
     ap.add_argument("--single-process", action="store_true",
                     help="N>1 without a launcher: ONE process drives all N GPUs through the C ABI's single-process device group "
                          "(pmx_mgpu_create = ncclCommInitAll; what a Rust caller uses) instead of starting one rank per GPU")
@@ -457,21 +454,17 @@ def main():
     import sponge_amd as S
     from sponge_amd import _lib, mgpu, synth
 
-    # PMX_BENCH_REHEARSAL=1: a dry run of the N > 1 code path on a box with ONE GPU (tools/gpu_n2_rehearsal.sh): the ranks
-    # share the visible GPUs round-robin, torch.distributed runs on gloo and the gathers are staged through the host
-    # (RCCL refuses two ranks on one device).  It exercises the sharding, the step functions, the verification of the
-    # gathered buffer and the JSON line; its numbers mean nothing and the line says so.
-    # PMX_BENCH_REHEARSAL=group: the same shared-GPU dry run, but through the PRODUCT's multi-rank path - the C ABI's device
-    # group (pmx_mgpu_create_rank, pmx_mgpu_permute_shards_dev, pmx_mgpu_all_gather_dev, pmx_mgpu_merkle_2to1_dev) exactly as
-    # in a real N > 1 run; only torch.distributed's control plane is on gloo.  The collective library then has to accept
-    # several ranks on one device, which RCCL does not: the caller names one that does with PMX_RCCL_LIBRARY
-    # (tools/gpu_group_rehearsal.sh uses the tests' stand-in).  Again: every branch executes, no number means anything.
+    # PMX_BENCH_REHEARSAL=group: a dry run of the N > 1 code path on a box with ONE GPU, through the PRODUCT's multi-rank path - the C
+    # ABI's device group (pmx_mgpu_create_rank, pmx_mgpu_permute_shards_dev, pmx_mgpu_all_gather_dev, pmx_mgpu_merkle_2to1_dev) exactly as
+    # in a real N > 1 run; the ranks share the visible GPUs round-robin and only torch.distributed's control plane is on gloo.  The
+    # collective library then has to accept several ranks on one device, which RCCL does not: the caller names one that does with
+    # PMX_RCCL_LIBRARY (tools/gpu_group_rehearsal.sh uses the tests' stand-in).  Every branch executes, no number means anything, and
+    # the line says so.  (There is no other gather path: a run that cannot form the device group fails.)
     rehearsal_mode = os.environ.get("PMX_BENCH_REHEARSAL", "")
-    if rehearsal_mode not in ("", "1", "group"):
-        raise SystemExit("PMX_BENCH_REHEARSAL is 1 (gathers staged through the host) or group (the C ABI's device group)")
+    if rehearsal_mode not in ("", "group"):
+        raise SystemExit("PMX_BENCH_REHEARSAL is unset or 'group' (the C ABI's device group on shared GPUs)")
     rehearsal = rehearsal_mode != ""
-    host_staged = rehearsal_mode == "1"
-    if rehearsal_mode == "group":
+    if rehearsal:
         _lib.use_test_library()      # only the test-hook build reads PMX_RCCL_LIBRARY (the stand-in that accepts ranks sharing a GPU)
     if rehearsal:
         local_rank %= torch.cuda.device_count()
@@ -525,9 +518,7 @@ def main():
 
     # ---- the engine: one context at N = 1, the C ABI's device group (RCCL) at N > 1 -------------------------------------
     group, group_error, rccl = None, None, None
-    if world > 1 and host_staged:
-        rccl = {"ranks": None, "version": None, "via": "REHEARSAL on gloo, gathers staged through the host - not a measurement"}
-    elif world > 1:
+    if world > 1:
         uid = [mgpu.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0, device=ctl)
         try:
@@ -543,18 +534,14 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok) == 0:
             # The product's gather is pmx_mgpu_all_gather_dev.  A run that cannot form the device group is a failed run, not a
-            # run on another code path - unless the caller asked for the torch.distributed gather explicitly.
-            if group is not None:      # all ranks take the same path
+            # run on another code path.
+            if group is not None:      # all ranks leave together
                 group.close()
                 group = None
-            if not args.allow_torch_gather:
-                sys.stderr.write("rank %d: the C ABI's device group could not be formed on every rank (%s); "
-                                 "--allow-torch-gather would gather through torch.distributed instead\n" % (rank, group_error or "another rank failed"))
-                dist.barrier()
-                dist.destroy_process_group()
-                sys.exit(4)
-            rccl = {"ranks": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
-                    "via": "torch.distributed, by --allow-torch-gather (the C ABI's device group failed: %s)" % (group_error or "on another rank")}
+            sys.stderr.write("rank %d: the C ABI's device group could not be formed on every rank (%s)\n" % (rank, group_error or "another rank failed"))
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(4)
     ctx = cfg.context(local_rank)
     if rank == 0:       # the issue slot at the dominant kernel's occupancy, measured before anything is timed
         early = _lib.PmxEngineInfo()
@@ -566,11 +553,6 @@ def main():
         stream = torch.cuda.ExternalStream(group.stream(0), device=dev)     # the library's stream of this device
     else:
         stream = torch.cuda.current_stream()
-
-    def torch_all_gather(local, out):
-        """The gather through torch.distributed (fallback / rehearsal): rank r's rows at r's span of `out`, ragged or not."""
-        from sponge_amd import distributed as D
-        D.all_gather_rows(local, out, host_staged=host_staged)
 
     def fresh_inputs():
         """this rank's shard of the global seeded input, uploaded (used for the timed buffers and again for the check)"""
@@ -621,9 +603,6 @@ def main():
                 group.merkle_2to1_dev([nodes.data_ptr()], [top.data_ptr()], n_total)
             else:
                 ctx.merkle_2to1_dev(nodes.data_ptr(), n, stream.cuda_stream)
-                if world > 1:
-                    torch_all_gather(nodes[2 * n - 2:2 * n - 1], top[:world])          # 32-byte subtree roots
-                    ctx.merkle_2to1_dev(top.data_ptr(), world, stream.cuda_stream)
 
         def final_gather():
             pass
@@ -634,10 +613,7 @@ def main():
         units_per_step = float(n_total)
 
         def gather_now(src):
-            if group is not None:
-                group.all_gather_dev([src.data_ptr()], [gathered.data_ptr()], n_total, t)
-            else:
-                torch_all_gather(src, gathered)
+            group.all_gather_dev([src.data_ptr()], [gathered.data_ptr()], n_total, t)      # (world > 1: the device group exists)
 
         def step(i):
             if group is not None:
@@ -807,6 +783,12 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
         # (the issue slot is 4: one wave instruction per 16 lanes x 4 passes)
         "clock_normalised": clock_normalised(kernel_s, peak.shader_clock_hz, peak.compute_units, units_per_step / max(world, 1), valu_issue),
         "gather_ms": 1e3 * (dev_s - steps_s) if world > 1 else None,
+        # what the final gather should take if every peer's shard arrives over its own xGMI link at the link's rate (MI355X: 7 links x
+        # ~153 GB/s per GPU, point to point): one shard's bytes / 153 GB/s, for up to 8 GPUs of one node - the first multi-GPU run judges
+        # itself against this (tools/first_8gpu_run.sh prints both)
+        "gather_ms_predicted": (1e3 * (n * t * 32) / 153e9 if (world > 1 and not merkle and not hashing and not duplex and args.gather != "none") else None),
+        "gather_model": ("one ncclAllGather of %d shards of %d bytes; every GPU receives %d of them, each over its own xGMI link (153 GB/s per link and direction)"
+                         % (world, n * t * 32, world - 1)) if (world > 1 and not merkle and not hashing and not duplex and args.gather != "none") else None,
     }
     if launcher:
         out["config"]["launcher"] = launcher
@@ -894,11 +876,6 @@ def run_verification(env):
             group.merkle_2to1_dev([nodes.data_ptr()], [top.data_ptr()], n_total)
         else:
             ctx.merkle_2to1_dev(nodes.data_ptr(), n, stream.cuda_stream)
-            if world > 1:
-                torch.cuda.synchronize()
-                env["torch_all_gather"](nodes[2 * n - 2:2 * n - 1], top[:world])
-                torch.cuda.synchronize()
-                ctx.merkle_2to1_dev(top.data_ptr(), world, stream.cuda_stream)
         torch.cuda.synchronize()
         got = to_np(nodes)
         ok = True
@@ -931,11 +908,7 @@ def run_verification(env):
         else:
             ctx.permute_batch_dev(fresh.data_ptr(), n, stream.cuda_stream)
         if world > 1 and gathered is not None:
-            if group is not None:
-                group.all_gather_dev([fresh.data_ptr()], [gathered.data_ptr()], n_total, t)
-            else:
-                torch.cuda.synchronize()
-                env["torch_all_gather"](fresh, gathered)
+            group.all_gather_dev([fresh.data_ptr()], [gathered.data_ptr()], n_total, t)
             torch.cuda.synchronize()
             ok, checked = True, 0
             for r in range(world):               # every rank checks every shard of ITS copy of the gathered result

@@ -155,13 +155,7 @@ extern "C" int pmx_ctx_create(const pmx_config *cfg, int device, pmx_ctx **out) 
     d.n_const_words = (uint32_t)pp.consts.size();
     d.mds_offset = (uint32_t)pp.mds_offset;
     d.opt_offset = (uint32_t)pp.opt_offset;
-    d.opt_full_offset = (uint32_t)pp.opt_full_offset;
-    d.opt_sparse_offset = (uint32_t)pp.opt_sparse_offset;
-    d.opt_bdense_offset = (uint32_t)pp.opt_bdense_offset;
     d.coop_offset = (uint32_t)pp.coop_offset;
-    d.tab_full_offset = (uint32_t)pp.tab_full_offset;
-    d.tab_sparse_offset = (uint32_t)pp.tab_sparse_offset;
-    d.tab_bdense_offset = (uint32_t)pp.tab_bdense_offset;
     d.mfma_offset = (uint32_t)pp.mfma_offset;
     d.mfma_dense = pp.mfma_dense ? 1u : 0u;
     d.win_offset = (uint32_t)pp.win_offset;
@@ -453,6 +447,26 @@ static bool is_pinned(const void *p) {
     return attr.type == hipMemoryTypeHost;
 }
 
+// A pageable buffer of a large call is page-locked for the length of the call (hipHostRegister: 4.2 ms for the 96 MiB of 2^20 t = 3
+// states, unregister 0.1 ms - profiles/r06/g_host_path_probe.txt) so that it takes the same pipeline: 7 ms instead of the 8 ... 20 ms of the
+// runtime's own staging through bounce buffers.  A registration that fails (locked-memory limit, a range that is not plain memory) leaves
+// the buffer as it is and the call takes the single-chunk path.
+struct ScopedPin {
+    void *ptr = nullptr;
+    ScopedPin(const void *p, size_t bytes) {
+        if (p && bytes >= kMinBytes && !is_pinned(p)) {
+            if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) ptr = const_cast<void *>(p);
+            else (void)hipGetLastError();
+        }
+    }
+    ~ScopedPin() {
+        if (ptr && hipHostUnregister(ptr) != hipSuccess) (void)hipGetLastError();
+    }
+    ScopedPin(const ScopedPin &) = delete;
+    ScopedPin &operator=(const ScopedPin &) = delete;
+    static constexpr size_t kMinBytes = (size_t)16 << 20;   // below this the registration costs more than it saves
+};
+
 // chunks of a batch for the pinned pipeline: rows per chunk (multiple of 256), at most 8 chunks
 static size_t pipeline_rows(size_t n) {
     if (n < ((size_t)1 << 16)) return n;
@@ -483,6 +497,7 @@ extern "C" int pmx_permute_batch(pmx_ctx *ctx, uint64_t *states, size_t n) {
     if ((rc = batch_bytes(n, ctx->t, &bytes))) return rc;
     void *d = nullptr;
     if ((rc = ctx_scratch(ctx, 0, bytes, &d))) return rc;
+    ScopedPin pin(states, bytes);   // (declared in front of the drain: unregistered only after the drain has found the streams idle)
     StreamDrain drain{ctx};
     const size_t step = is_pinned(states) ? pipeline_rows(n) : n;   // pinned: upload / kernel / download overlap, both directions at once
     return host_pipeline(
@@ -529,6 +544,7 @@ extern "C" int pmx_hash_batch(pmx_ctx *ctx, const uint64_t *in, size_t in_len, u
     void *d_in = nullptr, *d_out = nullptr;
     if ((rc = ctx_scratch(ctx, 0, in_bytes, &d_in))) return rc;
     if ((rc = ctx_scratch(ctx, 1, out_bytes, &d_out))) return rc;
+    ScopedPin pin_in(in, in_bytes), pin_out(out, out_bytes);   // (in front of the drain: see pmx_permute_batch)
     StreamDrain drain{ctx};
     const size_t in_row = in_len * 32, out_row = out_len * 32;
     const size_t step = ((!in_bytes || is_pinned(in)) && (!out_bytes || is_pinned(out))) ? pipeline_rows(n) : n;

@@ -5,16 +5,16 @@
 // 16-B-per-lane contiguous stream, whatever t is.  Round constants and the MDS matrix are wave-uniform.
 // Arithmetic: pmx_field.hpp (unsaturated 9 x 29-bit Montgomery form); round schedule: pmx_permute.hpp.
 //
-// Engines (same interface: load_states / store_states / get / set / zero / permute):
-//   RegEngine<3, ALPHA, OPT, TAB>  t = 3: state in VGPRs, element loops unrolled; round constants staged in LDS, the
-//                              matrices of the optimised schedule as shifted tables through the scalar cache (TAB).
-//   HybridEngine<T, ALPHA>     t = 4..9 on the optimised schedule: state in VGPRs, the element loops of the full
-//                              rounds rolled through one LDS scratch array per wave, tables via the scalar cache
-//                              (shifted tables for everything at t <= 5, for the identity lanes above).
-//   LdsEngine<ALPHA>           any width at run time (t = 2, 10..16, or no partial section): state kept in LDS as
-//                              [element][limb][lane] (conflict-free 4-byte accesses), element loops rolled.
+// Engines (same interface: load_states / store_states / get / set / zero / permute), one per regime:
 //   QuadEngine<ALPHA>          t = 3, launches of <= 32768 units (latency-bound: narrow tree levels, a handful of sponges):
 //                              one state per quad of lanes, sparse rounds three multiplications deep.
+//   HybridEngine<T, ALPHA>     t = 3..9 on the optimised schedule: state in VGPRs, the element loop of the full rounds' S-boxes rolled
+//                              through one LDS scratch array per wave, EVERY product by a constant a layer on the matrix cores
+//                              (pmx_mfma.hpp: the dense layers, and the partial rounds as windows closed by one layer each).
+//   LdsEngine<ALPHA>           any width at run time (t = 2, 10..16, no partial section, a zero in the schedule's algebra): the
+//                              reference's dense schedule, state kept in LDS as [element][limb][lane], element loops rolled.
+// (Rounds 1-5 also had a register engine for t = 3 and VALU-row forms of the hybrid engine; they went in round 6, when every modulus
+// got its int8 tables.)
 //
 // Reference semantics implemented here (file:line in /root/reference):
 //   permute        src/poseidon/mod.rs:95-118   (apply_ark :76-80, apply_s_box :63-74, apply_mds :82-93)
@@ -44,198 +44,37 @@ namespace pmx {
 extern __shared__ uint4 pmx_lds[];  // dynamic LDS, 16-byte granules
 
 // ------------------------------------------------------------------------------------------------
-// RegEngine: t known at compile time, state in registers (internal field form).
-// LDS: [constants: n_const_words u32, rounded up to 16 B][staging: kThreads * T * 2 uint4]
+// HybridEngine: t = 3..9 on the optimised schedule, every product by a constant on the matrix cores (pmx_mfma.hpp): the dense layers
+// and, as windows of t S-boxes per layer, the linear part of the partial rounds.  State in registers (9 t VGPRs); every wave has one
+// LDS scratch array [element][limb][lane] (2.25 (t - 1) KiB) that gives the rolled S-box loop of the full rounds and the layers' output
+// rows their dynamic indexing (pmx_permute.hpp: permute_hybrid) and doubles as the staging area of the coalesced ABI store.
+// Wave-uniform kernels only (permute, hash, compress, and the passes of the absorb / squeeze driver, which ARE permutation launches:
+// inside a per-lane loop not every lane is active, and the lane exchange of the rows needs both lanes of a pair).
+// (Rounds 1-4 also had this engine with VALU rows and sparse partial rounds, and a register engine for t = 3; since round 6 every config
+// that has the optimised schedule has the window tables - any modulus - and the rest runs on the run-time-width engine.)
 // ------------------------------------------------------------------------------------------------
-// Workgroup of the t = 3 register engine: one wave per SIMD of a CU (A/B, round 2: 128 threads -6 % on C2 / hash / tree - the waves land
-// unevenly on the SIMDs -, 512 threads -0.3 % C2, -3 % tree).  Its large-batch (table) kernels and its absorb / squeeze kernels are held to
-// four waves per SIMD (left alone the allocator took 140 / 160 VGPRs for the drivers: absorb +4 %, squeeze +10 % when held to 128; round 3).
-// The round constants are staged in LDS (broadcast reads) - scalar loads from global memory were 1.2 % faster on C2 in one session, within
-// what one box differs from the next - and the modulus stays in SGPRs (in vector registers: 46 -> 42 SGPR spills, C2 +-0, hash -1.3 %).
-constexpr int kRegThreads = 256, kRegTabMinWaves = 4, kRegDriverMinWaves = 4;
-template <int T, int ALPHA, bool OPT, bool TAB = false>
-struct RegEngine {
-    static_assert(OPT || !TAB, "shifted tables exist for the optimised schedule");
-    static constexpr int kThreads = kRegThreads;
-    // the large-batch (table) kernels live on four waves per SIMD: held to 128 VGPRs (left alone the allocator has taken
-    // anything between 105 and 138 for the same source); the element-form kernels serve launches that cannot fill the chip
-    static constexpr int kMinWaves = TAB ? kRegTabMinWaves : 1, kMinWavesDriver = kRegDriverMinWaves;
-    static constexpr bool kWaveUniformOnly = false;   // permute() may be called under a partial EXEC mask (per-lane driver kernels)
-    static constexpr int kChunks = 2 * T;  // 16-byte chunks per ABI state
-
-    Fe s[T];
-    Rounds c;
-    FieldRt f;
-    Fe one;
-    OptTables tb;         // constants (LDS or global)
-    uint4 *stage;         // LDS staging for coalesced state I/O
-
-    // words of the constant table staged in LDS: [ark' | full | sparse | bdense] of the optimised schedule - only ark'
-    // when its matrices are shifted tables, which stream through the scalar cache - or [ark | mds] of the dense one
-    __host__ __device__ __forceinline__ static uint32_t first_word(const DevConfig &d) { return OPT ? d.opt_offset : 0; }
-    __host__ __device__ __forceinline__ static uint32_t last_word(const DevConfig &d) { return TAB ? d.opt_full_offset : OPT ? d.coop_offset : d.opt_offset; }
-
-    static size_t lds_bytes(const DevConfig &d, uint32_t /*t*/) {
-        return (size_t)((last_word(d) - first_word(d) + 3) / 4) * 16 + (size_t)kThreads * kChunks * 16;
-    }
-
-    __device__ __forceinline__ RegEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
-        f.io = consts + d.io_offset;
-        const uint32_t w0 = first_word(d);
-        const uint32_t const_chunks = (last_word(d) - w0 + 3) / 4;
-        const uint4 *g = reinterpret_cast<const uint4 *>(consts + w0);   // offsets are multiples of 12 words = 48 B
-        for (uint32_t q = threadIdx.x; q < const_chunks; q += kThreads) pmx_lds[q] = g[q];
-        const uint32_t *base = reinterpret_cast<const uint32_t *>(pmx_lds) - w0;
-        stage = pmx_lds + const_chunks;
-        __syncthreads();
-        tb.tab_full = consts + d.tab_full_offset;
-        tb.tab_sparse = consts + d.tab_sparse_offset;
-        tb.tab_bdense = consts + d.tab_bdense_offset;
-        if constexpr (OPT) {
-            tb.ark = base + d.opt_offset;
-            tb.full = base + d.opt_full_offset;     // (the element tables past ark' are staged only when !TAB, and only read then)
-            tb.sparse = base + d.opt_sparse_offset;
-            tb.bdense = base + d.opt_bdense_offset;
-            tb.mds = nullptr;
-        } else {
-            tb.ark = base;
-            tb.mds = base + d.mds_offset;
-            tb.full = nullptr;
-            tb.sparse = nullptr;
-            tb.bdense = nullptr;
-        }
-    }
-
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int i = 0; i < T; ++i) s[i] = fe_zero();
-    }
-
-    // ABI <-> internal: the optimised schedule works in coordinates in which the ABI residue is the internal form (no
-    // multiplication, pmx_field.hpp: fe_from_abi_scaled); the dense schedule converts exactly
-    __device__ __forceinline__ Fe from_abi(const Abi &x) const {
-        if constexpr (OPT) return fe_from_abi_scaled(x);
-        else return fe_from_abi(x, f);
-    }
-    __device__ __forceinline__ Abi to_abi(const Fe &x) const {
-        if constexpr (OPT) return fe_to_abi_scaled(x, f);
-        else return fe_to_abi(x, f);
-    }
-
-    // The block's kThreads states are contiguous in global memory: copy them as one linear stream.
-    __device__ __forceinline__ void load_states(const uint64_t *g_states, size_t n) {
-        const size_t first = (size_t)blockIdx.x * kThreads;
-        const size_t valid = n > first ? (n - first < (size_t)kThreads ? n - first : (size_t)kThreads) : 0;
-        const uint4 *g = reinterpret_cast<const uint4 *>(g_states) + first * kChunks;
-        const uint32_t n_chunks = (uint32_t)valid * kChunks;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kChunks; ++k) {
-            const uint32_t q = threadIdx.x + k * kThreads;
-            if (q < n_chunks) stage[q] = g[q];
-        }
-        __syncthreads();
-        if (threadIdx.x < valid) {
-#pragma unroll
-            for (int i = 0; i < T; ++i)
-                s[i] = from_abi(abi_from_u4(stage[threadIdx.x * kChunks + 2 * i], stage[threadIdx.x * kChunks + 2 * i + 1]));
-        } else {
-            zero();
-        }
-    }
-
-    __device__ __forceinline__ void store_states(uint64_t *g_states, size_t n) {
-        const size_t first = (size_t)blockIdx.x * kThreads;
-        const size_t valid = n > first ? (n - first < (size_t)kThreads ? n - first : (size_t)kThreads) : 0;
-        uint4 *g = reinterpret_cast<uint4 *>(g_states) + first * kChunks;
-        const uint32_t n_chunks = (uint32_t)valid * kChunks;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            const Abi a = to_abi(s[i]);
-            stage[threadIdx.x * kChunks + 2 * i] = abi_lo(a);
-            stage[threadIdx.x * kChunks + 2 * i + 1] = abi_hi(a);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kChunks; ++k) {
-            const uint32_t q = threadIdx.x + k * kThreads;
-            if (q < n_chunks) g[q] = stage[q];
-        }
-    }
-
-    // element i of this lane's state; i may differ between lanes
-    __device__ __forceinline__ Fe get(uint32_t i) const {
-        Fe r = s[0];
-#pragma unroll
-        for (int k = 1; k < T; ++k) {
-#pragma unroll
-            for (int w = 0; w < kN; ++w) r.l[w] = (i == (uint32_t)k) ? s[k].l[w] : r.l[w];
-        }
-        return r;
-    }
-    __device__ __forceinline__ void set(uint32_t i, const Fe &v) {
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-#pragma unroll
-            for (int w = 0; w < kN; ++w) s[k].l[w] = (i == (uint32_t)k) ? v.l[w] : s[k].l[w];
-        }
-    }
-
-    static void describe(EngineInfo &o) {
-        std::snprintf(o.engine, sizeof o.engine, "RegEngine<%d,%d,%s>", T, ALPHA, TAB ? "opt,tab" : OPT ? "opt" : "dense");
-        o.threads = kThreads;
-        o.optimised = OPT;
-        o.row_tables = o.lane_tables = TAB;
-        o.mfma_dense = 0;
-    }
-
-    // lanes [want_lo, want_hi) of the result are all the caller will read (see permute_opt); default: the whole state
-    __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T, bool /*lane0_zero*/ = false) {
-        if constexpr (TAB) permute_opt_tab<T, ALPHA>(s, tb, c, one, f, want_lo, want_hi);
-        else if constexpr (OPT) permute_opt<T, ALPHA>(s, tb, c, one, f, want_lo, want_hi);
-        else permute_dense<T, ALPHA>(s, tb.ark, tb.mds, c, one, f);
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// HybridEngine: t = 4..9 on the optimised schedule.  State in registers (9t VGPRs); one wave per workgroup
-// with one LDS scratch array [element][limb][lane] (2.25 t KiB) that gives the rolled element loops of the full
-// rounds their dynamic indexing (pmx_permute.hpp: permute_hybrid) and doubles as the staging area of the
-// coalesced ABI load/store.  Constants come through the scalar cache (the table is up to 80 KiB at t = 9).
-// ------------------------------------------------------------------------------------------------
-// One wave per workgroup for the VALU-row engines, each wave with its own LDS region (four-wave workgroups - co-resident waves in the
-// same round, sharing its table lines in the scalar cache - were measured: C3 -0.6 %, t = 9 hash +0.7 %: the s_waitcnt time of those
-// kernels is not a cache-capacity effect).  Register bounds of the VALU-row engines: t = 4 (133 VGPRs when left alone) held to 128, four
-// waves per SIMD, +3.8 %; t = 5, 6 three waves (t = 6, 176 VGPRs left alone, +6 % when held to 168); t = 7, 8, 9 spill and lose
-// 23 / 46 / 68 % when held to three (round 3 A/B).
-constexpr int kHybWaves = 1, kHyb4WaveMaxT = 4, kHyb3WaveMaxT = 6;
-// MFMA: every product by a constant runs on the matrix cores (pmx_mfma.hpp) - the dense layers and, as windows of t S-boxes
-// per layer, the linear part of the partial rounds.  Wave-uniform kernels only (permute, hash, compress, and the passes of the absorb / squeeze driver, which ARE permutation
-// launches: inside a per-lane loop not every lane is active, and the lane exchange of this path needs both lanes of a pair).
-// Register bounds of the matrix-core engines (their byte strings and sums want registers), measured per width:
+// Register bounds (their byte strings and sums want registers), measured per width:
 #ifndef PMX_MFMA_4WAVE_MAX_T
-#define PMX_MFMA_4WAVE_MAX_T 3   // (t = 3: 123 / 125 VGPRs since the 32-byte elements of round 5 - four waves without a spill; it was 151 before)
+#define PMX_MFMA_4WAVE_MAX_T 3   // (t = 3: 120 VGPRs - four waves per SIMD without a spill)
 #endif
 #ifndef PMX_MFMA_3WAVE_MAX_T
 #define PMX_MFMA_3WAVE_MAX_T 5
 #endif
 // Four waves per workgroup (one per SIMD), two workgroups per CU at t = 9 (8 x 18 KiB of scratch).  Since round 6 the rows' tables are
 // streamed by every wave for itself (pmx_mfma.hpp: no LDS tile, no workgroup barrier inside the permutation); the workgroup only shares
-// the barriers of the state load / store staging.  (One wave per workgroup was measured: +-0, profiles/r06/b_ab_*.)
+// the barriers of the state store staging.  (One wave per workgroup was measured: +-0, profiles/r06/b_ab_*.)
 constexpr int kMfmaWaves = 4;
-template <int T, int ALPHA, bool MFMA = false>
+template <int T, int ALPHA>
 struct HybridEngine {
-    static constexpr int kWaves = MFMA ? kMfmaWaves : kHybWaves;
+    static_assert(T >= PMX_MFMA_MIN_T && T <= PMX_MFMA_MAX_T && mfma_window_for(T) > 0, "the window engines cover t = 3 .. 9");
+    static constexpr int kWaves = kMfmaWaves;
     static constexpr int kThreads = 64 * kWaves;
     // waves per SIMD the register allocation must allow (4: <= 128 VGPRs, 3: <= 168, 2: <= 256)
-    static constexpr int kMinWaves = MFMA ? (T <= PMX_MFMA_4WAVE_MAX_T ? 4 : T <= PMX_MFMA_3WAVE_MAX_T ? 3 : 2)
-                                          : (T <= kHyb4WaveMaxT ? 4 : T <= kHyb3WaveMaxT ? 3 : 2);
-    static constexpr int kMinWavesDriver = 2;   // absorb / squeeze kernels (per-lane modes: more live state) spill under the tighter bounds
-    // the matrix-core rows exchange operands between the lanes of a pair (l, l + 32): permute() must be reached by every lane of the
-    // wave - never from a per-lane loop (absorb_kernel / squeeze_kernel static_assert on this; the drivers of these widths run as
-    // passes, sponge_first_kernel)
-    static constexpr bool kWaveUniformOnly = MFMA;
+    static constexpr int kMinWaves = T <= PMX_MFMA_4WAVE_MAX_T ? 4 : T <= PMX_MFMA_3WAVE_MAX_T ? 3 : 2;
+    static constexpr int kMinWavesDriver = 2;   // (the pass kernels carry the driver's walk around the permutation: held to two waves)
+    // the rows exchange operands between the lanes of a pair (l, l + 32): permute() must be reached by every lane of the wave - never
+    // from a per-lane loop (absorb_kernel / squeeze_kernel static_assert on this; the drivers run as passes, sponge_first_kernel)
+    static constexpr bool kWaveUniformOnly = true;
     static constexpr int kChunks = 2 * T;
     // one wave's LDS region: scratch slots for elements 0..T-2 (2304 B each) or the ABI staging of its 64 states
     // (2048 T B), whichever is larger
@@ -269,14 +108,7 @@ struct HybridEngine {
 
     __device__ __forceinline__ HybridEngine(const DevConfig &d, const uint32_t *consts) : c(d.rounds), f(d.field), one(d.one) {
         f.io = consts + d.io_offset;
-        tb.mds = consts + d.mds_offset;
         tb.ark = consts + d.opt_offset;
-        tb.full = consts + d.opt_full_offset;
-        tb.sparse = consts + d.opt_sparse_offset;
-        tb.bdense = consts + d.opt_bdense_offset;
-        tb.tab_full = consts + d.tab_full_offset;
-        tb.tab_sparse = consts + d.tab_sparse_offset;
-        tb.tab_bdense = consts + d.tab_bdense_offset;
         tb.mfma = consts + d.mfma_offset;
         tb.win = consts + d.win_offset;
         lane = threadIdx.x & 63;
@@ -287,7 +119,7 @@ struct HybridEngine {
     __device__ __forceinline__ void zero() {
         static_for<0, T>([&](auto i) { s[i] = fe_zero(); });
     }
-    __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi_scaled(x); }      // optimised schedule: see RegEngine
+    __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi_scaled(x); }      // the optimised schedule carries the ABI residue as its internal form (pmx_field.hpp: fe_from_abi_scaled)
     __device__ __forceinline__ Abi to_abi(const Fe &x) const { return fe_to_abi_scaled(x, f); }
 
     // widths whose permute kernel otherwise keeps spills inside the rounds read their elements in a rolled loop (t = 6 at three waves per
@@ -431,15 +263,13 @@ struct HybridEngine {
     }
 
     static void describe(EngineInfo &o) {
-        if (MFMA && mfma_window_for(T) > 0) std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,mfma,windows of %d>", T, ALPHA, mfma_window_for(T));
-        else std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,%s>", T, ALPHA, MFMA ? "mfma" : "valu");
+        std::snprintf(o.engine, sizeof o.engine, "HybridEngine<%d,%d,mfma,windows of %d>", T, ALPHA, mfma_window_for(T));
         o.threads = kThreads;
         o.optimised = 1;
-        // (window engines: the only rows left are the history terms of the S-box inputs - 1: shifted tables on the VALU, 2: rows on the matrix cores)
-        o.row_tables = (MFMA && mfma_window_for(T) > 0) ? (mfma_hist_tab(T) ? 1 : 2) : (T <= kHybridTabMaxT);
-        o.lane_tables = 1;   // (the identity lanes of the VALU-row engines take shifted tables at every width)
-        o.mfma_dense = MFMA;
-        o.partial_window = MFMA ? mfma_window_for(T) : 0;
+        o.row_tables = mfma_hist_tab(T) ? 1 : 2;   // how the history terms of the S-box inputs are formed: 1 shifted table on the VALU (t = 3), 2 rows on the matrix cores
+        o.lane_tables = 0;
+        o.mfma_dense = 1;
+        o.partial_window = mfma_window_for(T);
     }
 
     __device__ __forceinline__ Fe get(uint32_t i) const {
@@ -459,7 +289,7 @@ struct HybridEngine {
 
     // lane0_zero: the caller knows lane 0 of the state is zero (pmx_permute.hpp: the window engines skip its round-0 S-box)
     __device__ __forceinline__ void permute(uint32_t want_lo = 0, uint32_t want_hi = T, bool lane0_zero = false) {
-        permute_hybrid<T, ALPHA, Scratch, MFMA, MFMA ? mfma_window_for(T) : 0>(s, sc, tb, c, one, f, want_lo, want_hi, lane0_zero);
+        permute_hybrid<T, ALPHA, Scratch, mfma_window_for(T)>(s, sc, tb, c, one, f, want_lo, want_hi, lane0_zero);
     }
 };
 
@@ -782,7 +612,7 @@ struct QuadEngine {
         s = fe_zero();
     }
 
-    __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi_scaled(x); }      // optimised schedule: see RegEngine
+    __device__ __forceinline__ Fe from_abi(const Abi &x) const { return fe_from_abi_scaled(x); }      // the optimised schedule carries the ABI residue as its internal form (pmx_field.hpp: fe_from_abi_scaled)
     __device__ __forceinline__ Abi to_abi(const Fe &x) const { return fe_to_abi_scaled(x, f); }
 
     // element held by lane `lane` of this quad, in every lane
@@ -1206,6 +1036,7 @@ __global__ void __launch_bounds__(Engine::kThreads, Engine::kMinWaves)
 template <class Engine>
 struct Launch {
     static int grid(size_t n) { return (int)((n + Engine::kThreads - 1) / Engine::kThreads); }
+    static size_t lds(const DevConfig &c, uint32_t t) { return Engine::lds_bytes(c, t); }
     // more than 64 KiB of dynamic LDS has to be asked for per kernel (and device)
     template <class K>
     static void allow_lds(K kernel, size_t bytes) {
@@ -1294,24 +1125,20 @@ struct Launch {
 };
 
 #if PMX_TU == 99
-// ---- tuning aid (Makefile target asm1): ONE kernel of one hybrid engine, for reading its ISA and register report in seconds -------
+// ---- tuning aid (Makefile target asm1): ONE kernel of one window engine, for reading its ISA and register report in seconds ----------
 #if !defined(PMX_ONE_T) || !defined(PMX_ONE_ALPHA)
 #error "PMX_TU = 99 (make asm1) names its engine with -DPMX_ONE_T=<width> -DPMX_ONE_ALPHA=<5 | 0>"
 #endif
-template __global__ void permute_kernel<HybridEngine<PMX_ONE_T, PMX_ONE_ALPHA, true>>(const DevConfig, const uint32_t *__restrict__, uint64_t *__restrict__, size_t);
+template __global__ void permute_kernel<HybridEngine<PMX_ONE_T, PMX_ONE_ALPHA>>(const DevConfig, const uint32_t *__restrict__, uint64_t *__restrict__, size_t);
 #elif PMX_TU != 0
-// ---- hybrid family of this translation unit -------------------------------------------------------------------------
+// ---- window engines of this translation unit ------------------------------------------------------------------------
 // four translation units (they dominate the build time, so they compile in parallel): the exponent (1, 3: alpha = 5; 2, 4: any other) x the
-// widths (1, 2: t <= 6; 3, 4: t = 7..9).  The public launchers of TU 0 pick the half by t.
+// widths (1, 2: t = 3 .. 6; 3, 4: t = 7 .. 9).  The public launchers of TU 0 pick the half by t, after they have checked that the config
+// has the engine's tables (DevConfig::mfma_dense) and that its LDS fits the device.
 #if PMX_TU == 1 || PMX_TU == 3
 #define PMX_HYB_ALPHA 5
 #else
 #define PMX_HYB_ALPHA 0
-#endif
-#if PMX_TU == 1 || PMX_TU == 2
-#define PMX_HYB_NARROW 1
-#else
-#define PMX_HYB_NARROW 0
 #endif
 #if PMX_TU == 1
 #define PMX_HYB_NAME(op) hybrid5n_##op
@@ -1322,9 +1149,10 @@ template __global__ void permute_kernel<HybridEngine<PMX_ONE_T, PMX_ONE_ALPHA, t
 #else
 #define PMX_HYB_NAME(op) hybridgw_##op
 #endif
-#if PMX_HYB_NARROW
+#if PMX_TU == 1 || PMX_TU == 2
 #define PMX_HYB_DISPATCH(CALL)                                             \
     switch (t) {                                                           \
+        case 3: return Launch<HybridEngine<3, PMX_HYB_ALPHA>>::CALL;       \
         case 4: return Launch<HybridEngine<4, PMX_HYB_ALPHA>>::CALL;       \
         case 5: return Launch<HybridEngine<5, PMX_HYB_ALPHA>>::CALL;       \
         case 6: return Launch<HybridEngine<6, PMX_HYB_ALPHA>>::CALL;       \
@@ -1339,116 +1167,36 @@ template __global__ void permute_kernel<HybridEngine<PMX_ONE_T, PMX_ONE_ALPHA, t
         default: return hipErrorInvalidValue;                              \
     }
 #endif
-
-template <class Engine>
-static bool lds_fits_engine(const DevConfig &c, uint32_t t) { return Engine::lds_bytes(c, t) <= (size_t)c.max_lds_bytes; }
-// the wave-uniform kernels of the wide states: dense layers on the matrix cores when the config has their tables
-#define PMX_HYB_MFMA_CASE(W, CALL)                                                                      \
-    if (t == W && W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T && lds_fits_engine<HybridEngine<W, PMX_HYB_ALPHA, true>>(c, t)) \
-        return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::CALL;
-#if !PMX_HYB_NARROW
-#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(7, CALL) PMX_HYB_MFMA_CASE(8, CALL) PMX_HYB_MFMA_CASE(9, CALL)
-#elif PMX_MFMA_MIN_T <= 3   // t = 3 as well: device-filling launches (t3_mfma below), every exponent
-#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(3, CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
-#elif PMX_MFMA_MIN_T <= 4
-#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(4, CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
-#elif PMX_MFMA_MIN_T <= 5
-#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(5, CALL) PMX_HYB_MFMA_CASE(6, CALL)
-#elif PMX_MFMA_MIN_T <= 6
-#define PMX_HYB_MFMA_WIDTHS(CALL) PMX_HYB_MFMA_CASE(6, CALL)
-#else
-#define PMX_HYB_MFMA_WIDTHS(CALL)
-#endif
-#define PMX_HYB_MFMA(CALL)               \
-    do {                                 \
-        if (c.mfma_dense) {              \
-            PMX_HYB_MFMA_WIDTHS(CALL)    \
-        }                                \
-    } while (0)
-hipError_t PMX_HYB_NAME(permute)(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
-    PMX_HYB_MFMA(permute(c, t, states, n, st));
-    PMX_HYB_DISPATCH(permute(c, t, states, n, st));
-}
+hipError_t PMX_HYB_NAME(permute)(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) { PMX_HYB_DISPATCH(permute(c, t, states, n, st)); }
 hipError_t PMX_HYB_NAME(hash)(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                               size_t n, hipStream_t st) {
-    PMX_HYB_MFMA(hash(c, t, in, in_len, out, out_len, n, st));
     PMX_HYB_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
 }
 hipError_t PMX_HYB_NAME(compress)(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
-    PMX_HYB_MFMA(compress(c, t, in, out, n, st));
     PMX_HYB_DISPATCH(compress(c, t, in, out, n, st));
 }
-// absorb / squeeze: widths from PMX_HYB_PASS_MIN_T up run as passes on the permutation engine of their width (the matrix-core
-// one where the config has its tables) - measured against the per-lane-loop kernels in profiles/r04; below it the
-// per-lane-loop kernels absorb_kernel / squeeze_kernel.  (Set it to 10 for the round-3 behaviour.)
-#ifndef PMX_HYB_PASS_MIN_T
-#define PMX_HYB_PASS_MIN_T 4
-#endif
-template <int W>
-static bool hyb_use_mfma(const DevConfig &c, uint32_t t) {
-    if constexpr (W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T) return c.mfma_dense && lds_fits_engine<HybridEngine<W, PMX_HYB_ALPHA, true>>(c, t);
-    else return false;
-}
-template <int W, bool SQUEEZE>
-static hipError_t hyb_driver(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index, uint64_t *io, size_t len,
-                             size_t n, hipStream_t st, const PassScratch &scratch) {
-    if constexpr (W >= PMX_HYB_PASS_MIN_T) {
-        if constexpr (W >= PMX_MFMA_MIN_T && W <= PMX_MFMA_MAX_T) {
-            if (hyb_use_mfma<W>(c, t))
-                return Launch<HybridEngine<W, PMX_HYB_ALPHA, true>>::template sponge_passes<SQUEEZE>(c, t, states, tag, index, io, len, n, st, scratch);
-        }
-        return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::template sponge_passes<SQUEEZE>(c, t, states, tag, index, io, len, n, st, scratch);
-    } else {
-        if constexpr (SQUEEZE) return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::squeeze(c, t, states, tag, index, io, len, n, st);
-        else return Launch<HybridEngine<W, PMX_HYB_ALPHA>>::absorb(c, t, states, tag, index, io, len, n, st);
-    }
-}
-#if PMX_MFMA_MIN_T <= 3 && PMX_HYB_NARROW   // t = 3, device-filling calls (t3_mfma, which has checked the tables and the LDS): passes on the matrix-core engine
-#define PMX_HYB_DRIVER_T3(SQ, IO) \
-        case 3: return Launch<HybridEngine<3, PMX_HYB_ALPHA, true>>::template sponge_passes<SQ>(c, t, states, tag, index, IO, len, n, st, scratch);
-#else
-#define PMX_HYB_DRIVER_T3(SQ, IO)
-#endif
-#if PMX_HYB_NARROW
-#define PMX_HYB_DRIVER(SQ, IO)                                                     \
-    switch (t) {                                                                   \
-        PMX_HYB_DRIVER_T3(SQ, IO)                                                  \
-        case 4: return hyb_driver<4, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
-        case 5: return hyb_driver<5, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
-        case 6: return hyb_driver<6, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
-        default: return hipErrorInvalidValue;                                      \
-    }
-#else
-#define PMX_HYB_DRIVER(SQ, IO)                                                     \
-    switch (t) {                                                                   \
-        case 7: return hyb_driver<7, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
-        case 8: return hyb_driver<8, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
-        case 9: return hyb_driver<9, SQ>(c, t, states, tag, index, IO, len, n, st, scratch); \
-        default: return hipErrorInvalidValue;                                      \
-    }
-#endif
+// absorb / squeeze run as passes on the permutation engine of the width (pmx_sponge_plan.hpp)
 hipError_t PMX_HYB_NAME(absorb)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                                 const uint64_t *in, size_t len, size_t n, hipStream_t st, const PassScratch &scratch) {
-    PMX_HYB_DRIVER(false, const_cast<uint64_t *>(in));   // (the absorb form of the pass kernel only reads `io`)
+    uint64_t *io = const_cast<uint64_t *>(in);   // (the absorb form of the pass kernel only reads `io`)
+    PMX_HYB_DISPATCH(template sponge_passes<false>(c, t, states, tag, index, io, len, n, st, scratch));
 }
 hipError_t PMX_HYB_NAME(squeeze)(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                                  uint64_t *out, size_t len, size_t n, hipStream_t st, const PassScratch &scratch) {
-    PMX_HYB_DRIVER(true, out);
+    PMX_HYB_DISPATCH(template sponge_passes<true>(c, t, states, tag, index, out, len, n, st, scratch));
 }
-// pmx_ctx_engine_info for the hybrid family: the very conditions of the launchers above
+// LDS one workgroup of the width's engine asks for (the launchers of TU 0 compare it with the device's limit)
+size_t PMX_HYB_NAME(lds_bytes)(const DevConfig &c, uint32_t t) { PMX_HYB_DISPATCH(lds(c, t)); }
+// pmx_ctx_engine_info for the window engines
 hipError_t PMX_HYB_NAME(describe)(const DevConfig &c, uint32_t t, int op, size_t len, EngineInfo *o) {
-    const bool driver = op == PMX_OP_ABSORB || op == PMX_OP_SQUEEZE;
-    const bool passes = driver && ((int)t >= PMX_HYB_PASS_MIN_T || t == 3);   // (t = 3 comes here only for its pass driver: t3_mfma)
-    hipError_t e = hipErrorInvalidValue;
+    const bool passes = op == PMX_OP_ABSORB || op == PMX_OP_SQUEEZE;
     const int op_engine = passes ? PMX_OP_PERMUTE : op;        // a pass is the permutation engine's launch
     auto plain = [&]() -> hipError_t { PMX_HYB_DISPATCH(describe(c, t, op_engine, len, o)); };
-    auto fast = [&]() -> hipError_t { PMX_HYB_MFMA(describe(c, t, op_engine, len, o)); return hipErrorInvalidValue; };
-    if (!driver || passes) e = fast();
-    if (e != hipSuccess) e = plain();
+    const hipError_t e = plain();
     if (e == hipSuccess && passes) {
         const size_t passes_z = op == PMX_OP_SQUEEZE ? squeeze_passes(len, c.rounds.rate) : absorb_passes(len, c.rounds.rate);
-        const int passes = passes_z > 0x7fffffff ? 0x7fffffff : (int)passes_z;
-        o->launches = passes > 1 ? passes - 1 : passes;  // one launch per permutation a sponge of the batch can need
+        const int n_passes = passes_z > 0x7fffffff ? 0x7fffffff : (int)passes_z;
+        o->launches = n_passes > 1 ? n_passes - 1 : n_passes;  // one launch per permutation a sponge of the batch can need
         std::snprintf(o->engine + std::strlen(o->engine), sizeof o->engine - std::strlen(o->engine), " x passes");
     }
     return e;
@@ -1462,79 +1210,32 @@ hipError_t PMX_HYB_NAME(describe)(const DevConfig &c, uint32_t t, int op, size_t
     hipError_t P##compress(const DevConfig &, uint32_t, const uint64_t *, uint64_t *, size_t, hipStream_t);                      \
     hipError_t P##absorb(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, const uint64_t *, size_t, size_t, hipStream_t, const PassScratch &); \
     hipError_t P##squeeze(const DevConfig &, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint64_t *, size_t, size_t, hipStream_t, const PassScratch &); \
+    size_t P##lds_bytes(const DevConfig &, uint32_t);                                                                            \
     hipError_t P##describe(const DevConfig &, uint32_t, int, size_t, EngineInfo *);
 PMX_HYB_DECL(hybrid5n_)
 PMX_HYB_DECL(hybrid5w_)
 PMX_HYB_DECL(hybridgn_)
 PMX_HYB_DECL(hybridgw_)
-// the half of the hybrid family a width lives in (t <= 6 / t >= 7)
-#define PMX_HYB_HALVES(P)                                                                                                                    \
-    static hipError_t P##_permute(const DevConfig &c, uint32_t t, uint64_t *s, size_t n, hipStream_t st) {                                    \
-        return t <= 6 ? P##n_permute(c, t, s, n, st) : P##w_permute(c, t, s, n, st);                                                          \
-    }                                                                                                                                        \
-    static hipError_t P##_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t il, uint64_t *out, size_t ol, size_t n, hipStream_t st) { \
-        return t <= 6 ? P##n_hash(c, t, in, il, out, ol, n, st) : P##w_hash(c, t, in, il, out, ol, n, st);                                    \
-    }                                                                                                                                        \
-    static hipError_t P##_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {             \
-        return t <= 6 ? P##n_compress(c, t, in, out, n, st) : P##w_compress(c, t, in, out, n, st);                                            \
-    }                                                                                                                                        \
-    static hipError_t P##_absorb(const DevConfig &c, uint32_t t, uint64_t *s, uint32_t *tag, uint32_t *idx, const uint64_t *in, size_t len,   \
-                                 size_t n, hipStream_t st, const PassScratch &sc) {                                                           \
-        return t <= 6 ? P##n_absorb(c, t, s, tag, idx, in, len, n, st, sc) : P##w_absorb(c, t, s, tag, idx, in, len, n, st, sc);              \
-    }                                                                                                                                        \
-    static hipError_t P##_squeeze(const DevConfig &c, uint32_t t, uint64_t *s, uint32_t *tag, uint32_t *idx, uint64_t *out, size_t len,       \
-                                  size_t n, hipStream_t st, const PassScratch &sc) {                                                          \
-        return t <= 6 ? P##n_squeeze(c, t, s, tag, idx, out, len, n, st, sc) : P##w_squeeze(c, t, s, tag, idx, out, len, n, st, sc);          \
-    }                                                                                                                                        \
-    static hipError_t P##_describe(const DevConfig &c, uint32_t t, int op, size_t len, EngineInfo *o) {                                       \
-        return t <= 6 ? P##n_describe(c, t, op, len, o) : P##w_describe(c, t, op, len, o);                                                    \
-    }
-PMX_HYB_HALVES(hybrid5)
-PMX_HYB_HALVES(hybridg)
 
-// Engine choice: width 3 runs from registers, on the optimised schedule whenever its tables exist - with the matrices
-// as shifted tables (permute_opt_tab) for the two exponents that have a dedicated chain - (the dense schedule
-// remains for configs without a partial section); widths 4..9 (every rate of the reference's default
-// tables, src/test.rs:14-31) run on the register/LDS hybrid - alpha = 5 specialised, any other exponent on the
-// generic S-box; everything else uses the LDS-resident run-time-width engine.
-// alpha 5 and 17 have dedicated addition chains, other exponents share the generic S-box.
-// The register engine stages its round constants in LDS (144 B per round at t = 3, 576 B in the cooperative kernel):
-// configs with hundreds of rounds do not fit a workgroup's LDS and take the run-time-width engine, whose constants
-// come through the scalar cache, instead of failing at launch.
-template <class Engine>
-static bool lds_fits(const DevConfig &c, uint32_t t) { return Engine::lds_bytes(c, t) <= (size_t)c.max_lds_bytes; }
-
-#define PMX_DISPATCH(CALL)                                                                  \
-    do {                                                                                    \
-        const uint64_t alpha = c.rounds.alpha;                                              \
-        if (t == 3 && c.has_opt && lds_fits<RegEngine<3, 0, true, true>>(c, t)) {           \
-            if (alpha == 5) return Launch<RegEngine<3, 5, true, true>>::CALL;               \
-            if (alpha == 17) return Launch<RegEngine<3, 17, true, true>>::CALL;             \
-            return Launch<RegEngine<3, 0, true, true>>::CALL;                               \
-        }                                                                                   \
-        if (t == 3 && !c.has_opt && lds_fits<RegEngine<3, 0, false>>(c, t))                 \
-            return Launch<RegEngine<3, 0, false>>::CALL;                                    \
-        if (c.has_opt && t >= 4 && t <= 9) {                                                \
-            if (alpha == 5) return hybrid5_##CALL;                                          \
-            return hybridg_##CALL;                                                          \
-        }                                                                                   \
-        if (alpha == 5) return Launch<LdsEngine<5>>::CALL;                                  \
-        if (alpha == 17) return Launch<LdsEngine<17>>::CALL;                                \
-        return Launch<LdsEngine<0>>::CALL;                                                  \
-    } while (0)
-
-// The shifted tables trade multiplies for a constant stream, and a stream needs a second wave on the SIMD to hide
-// behind: measured per launch at t = 3, the table form wins from 2^17 states up (permute; 2^18 for compress), below
-// that - fewer than two waves per SIMD - the element form is 7-25 % faster (lone-wave latency 0.145 vs 0.16 ms).
-static constexpr size_t kTabMinPermute = (size_t)1 << 17, kTabMinCompress = (size_t)1 << 18;
-
-// t = 3, alpha 5 / 17, fewer than `limit` units: the element-form engine
-#define PMX_SMALL_BATCH(LIMIT, CALL)                                                                 \
-    do {                                                                                             \
-        if (t == 3 && c.has_opt && n < (LIMIT) && lds_fits<RegEngine<3, 5, true, false>>(c, t)) {   \
-            if (c.rounds.alpha == 5) return Launch<RegEngine<3, 5, true, false>>::CALL;              \
-            if (c.rounds.alpha == 17) return Launch<RegEngine<3, 17, true, false>>::CALL;            \
-        }                                                                                            \
+// Engine choice (round 6: three engines, one per regime - the register engine of t = 3 and the VALU-row hybrids of rounds 1-4 are gone):
+//   QuadEngine     t = 3, at most 32768 units: one state per quad of lanes - the call is one permutation's latency
+//   HybridEngine   t = 3 .. 9, configs that have the window tables (DevConfig::mfma_dense: the optimised schedule exists, at least two
+//                  full rounds, the window algebra meets no zero - every config of the reference's tables, any modulus): alpha = 5
+//                  specialised, any other exponent on the generic S-box; absorb / squeeze as passes
+//   LdsEngine      everything else (t = 2, t >= 10, no partial section, a zero in the algebra): run-time width, the reference's dense schedule
+// alpha 5 and 17 have dedicated addition chains in the quad and run-time-width engines, other exponents share the generic S-box.
+static bool window_engine(const DevConfig &c, uint32_t t) {
+    if (!c.has_opt || !c.mfma_dense || t < (uint32_t)PMX_MFMA_MIN_T || t > (uint32_t)PMX_MFMA_MAX_T) return false;
+    const size_t lds = c.rounds.alpha == 5 ? (t <= 6 ? hybrid5n_lds_bytes(c, t) : hybrid5w_lds_bytes(c, t)) : (t <= 6 ? hybridgn_lds_bytes(c, t) : hybridgw_lds_bytes(c, t));
+    return lds <= (size_t)c.max_lds_bytes;
+}
+// the window engine of a width: the exponent's half of the family, then the width's
+#define PMX_WINDOW(CALL) (c.rounds.alpha == 5 ? (t <= 6 ? hybrid5n_##CALL : hybrid5w_##CALL) : (t <= 6 ? hybridgn_##CALL : hybridgw_##CALL))
+#define PMX_LDS_ENGINE(CALL)                                                 \
+    do {                                                                     \
+        if (c.rounds.alpha == 5) return Launch<LdsEngine<5>>::CALL;          \
+        if (c.rounds.alpha == 17) return Launch<LdsEngine<17>>::CALL;        \
+        return Launch<LdsEngine<0>>::CALL;                                   \
     } while (0)
 
 // the quad engine's table exists (t = 3, optimised schedule) and fits LDS; the lane of each element is fixed by the
@@ -1544,10 +1245,10 @@ static bool quad_table(const DevConfig &c, uint32_t t) {
 }
 static bool quad_shape(const DevConfig &c, uint32_t t) { return quad_table(c, t) && c.rounds.capacity == 1 && c.rounds.rate == 2; }
 
-// Small batches are latency: the quad engine up to this many states / rows / sponges (one dependent chain of 32 k instead
-// of 58-67 k instructions: 0.066 instead of 0.145 ms up to 4096 states, 0.078 at 2^14, 0.132 vs 0.151 at 2^15; above, the
-// one-lane kernels fill the chip better).
-static constexpr size_t kQuadMaxSponges = 32768;
+// Small batches are latency: the quad engine up to this many states / rows / sponges / compressions (one dependent chain of 32 k
+// instead of 55 k instructions: 0.066 ms up to 4096 states, 0.078 at 2^14, 0.132 at 2^15; above, the one-lane-per-state engine fills the
+// chip better - profiles/r05/v_ab_t3_engine_threshold_32769.txt, w_ab_quad_kernels_up_to_16384_only_not_kept.txt).
+static constexpr size_t kQuadMaxUnits = 32768;
 #define PMX_QUAD_LAUNCH(KERNEL, ...)                                                                                        \
     do {                                                                                                                    \
         const dim3 grid_((unsigned)((n + 63) / 64));                                                                        \
@@ -1557,75 +1258,34 @@ static constexpr size_t kQuadMaxSponges = 32768;
         return hipGetLastError();                                                                                           \
     } while (0)
 
-// t = 3 on the matrix cores as well (round 4): HybridEngine<3, alpha, mfma, windows of 3> - the dense layers and the partial rounds'
-// linear part as int8 GEMM layers, 42.1 k instead of 53.0 k VALU instructions per permutation at alpha = 5 - for configs that have the
-// tables (modulus rule of pmx_mfma.hpp): permute, hash, compress, and the absorb / squeeze drivers as passes on that engine (like the
-// wider states).  From PMX_T3_MFMA_MIN units up, i.e. everything above the quad kernels' range: since round 5's row finish the engine
-// has the shorter dependent chain as well - a lone wave per SIMD finishes a permutation in 0.114 ms against the register engine's
-// 0.129 (hash rows 0.219 / 0.265, the absorb(4) + squeeze(3) driver 0.48 / 0.55, a tree level of 65536 compressions 0.108 / 0.126:
-// profiles/r05/v_ab_t3_engine_threshold_32769.txt; the threshold was 2^17 while the register engine was the faster one alone on a SIMD).
-// Every exponent (round 5): the window rewrite does not depend on alpha, only the S-box does - alpha = 5 on its dedicated chain,
-// anything else (17: the reference's own rate-2 default, src/test.rs:15; 257: its weights table, :23-31) on the generic S-box,
-// like the wider states.  If the engine's LDS does not fit the device the register engine keeps the call (launch and describe alike).
-#ifndef PMX_T3_MFMA_MIN
-#define PMX_T3_MFMA_MIN ((size_t)32769)
-#endif
-static bool t3_mfma(const DevConfig &c, uint32_t t, size_t n) {
-    return PMX_MFMA_MIN_T <= 3 && t == 3 && c.has_opt && c.mfma_dense && n >= PMX_T3_MFMA_MIN && lds_fits<HybridEngine<3, 5, true>>(c, t);
-}
-// the hybrid family's half by exponent, as PMX_DISPATCH picks it for the wider states
-#define PMX_T3_MFMA(CALL) (c.rounds.alpha == 5 ? hybrid5_##CALL : hybridg_##CALL)
 hipError_t launch_permute(const DevConfig &c, uint32_t t, uint64_t *states, size_t n, hipStream_t st) {
-    if (quad_table(c, t) && n <= kQuadMaxSponges) PMX_QUAD_LAUNCH(permute_quad_kernel, states, n);
-    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(permute(c, t, states, n, st));
-    PMX_SMALL_BATCH(kTabMinPermute, permute(c, t, states, n, st));
-    PMX_DISPATCH(permute(c, t, states, n, st));
+    if (quad_table(c, t) && n <= kQuadMaxUnits) PMX_QUAD_LAUNCH(permute_quad_kernel, states, n);
+    if (window_engine(c, t)) return PMX_WINDOW(permute(c, t, states, n, st));
+    PMX_LDS_ENGINE(permute(c, t, states, n, st));
 }
 hipError_t launch_hash(const DevConfig &c, uint32_t t, const uint64_t *in, size_t in_len, uint64_t *out, size_t out_len,
                        size_t n, hipStream_t st) {
-    if (quad_shape(c, t) && n <= kQuadMaxSponges) PMX_QUAD_LAUNCH(hash_quad_kernel, in, in_len, out, out_len, n);
-    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(hash(c, t, in, in_len, out, out_len, n, st));
-    PMX_SMALL_BATCH(kTabMinPermute, hash(c, t, in, in_len, out, out_len, n, st));
-    PMX_DISPATCH(hash(c, t, in, in_len, out, out_len, n, st));
+    if (quad_shape(c, t) && n <= kQuadMaxUnits) PMX_QUAD_LAUNCH(hash_quad_kernel, in, in_len, out, out_len, n);
+    if (window_engine(c, t)) return PMX_WINDOW(hash(c, t, in, in_len, out, out_len, n, st));
+    PMX_LDS_ENGINE(hash(c, t, in, in_len, out, out_len, n, st));
 }
-
-// Levels of at most this many compressions run on the cooperative kernel: the one-lane-per-state kernel has at most
-// half a wave per SIMD there and is bound by the 51k-multiply dependent chain of a single permutation (0.145 ms),
-// while the quad kernel's chain is 23k multiplies (0.067 ms alone on a SIMD, 0.12 ms with two waves per SIMD at 32768
-// compressions; A/B at 16384 vs 32768 on a 2^21-leaf tree: 4.70 vs 4.65 ms).
-static constexpr size_t kCoopMaxUnits = 32768;
-
-template <int ALPHA>
-static hipError_t launch_compress_coop(const DevConfig &c, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(compress_coop_kernel<ALPHA>, dim3((unsigned)((n + 63) / 64)), dim3(256), QuadEngine<ALPHA>::lds_bytes(c), st, c, c.consts, in, out, n);
-    return hipGetLastError();
-}
-
 hipError_t launch_compress(const DevConfig &c, uint32_t t, const uint64_t *in, uint64_t *out, size_t n, hipStream_t st) {
-    // (the split (rate 3, capacity 0) of the same width takes the one-lane-per-state kernel at every level)
-    if (quad_shape(c, t) && n <= kCoopMaxUnits) {
-        if (c.rounds.alpha == 5) return launch_compress_coop<5>(c, in, out, n, st);
-        if (c.rounds.alpha == 17) return launch_compress_coop<17>(c, in, out, n, st);
-        return launch_compress_coop<0>(c, in, out, n, st);
-    }
-    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(compress(c, t, in, out, n, st));
-    PMX_SMALL_BATCH(kTabMinCompress, compress(c, t, in, out, n, st));
-    PMX_DISPATCH(compress(c, t, in, out, n, st));
+    // (the split (rate 3, capacity 0) of the same width takes the one-lane-per-state engine at every level)
+    if (quad_shape(c, t) && n <= kQuadMaxUnits) PMX_QUAD_LAUNCH(compress_coop_kernel, in, out, n);
+    if (window_engine(c, t)) return PMX_WINDOW(compress(c, t, in, out, n, st));
+    PMX_LDS_ENGINE(compress(c, t, in, out, n, st));
 }
-
 hipError_t launch_absorb(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                          const uint64_t *in, size_t in_len, size_t n, hipStream_t st, const PassScratch &scratch) {
-    if (quad_shape(c, t) && n <= kQuadMaxSponges) PMX_QUAD_LAUNCH(absorb_quad_kernel, states, tag, index, in, in_len, n);
-    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
-    PMX_SMALL_BATCH(kTabMinPermute, absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
-    PMX_DISPATCH(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
+    if (quad_shape(c, t) && n <= kQuadMaxUnits) PMX_QUAD_LAUNCH(absorb_quad_kernel, states, tag, index, in, in_len, n);
+    if (window_engine(c, t)) return PMX_WINDOW(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
+    PMX_LDS_ENGINE(absorb(c, t, states, tag, index, in, in_len, n, st, scratch));
 }
 hipError_t launch_squeeze(const DevConfig &c, uint32_t t, uint64_t *states, uint32_t *tag, uint32_t *index,
                           uint64_t *out, size_t out_len, size_t n, hipStream_t st, const PassScratch &scratch) {
-    if (quad_shape(c, t) && n <= kQuadMaxSponges) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
-    if (t3_mfma(c, t, n)) return PMX_T3_MFMA(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
-    PMX_SMALL_BATCH(kTabMinPermute, squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
-    PMX_DISPATCH(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
+    if (quad_shape(c, t) && n <= kQuadMaxUnits) PMX_QUAD_LAUNCH(squeeze_quad_kernel, states, tag, index, out, out_len, n);
+    if (window_engine(c, t)) return PMX_WINDOW(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
+    PMX_LDS_ENGINE(squeeze(c, t, states, tag, index, out, out_len, n, st, scratch));
 }
 
 // ---- pmx_ctx_engine_info: the same conditions, describing instead of launching ------------------------------------------
@@ -1643,26 +1303,19 @@ hipError_t describe_launch(const DevConfig &c, uint32_t t, int op, size_t n, siz
     o->width = (int)t;
     switch (op) {
         case PMX_OP_PERMUTE:
-            if (quad_table(c, t) && n <= kQuadMaxSponges) return describe_quad(c, o);
-            if (t3_mfma(c, t, n)) return PMX_T3_MFMA(describe(c, t, op, len, o));
-            PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
+            if (quad_table(c, t) && n <= kQuadMaxUnits) return describe_quad(c, o);
             break;
         case PMX_OP_HASH:
         case PMX_OP_ABSORB:
         case PMX_OP_SQUEEZE:
-            if (quad_shape(c, t) && n <= kQuadMaxSponges) return describe_quad(c, o);
-            if (t3_mfma(c, t, n)) return PMX_T3_MFMA(describe(c, t, op, len, o));
-            PMX_SMALL_BATCH(kTabMinPermute, describe(c, t, op, len, o));
-            break;
         case PMX_OP_COMPRESS:
-            if (quad_shape(c, t) && n <= kCoopMaxUnits) return describe_quad(c, o);
-            if (t3_mfma(c, t, n)) return PMX_T3_MFMA(describe(c, t, op, len, o));
-            PMX_SMALL_BATCH(kTabMinCompress, describe(c, t, op, len, o));
+            if (quad_shape(c, t) && n <= kQuadMaxUnits) return describe_quad(c, o);
             break;
         default:
             return hipErrorInvalidValue;
     }
-    PMX_DISPATCH(describe(c, t, op, len, o));
+    if (window_engine(c, t)) return PMX_WINDOW(describe(c, t, op, len, o));
+    PMX_LDS_ENGINE(describe(c, t, op, len, o));
 }
 
 // ---- authentication paths (pmx_merkle_verify_paths_dev) --------------------------------------------------------------

@@ -15,8 +15,9 @@
 //   * multiplication and reduction are interleaved column by column (one live accumulator), the chain of a
 //     column seeded with the carry of the previous one (the build disables LLVM's Reassociate pass, which would
 //     undo that - csrc/Makefile);
-//   * products by CONSTANTS (every multiplication of the permutation except the S-box) go through shifted
-//     tables - nine precomputed residues per constant, 81 + 18 multiplies instead of 81 + 81 (tab_dot below).
+//   * products by CONSTANTS (every multiplication of the permutation except the S-box) are layers on the matrix cores (pmx_mfma.hpp);
+//     the one such product left on the VALU - the history term of a t = 3 window - takes a shifted table: nine precomputed residues
+//     of the constant, 81 + 18 multiplies instead of 81 + 81 (tab_lanes_stream below).
 //
 // ABI form (4 x u64 = 8 x u32 limbs, x * 2^256 mod p, fully reduced - ark-ff's Fp<MontBackend<_,4>,4>)
 // is converted on load (x2^256 -> x2^261: one Montgomery product with 2^266 mod p) and on store (one
@@ -31,7 +32,7 @@
 //   fe_add_lazy      inputs norm -> output lazy, B = Ba + Bb
 //   column sums      <= 27 products (one side lazy) + 9 reduction products + carry  < 2^64;  table products: <= 6
 //                    normalised terms of 9 products + 2 reduction products + carry      (tests/test_hostcheck.py)
-//   tab_dot output   norm, B < 1 + 2^-20 (+ Bs with an addend)
+//   table product    norm, B < Bs + 1 + 2^-20 (s: the addend)
 // p < 2^255  =>  p / 2^261 < 2^-6: with every operand B <= 4, T <= 3 * 16 p^2 gives outputs B < 1.75.
 //
 // The same source compiles for the host so the algorithms are unit-tested on CPU against the oracle
@@ -64,14 +65,14 @@ constexpr int kFeStride = 12;                // u32 words per stored constant (9
 
 // Scheduling fence (device only): nothing is moved across it by the machine scheduler.  Keeps the independent lane
 // updates of a wide state from being interleaved (t = 6, 8 spilled kilobytes to scratch without it) and bounds how
-// much of a constant stream is hoisted into SGPRs (tab_dot_stream).
+// much of a constant stream is hoisted into SGPRs (tab_lanes_stream).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PMX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define PMX_SCHED_FENCE() ((void)0)
 #endif
 
-// Fence for a software-pipelined constant stream (tab_dot_stream): sched_barrier alone only orders instructions that
+// Fence for a software-pipelined constant stream (tab_lanes_stream): sched_barrier alone only orders instructions that
 // have side effects - instruction selection is free to place the multiplies of every chunk after the last barrier,
 // which it does.  Passing the accumulator through an empty volatile asm with a memory clobber pins the multiplies
 // that produce it before the fence and the constant loads that follow it after.
@@ -111,7 +112,7 @@ struct Abi {
 struct FieldRt {
     uint32_t p[kN];       // modulus, 29-bit limbs
     uint32_t pinv;        // -p^-1 mod 2^29
-    uint32_t unit;        // 1, as a run-time value: x * unit + acc is a single v_mad_u64_u32 (mont_mul_add, tab_dot)
+    uint32_t unit;        // 1, as a run-time value: x * unit + acc is a single v_mad_u64_u32 (mont_mul_add, tab_col_end)
     const uint32_t *io;   // kIoWords words: [p as 8 x 32-bit limbs | 2^266 mod p | 2^256 mod p (9 x 29-bit limbs each)]
 };
 constexpr int kIoP32 = 0, kIoToInt = 8, kIoToAbi = 8 + kN, kIoWords = 28;
@@ -333,113 +334,23 @@ PMX_FN constexpr int tab_index(int i, int k, int j) {
 }
 
 // end of column k of a table product: the two reduction chains reach up to here, then either a Montgomery step
-// (k < 2) or a result limb (with the addend of the ADD form entering first)
-template <int G, bool ADD>
-PMX_FN void tab_col_end(int k, uint64_t (&acc)[G], uint32_t (&m)[kTabSteps], Fe &out, const Fe &s, const FieldRt &f) {
+// (k < 2) or a result limb (with the addend entering first): s norm, result norm with B < Bs + 1 + 2^-20
+PMX_FN void tab_col_end(int k, uint64_t &acc, uint32_t (&m)[kTabSteps], Fe &out, const Fe &s, const FieldRt &f) {
 #pragma unroll
     for (int q = 0; q < kTabSteps; ++q) {
-        if (q < k && k - q < kN) acc[0] += (uint64_t)m[q] * f.p[k - q];
+        if (q < k && k - q < kN) acc += (uint64_t)m[q] * f.p[k - q];
     }
-    if constexpr (G == 1) {
-        if (k < kTabSteps) {
-            m[k] = mont_step(acc[0], f);
-        } else {
-            if constexpr (ADD) acc[0] += (uint64_t)s.l[k - kTabSteps] * f.unit;
-            if (k < kN + kTabSteps - 1) {
-                out.l[k - kTabSteps] = (uint32_t)acc[0] & kMask;
-                acc[0] >>= kW;
-            } else {
-                out.l[k - kTabSteps] = (uint32_t)acc[0];
-            }
-        }
+    if (k < kTabSteps) {
+        m[k] = mont_step(acc, f);
     } else {
-        uint32_t low = ((uint32_t)acc[0] & kMask) + ((uint32_t)acc[1] & kMask);
-        if constexpr (ADD) {
-            if (k >= kTabSteps && k < kN + kTabSteps - 1) low += s.l[k - kTabSteps];   // three 29-bit values: < 2^31
-        }
-        const uint64_t carry = (acc[0] >> kW) + (acc[1] >> kW);
-        acc[1] = 0;
-        if (k < kTabSteps) {
-            m[k] = (low * f.pinv) & kMask;
-            const uint64_t v = (uint64_t)m[k] * f.p[0] + low;   // low 29 bits are zero
-            acc[0] = carry + (v >> kW);
-        } else if (k < kN + kTabSteps - 1) {
-            out.l[k - kTabSteps] = low & kMask;
-            acc[0] = carry + (low >> kW);
+        acc += (uint64_t)s.l[k - kTabSteps] * f.unit;
+        if (k < kN + kTabSteps - 1) {
+            out.l[k - kTabSteps] = (uint32_t)acc & kMask;
+            acc >>= kW;
         } else {
-            out.l[k - kTabSteps] = (uint32_t)acc[0];   // top limb: no products this high, acc[1] is empty
-            if constexpr (ADD) out.l[k - kTabSteps] += s.l[k - kTabSteps];
+            out.l[k - kTabSteps] = (uint32_t)acc;
         }
     }
-}
-
-template <int N, bool ADD>
-PMX_FN Fe tab_dot(const Fe *z, const uint32_t *tab, const Fe &s, const FieldRt &f) {
-
-    static_assert(N <= 12, "two accumulators");
-    constexpr int G = N <= 6 ? 1 : 2;
-    constexpr int kSplit = G == 1 ? N : (N + 1) / 2;   // terms [0, kSplit) -> acc[0], the rest -> acc[1]
-    uint32_t m[kTabSteps];
-    Fe out;
-    uint64_t acc[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = 0;
-#pragma unroll
-    for (int k = 0; k < kN + kTabSteps; ++k) {
-        if (k < kN) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-#pragma unroll
-                for (int j = 0; j < kN; ++j) acc[i < kSplit ? 0 : G - 1] += (uint64_t)z[i].l[j] * tab[tab_index<N>(i, k, j)];
-            }
-        }
-        tab_col_end<G, ADD>(k, acc, m, out, s, f);
-    }
-    return out;
-}
-
-// ---- the same products with the constant stream software-pipelined (wide states, 2-3 waves per SIMD) -----------
-// An N-term row consumes 81 N SGPR operands, one per multiply.  Left alone the compiler hoists as much of that
-// stream as it can and spills SGPRs to VGPR lanes by the thousand (v_readlane / v_writelane are VALU instructions).
-// Here the stream is cut into chunks of at most 27 words - three terms of one column of a row, or three columns of
-// a single product; the rows are laid out so that a chunk is contiguous - chunk c + 1 is loaded while chunk c is
-// multiplied, and a scheduling fence after every chunk stops anything else from moving up.
-
-template <int N, bool ADD = false>
-PMX_FN Fe tab_dot_stream(const Fe *z, const uint32_t *tab, const FieldRt &f, const Fe *addend = nullptr) {
-    constexpr int NG = (N + kTabChunk - 1) / kTabChunk;   // term groups per column
-    constexpr int G = N <= 6 ? 1 : 2;                     // groups 0, 1 -> acc[0] (<= 54 + 2 products), the rest -> acc[1]
-    static_assert(N <= 9, "two accumulators");
-    constexpr int kChunks = kN * NG;
-    uint32_t m[kTabSteps];
-    Fe out;
-    uint64_t acc[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = 0;
-    uint32_t buf[2][kTabChunk * kN];
-    auto load = [&](auto cc, uint32_t *b) {
-        constexpr int c = decltype(cc)::value, k = c / NG, g = c % NG;
-        constexpr int cnt = (N - kTabChunk * g) < kTabChunk ? (N - kTabChunk * g) : kTabChunk;
-#pragma unroll
-        for (int w = 0; w < cnt * kN; ++w) b[w] = tab[(k * NG + g) * kTabChunkWords + w];
-    };
-    load(std::integral_constant<int, 0>{}, buf[0]);
-    static_for<0, kChunks>([&](auto cc) {
-        constexpr int c = decltype(cc)::value, k = c / NG, g = c % NG;
-        constexpr int cnt = (N - kTabChunk * g) < kTabChunk ? (N - kTabChunk * g) : kTabChunk;
-        if constexpr (c + 1 < kChunks) load(std::integral_constant<int, c + 1>{}, buf[(c + 1) & 1]);
-#pragma unroll
-        for (int i = 0; i < cnt; ++i) {
-#pragma unroll
-            for (int j = 0; j < kN; ++j) acc[(G == 2 && g >= 2) ? 1 : 0] += (uint64_t)z[kTabChunk * g + i].l[j] * buf[c & 1][i * kN + j];
-        }
-        if constexpr (g == NG - 1) tab_col_end<G, ADD>(k, acc, m, out, ADD ? *addend : out, f);
-        if constexpr (G == 2) PMX_STREAM_FENCE(acc[1]);
-        PMX_STREAM_FENCE(acc[0]);
-    });
-#pragma unroll
-    for (int k = kN; k < kN + kTabSteps; ++k) tab_col_end<G, ADD>(k, acc, m, out, ADD ? *addend : out, f);
-    return out;
 }
 
 // s[l] <- s[l] + z0 * w_l for L single constants whose tables follow each other (the identity lanes of one sparse
@@ -450,7 +361,7 @@ PMX_FN void tab_lanes_stream(const Fe &z0, const uint32_t *tab, Fe *s, const Fie
     constexpr int kChunks = L * kParts;
     uint32_t m[kTabSteps];
     Fe out;
-    uint64_t acc[1] = {0};
+    uint64_t acc = 0;
     uint32_t buf[2][kTabChunk * kN];
     auto load = [&](auto cc, uint32_t *b) {
         constexpr int c = decltype(cc)::value;
@@ -464,16 +375,16 @@ PMX_FN void tab_lanes_stream(const Fe &z0, const uint32_t *tab, Fe *s, const Fie
 #pragma unroll
         for (int kk = 0; kk < kTabChunk; ++kk) {
 #pragma unroll
-            for (int j = 0; j < kN; ++j) acc[0] += (uint64_t)z0.l[j] * buf[c & 1][kk * kN + j];
-            tab_col_end<1, true>(kTabChunk * h + kk, acc, m, out, s[l], f);
+            for (int j = 0; j < kN; ++j) acc += (uint64_t)z0.l[j] * buf[c & 1][kk * kN + j];
+            tab_col_end(kTabChunk * h + kk, acc, m, out, s[l], f);
         }
         if constexpr (h == kParts - 1) {
 #pragma unroll
-            for (int k = kN; k < kN + kTabSteps; ++k) tab_col_end<1, true>(k, acc, m, out, s[l], f);
+            for (int k = kN; k < kN + kTabSteps; ++k) tab_col_end(k, acc, m, out, s[l], f);
             s[l] = out;
-            acc[0] = 0;
+            acc = 0;
         }
-        PMX_STREAM_FENCE(acc[0]);
+        PMX_STREAM_FENCE(acc);
     });
 }
 
@@ -496,22 +407,6 @@ PMX_FN void cols_mul_acc(Cols &t, const Fe &a, const Fe &b) {
     }
 }
 
-// the first term of a row: every column is WRITTEN by its first product instead of being zeroed and added to (the
-// zero-initialised accumulators were being hoisted above the preceding S-box and spilled: eight scratch accesses per
-// sparse round of the t = 9 permute kernel)
-PMX_FN void cols_mul_init(Cols &t, const Fe &a, const Fe &b) {
-#pragma unroll
-    for (int i = 0; i < kN; ++i) {
-#pragma unroll
-        for (int j = 0; j < kN; ++j) {
-            const int k = i + j;
-            if (i == (k > kN - 1 ? k - (kN - 1) : 0)) t.c[k] = (uint64_t)a.l[i] * b.l[j];
-            else t.c[k] += (uint64_t)a.l[i] * b.l[j];
-        }
-    }
-    t.c[2 * kN - 1] = 0;
-}
-
 // push every column's bits above 29 into the next column
 PMX_FN void cols_compress(Cols &t) {
 #pragma unroll
@@ -521,19 +416,9 @@ PMX_FN void cols_compress(Cols &t) {
     }
 }
 
-// the same for columns lo .. hi only (the ones a long dot product would overflow; matrix_row in pmx_permute.hpp)
-template <int LO, int HI>
-PMX_FN void cols_compress_range(Cols &t) {
-#pragma unroll
-    for (int k = LO; k <= HI; ++k) {
-        t.c[k + 1] += t.c[k] >> kW;
-        t.c[k] &= kMask;
-    }
-}
-
 // Montgomery reduction of 18 columns, compressed or not: column k is consumed as (carry from below + its own sum), so
 // the only requirement is that no column overflows 64 bits once its up to nine m_j p_i products and the carry (< 2^35)
-// are added - callers bound their column sums accordingly (matrix_row; tests/test_hostcheck.py replays the worst case).
+// are added - callers bound their column sums accordingly (permute_dense_rt; tests/test_hostcheck.py replays the worst case).
 // Norm result, B < value / (p 2^261) + 1.
 // ADD: + s, entering the upper columns (s * 2^261) on their way out - one multiply-by-one v_mad per limb, nothing live
 // before the reduction; s norm, B grows by Bs.

@@ -37,8 +37,7 @@ struct DevConfig {
     const uint32_t *consts;   // device; layout: pmx_prepare.hpp Prepared::consts
     uint32_t n_const_words;   // words in consts
     uint32_t mds_offset;      // word offsets inside consts
-    uint32_t opt_offset, opt_full_offset, opt_sparse_offset, opt_bdense_offset, coop_offset;
-    uint32_t tab_full_offset, tab_sparse_offset, tab_bdense_offset;   // shifted tables (pmx_field.hpp: tab_dot)
+    uint32_t opt_offset, coop_offset;   // ark' of the optimised schedule; the quad engine's table (t = 3)
     uint32_t mfma_offset;     // int8 tables of the dense layers (pmx_mfma.hpp); valid when mfma_dense
     uint32_t mfma_dense;      // 1: those tables exist (t and modulus qualify: pmx_prepare.hpp)
     uint32_t win_offset;      // window tables of the partial section (pmx_mfma.hpp); valid when mfma_dense and the width takes windows

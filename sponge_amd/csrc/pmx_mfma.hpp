@@ -2,7 +2,7 @@
 // t = 7..9) and - round 4 - the linear part of the partial rounds gathered into windows (below: PMX_MFMA_WINDOW), at every width from 3.
 //
 // A dense layer multiplies the state by a matrix of CONSTANTS: out_i = sum_j c_ij z_j.  On the VALU that is t rows of
-// 81 t + 81 limb products (pmx_permute.hpp: matrix_rows_rolled); here it is an int8 GEMM whose N dimension is the 64 states
+// 81 t + 81 limb products (rounds 1-3 did that); here it is an int8 GEMM whose N dimension is the 64 states
 // of the wave (one per lane), whose K dimension is the bytes of the state and whose M dimension is the bytes of the result:
 //
 //   * every element z_j a layer takes in is an S-box output (a Montgomery product: below 1.3 p) or a row of the layer before
@@ -11,7 +11,7 @@
 //     -12 ... -25 % products per row, 16 registers fewer at t = 9; the bound holds for every exponent: alpha = 1 is formed as the
 //     product x * 1, alpha = 0 is the constant 1 - pmx_field.hpp: fe_sbox);
 //   * for output row i the host stores Y_{j,b} = c_ij * 2^(8 b + 24) mod p in 32 BALANCED signed bytes y_e in [-128, 127]
-//     (pmx_prepare.hpp: put_mfma_layer; the modulus' top byte must be <= 126 for 32 of them to do), laid out as the A
+//     (pmx_prepare.hpp: put_mfma_layer; a residue above what 32 of them reach - moduli near 2^255 - is stored as Y - p), laid out as the A
 //     operand: 16 bytes per lane and k-step, lane l = row e (l & 31) and half (l >> 5) of the k-step;
 //   * MFMA bytes are signed, state bytes are not: they enter as u - 128 (one v_xor per register) and the host adds the
 //     constant 128 * sum_k Y_k back (per output row, as eight 64-bit word sums);
@@ -37,9 +37,7 @@ namespace pmx {
 
 // Widths whose dense layers go to the matrix cores.  A row costs ~85 VALU instructions of finish plus its share of the state's
 // re-cut (27 per element) and 2 t MFMA issue slots (58 clocks of the matrix pipe each), against 81 t + 81 multiplies and their carries on the VALU.
-#ifndef PMX_MFMA_MIN_T
-#define PMX_MFMA_MIN_T 3   // (10: the library never selects these engines nor builds their tables - INTEGRATION.md section 8)
-#endif
+#define PMX_MFMA_MIN_T 3
 #define PMX_MFMA_MAX_T 9   // (a row's mid-column budget and the 36 t / 32 k-steps are laid out for t <= 9)
 constexpr int kMfmaElemBytes = 32;   // K bytes per element: every input of a layer is below 2^256 (see above), one k-step each
 constexpr int kMfmaShift = 24;       // the tables hold c 2^(8 b + kMfmaShift): the row finish divides by 2^24 (one Montgomery step inside the word sums)
@@ -73,7 +71,7 @@ constexpr int kMfmaMaxInputs = PMX_MFMA_MAX_T - 1 + (PMX_MFMA_WINDOW < PMX_MFMA_
 static_assert(32 * kMfmaMaxInputs * 128 * 128 < (1 << 25), "a sum of byte products must stay inside the accumulator budget of mfma_row_acc");
 static_assert((unsigned long long)kMfmaMaxInputs * 32 * 255 < (1ull << kMfmaShift), "a row must stay below 2^256: n_in * 32 * 255 * p / 2^24 + p < 2 p");
 // The history terms of a window's S-box inputs, x_{k+1} - z_k = u_k + sum_{i<k} h_{k,i} z_i (k = 2 .. K - 1): at t = 3 - ONE term per window -
-// a product by a shifted table on the VALU (pmx_field.hpp: tab_dot; profiles/r04/q_ab_history_tables.txt), from t = 4 rows on the matrix
+// a product by a shifted table on the VALU (pmx_field.hpp: tab_lanes_stream; profiles/r04/q_ab_history_tables.txt), from t = 4 rows on the matrix
 // cores (below; profiles/r05/k_ab_history_rows_on_the_matrix_cores.txt, l_ab_history_rows_t4_t5.txt: t = 4 +1.8 %, 5 +3.7 %, 6 +6.3 %, 7 +4.7 %,
 // 8 +4.9 %, 9 +3.6 % over tables (t <= 5) / elements (t >= 6)).
 #ifndef PMX_MFMA_HIST_TAB_MAX_T
@@ -309,7 +307,7 @@ __device__ __forceinline__ void lane32_swap(uint32_t &x, uint32_t &y) {
 }
 
 // Rows [lo, hi) of the layer whose tables start at `layer` (global memory; mfma_layer_words(T) words); the other rows of s
-// come back unspecified, like matrix_rows_rolled.  s norm.  Every lane of the wave must be active.
+// come back unspecified.  s norm.  Every lane of the wave must be active.
 // General form: NIN input elements at `in`, rows [lo, hi) of NOUT into out (which may alias in: the inputs are consumed first).
 // the operand form of an element: its eight words, the second half handed to the partner lane (+-32) - lanes 32-63 of a product feed
 // the second half of every k-step for the states of lanes 0-31

@@ -2,6 +2,7 @@
 // round constants / MDS matrix rewritten into the internal field form (29-bit limbs, x * 2^261 mod p).
 // Shared by pmx_api.cpp (which uploads the table) and the CPU-side algorithm check in tests/hostcheck.
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,6 +39,7 @@ struct Prepared {
     //   [mds_offset, opt_offset)   mds      [t][t]
     //   -- only when has_opt (see pmx_permute.hpp: OptTables) --
     //   opt_offset                 ark'     [rounds][t]
+    //   -- t == 3 only: the element form of the optimised schedule's matrices, the source of the quad engine's table (coop) --
     //   opt_full_offset            full     [RF-1][t][t]     one matrix per full round except the entrance round
     //   opt_sparse_offset          sparse   [RP][2t-1]       layer 0 follows the entrance round, layer j partial round j-1
     //   opt_bdense_offset          bdense   [t][t]           layer after the last partial round
@@ -48,13 +50,6 @@ struct Prepared {
     //   -- only when has_opt and t == 3 (pmx_permute.hpp: cooperative schedule) --
     //   coop_offset                coop     [rounds][3][4]
     size_t coop_offset;
-    //   -- only when has_opt: shifted tables (pmx_field.hpp: tab_dot); R = tab_row_words(t) --
-    //   tab_full_offset            full     [RF-1][t] rows of R words (normalised rows: their t-1 constants c_1.. in the
-    //                                       tab_row_words(t-1) layout at the start of the row; last matrix: all t)
-    //   tab_sparse_offset          sparse   [RP] x (row 0 over its t-1 constants v: tab_row_words(t-1) words, then t-1 single
-    //                                       constants w of kTabOneWords)
-    //   tab_bdense_offset          bdense   [t] rows of R words (normalised)
-    size_t tab_full_offset, tab_sparse_offset, tab_bdense_offset;
     //   -- only when mfma_dense: the dense layers as int8 GEMM operands (pmx_mfma.hpp); RF - 1 layers of `full`, then bdense --
     //   mfma_offset                [RF][mfma_layer_words(t)]
     size_t mfma_offset;
@@ -75,26 +70,50 @@ inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in
     const size_t nq = (size_t)mfma_k_steps((int)n_in), row_words = (size_t)mfma_row_words((int)n_in);
     int8_t *bytes = reinterpret_cast<int8_t *>(dst);
     long long *corr = reinterpret_cast<long long *>(dst + n_out * row_words);
+    // 32 balanced digits reach from -128 S to 127 S, S = (256^32 - 1) / 255: every residue of a modulus whose top byte is at most 126,
+    // but not the residues above 127 S = 0.996 * 2^255 of a larger one (2^255 - 19).  Such a residue Y is stored as Y - p instead (congruent,
+    // above -2^255 > -128 S), and the row's correction takes 255 p for it - the term then contributes U Y + (255 - U) p for the state byte
+    // U in [0, 255]: non-negative, congruent, and at most 255 p like every other term, so every bound of pmx_mfma.hpp stands as it is
+    // (round 6; until then those moduli had no tables and ran on VALU rows).
     for (size_t i = 0; i < n_out; ++i) {
         long long colsum[32] = {0};
+        size_t negatives = 0;
         constexpr int shift = kMfmaShift;
         for (size_t j = 0; j < n_in; ++j) {
             U256 y = times_pow2(hf, hf.from_mont(rows[i * n_in + j]), shift);
             for (size_t b = 0; b < (size_t)kMfmaElemBytes; ++b) {   // (the inputs of a layer are below 2^256: pmx_mfma.hpp)
-                // balanced bytes of y: digit e in [-128, 127], carry into the next
-                unsigned carry = 0;
                 const size_t k = j * kMfmaElemBytes + b, q = k / 32, r = k % 32, h = r / 16, byte = r % 16;
-                for (size_t e = 0; e < 32; ++e) {
-                    int dgt = (int)((y.l[e / 8] >> (8 * (e % 8))) & 0xff) + (int)carry;
-                    carry = 0;
-                    if (dgt >= 128) {
-                        dgt -= 256;
-                        carry = 1;
+                // balanced bytes of the 256-bit pattern v: digit e in [-128, 127], carry into the next; returns the carry out of digit 31
+                auto digits = [&](const U256 &v, int8_t *out32) {
+                    unsigned carry = 0;
+                    for (size_t e = 0; e < 32; ++e) {
+                        int dgt = (int)((v.l[e / 8] >> (8 * (e % 8))) & 0xff) + (int)carry;
+                        carry = 0;
+                        if (dgt >= 128) {
+                            dgt -= 256;
+                            carry = 1;
+                        }
+                        out32[e] = (int8_t)dgt;
                     }
-                    bytes[(((i * nq + q) * 64 + 32 * h + e) * 16) + byte] = (int8_t)dgt;
-                    colsum[e] += dgt;
+                    return carry;
+                };
+                int8_t d32[32];
+                if (digits(y, d32)) {          // Y > 127 S: the digits of the two's-complement pattern of Y - p (its carry out is its sign)
+                    U256 neg;
+                    unsigned __int128 borrow = 0;
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned __int128 dif = (unsigned __int128)y.l[w] - hf.p.l[w] - borrow;
+                        neg.l[w] = (uint64_t)dif;
+                        borrow = (dif >> 64) & 1;
+                    }
+                    const unsigned sign = digits(neg, d32);
+                    if (!borrow || !sign) std::abort();   // (cannot happen: Y < p, and Y - p > -2^255 has 32 balanced digits)
+                    ++negatives;
                 }
-                // (carry out of byte 31 cannot happen: the caller admits only moduli whose top byte is <= 126)
+                for (size_t e = 0; e < 32; ++e) {
+                    bytes[(((i * nq + q) * 64 + 32 * h + e) * 16) + byte] = d32[e];
+                    colsum[e] += d32[e];
+                }
                 y = times_pow2(hf, y, 8);
             }
         }
@@ -104,7 +123,8 @@ inline void put_mfma_layer_io(const HostField &hf, const U256 *rows, size_t n_in
         for (size_t w = 0; w < 8; ++w) {
             long long v = 0;
             for (size_t tt = 0; tt < 4; ++tt) v += (128 * colsum[4 * w + tt]) * (1ll << (8 * tt));
-            corr[i * 8 + w] = v + (long long)((add.l[w / 2] >> (32 * (w % 2))) & 0xffffffffull);
+            const long long p_word = (long long)((hf.p.l[w / 2] >> (32 * (w % 2))) & 0xffffffffull);   // (negatives * 255 < 2^18: the product stays below 2^50)
+            corr[i * 8 + w] = v + (long long)((add.l[w / 2] >> (32 * (w % 2))) & 0xffffffffull) + (long long)(negatives * 255) * p_word;
         }
     }
 }
@@ -730,13 +750,18 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
         out.opt_offset = out.consts.size();
         out.opt_full_offset = out.opt_sparse_offset = out.opt_bdense_offset = out.opt_offset;
         if (out.has_opt) {
+            // ark' for every engine of the optimised schedule; the matrices in element form only where the quad engine's table is
+            // built from them (t = 3) - the window engines read the same matrices as int8 tables (below)
+            const bool elems = t == 3;
             out.opt_full_offset = out.opt_offset + n_ark * kFeStride;
-            out.opt_sparse_offset = out.opt_full_offset + src_full.size() * kFeStride;
-            out.opt_bdense_offset = out.opt_sparse_offset + src_sparse.size() * kFeStride;
-            out.consts.resize(out.opt_bdense_offset + src_bdense.size() * kFeStride, 0u);
+            out.opt_sparse_offset = out.opt_full_offset + (elems ? src_full.size() : 0) * kFeStride;
+            out.opt_bdense_offset = out.opt_sparse_offset + (elems ? src_sparse.size() : 0) * kFeStride;
+            out.consts.resize(out.opt_bdense_offset + (elems ? src_bdense.size() : 0) * kFeStride, 0u);
             size_t k = out.opt_offset / kFeStride;
-            for (const auto *vec : {&ark_opt, &src_full, &src_sparse, &src_bdense})
-                for (const U256 &v : *vec) to_limbs29(times_pow2(hf, v, 5), &out.consts[(k++) * kFeStride]);
+            for (const U256 &v : ark_opt) to_limbs29(times_pow2(hf, v, 5), &out.consts[(k++) * kFeStride]);
+            if (elems)
+                for (const auto *vec : {&src_full, &src_sparse, &src_bdense})
+                    for (const U256 &v : *vec) to_limbs29(times_pow2(hf, v, 5), &out.consts[(k++) * kFeStride]);
         }
     }
     // cooperative t = 3 table: per (round, lane): ark' element, then the lane's matrix row of that round
@@ -779,36 +804,11 @@ inline int prepare(const pmx_config *cfg, Prepared &out, std::string &err) {
             }
         }
     }
-    // shifted tables of every constant the optimised schedule multiplies by.  A normalised row (column 0 = ONE) is an
-    // addend plus a (t-1)-term dot product over c_1.., the last round's rows are t-term dot products; a sparse layer is its
-    // row 0 (t-1 terms) followed by t-1 single products.
-    out.tab_full_offset = out.tab_sparse_offset = out.tab_bdense_offset = out.consts.size();
-    if (out.has_opt) {
-        const size_t row = (size_t)tab_row_words((int)t), row0 = (size_t)tab_row_words((int)t - 1), per_round = (size_t)sparse_tab_words((int)t),
-                     src_per_round = 2 * t - 1;
-        const size_t n_sparse = src_sparse.size() / src_per_round;
-        out.tab_sparse_offset = out.tab_full_offset + n_full * t * row;
-        out.tab_bdense_offset = out.tab_sparse_offset + n_sparse * per_round;
-        out.consts.resize(out.tab_bdense_offset + t * row, 0u);
-        for (size_t o = 0; o < n_full; ++o) {
-            for (size_t i = 0; i < t; ++i) {
-                uint32_t *dst = &out.consts[out.tab_full_offset + (o * t + i) * row];
-                if (o + 1 == n_full) put_shifted_row(hf, &src_full[(o * t + i) * t], t, dst);             // last round: dense
-                else put_shifted_row(hf, &src_full[(o * t + i) * t + 1], t - 1, dst);                  // normalised: c_1 ..
-            }
-        }
-        for (size_t i = 0; i < t; ++i) put_shifted_row(hf, &src_bdense[i * t + 1], t - 1, &out.consts[out.tab_bdense_offset + i * row]);
-        for (size_t r = 0; r < n_sparse; ++r) {
-            uint32_t *dst = &out.consts[out.tab_sparse_offset + r * per_round];
-            put_shifted_row(hf, &src_sparse[r * src_per_round + 1], t - 1, dst);   // row 0 without its first entry (ONE: the addend)
-            for (size_t l = 0; l + 1 < t; ++l) put_shifted_row(hf, &src_sparse[r * src_per_round + t + l], 1, dst + row0 + l * kTabOneWords);
-        }
-    }
-    // dense layers of the widest states as int8 GEMM operands
+    // the dense layers as int8 GEMM operands
     while (out.consts.size() % 4) out.consts.push_back(0u);   // 16-byte operands
     out.mfma_offset = out.consts.size();
     // (a layer's inputs must be below 2^256: S-box outputs ARE products for every alpha - pmx_field.hpp: fe_sbox; p < 2^255 is a limit of the build)
-    out.mfma_dense = out.has_opt && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T && n_full >= 1 && (hf.p.l[3] >> 56) <= 126;
+    out.mfma_dense = out.has_opt && t >= PMX_MFMA_MIN_T && t <= PMX_MFMA_MAX_T && n_full >= 1;
     if (out.mfma_dense) {
         const size_t lw = (size_t)mfma_layer_words((int)t);
         out.consts.resize(out.mfma_offset + (n_full + 1) * lw, 0u);

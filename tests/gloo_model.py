@@ -1,11 +1,11 @@
-"""torch.distributed helpers around the sharded batch: one process per GPU (backend "nccl" = RCCL over xGMI on the GPU
-box, "gloo" in the CPU tests).  Sponge states are independent (reference src/poseidon/mod.rs:62-183 has no
-cross-state data flow), so the batch is cut into contiguous shards and there is NO collective on the data
-path; a collective is used only for the final gather of results (and for the 32-byte subtree roots of the Merkle mode).
+"""TEST SUPPORT (round 6: moved out of the package - nothing in the product or in bench.py uses it): a torch.distributed model of the
+sharded batch for the world-size-2 gloo tests on CPU (tests/test_distributed_gloo.py).  Sponge states are independent (reference
+src/poseidon/mod.rs:62-183 has no cross-state data flow), so the batch is cut into contiguous shards and there is NO collective on the
+data path; a collective is used only for the final gather of results (and for the 32-byte subtree roots of the Merkle mode).
 
-The product path for this is the C ABI's device group (pmx_mgpu_*, sponge_amd/mgpu.py), which talks to RCCL itself.
-What lives here is what bench.py falls back to if a group cannot be formed, what its single-GPU rehearsal uses, and
-what the world-size-2 gloo tests run on CPU.
+The product's multi-GPU path is the C ABI's device group (pmx_mgpu_*, sponge_amd/mgpu.py), which talks to RCCL itself and partitions
+with the same arithmetic (pmx_shard_bounds); these helpers restate that partition and the two gathers on torch.distributed so that the
+shard arithmetic and the gather layout can be exercised by real ranks where there is no GPU.
 """
 from __future__ import annotations
 

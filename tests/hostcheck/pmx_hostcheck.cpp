@@ -54,33 +54,6 @@ static Abi load_abi(const uint64_t *p) {
 }
 static void store_abi(uint64_t *p, const Abi &a) { std::memcpy(p, a.w, 32); }
 
-template <int T, bool TAB = false>
-static void permute_opt_t(const Prepared &pp, uint64_t *states, size_t n) {
-    OptTables tb;
-    tb.ark = pp.consts.data() + pp.opt_offset;
-    tb.mds = pp.consts.data() + pp.mds_offset;
-    tb.full = pp.consts.data() + pp.opt_full_offset;
-    tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
-    tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
-    tb.tab_full = pp.consts.data() + pp.tab_full_offset;
-    tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
-    tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
-    for (size_t k = 0; k < n; ++k) {
-        Fe s[T];
-        for (int i = 0; i < T; ++i) s[i] = fe_from_abi_scaled(load_abi(states + (k * T + i) * 4));
-        if constexpr (TAB) {
-            if (pp.c.alpha == 5) permute_opt_tab<T, 5>(s, tb, pp.c, pp.one, pp.f);
-            else if (pp.c.alpha == 17) permute_opt_tab<T, 17>(s, tb, pp.c, pp.one, pp.f);
-            else permute_opt_tab<T, 0>(s, tb, pp.c, pp.one, pp.f);
-        } else {
-            if (pp.c.alpha == 5) permute_opt<T, 5>(s, tb, pp.c, pp.one, pp.f);
-            else if (pp.c.alpha == 17) permute_opt<T, 17>(s, tb, pp.c, pp.one, pp.f);
-            else permute_opt<T, 0>(s, tb, pp.c, pp.one, pp.f);
-        }
-        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
-    }
-}
-
 // cooperative t = 3 schedule, the four lanes of a quad simulated in turn (lane 3: the squaring lane of the folded sparse
 // rounds; in the uniform rounds it only shadows lane 2)
 template <int ALPHA>
@@ -132,44 +105,13 @@ struct HostScratch {
     void set(uint32_t i, const Fe &x) { slot[i] = x; }
 };
 
-template <int T>
-static void permute_hybrid_t(const Prepared &pp, uint64_t *states, size_t n) {
-    OptTables tb;
-    tb.ark = pp.consts.data() + pp.opt_offset;
-    tb.mds = pp.consts.data() + pp.mds_offset;
-    tb.full = pp.consts.data() + pp.opt_full_offset;
-    tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
-    tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
-    tb.tab_full = pp.consts.data() + pp.tab_full_offset;
-    tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
-    tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
-    tb.mfma = nullptr;
-    tb.win = nullptr;
-    for (size_t k = 0; k < n; ++k) {
-        Fe s[T];
-        HostScratch<T> sc;
-        for (int i = 0; i < T; ++i) s[i] = fe_from_abi_scaled(load_abi(states + (k * T + i) * 4));
-        if (pp.c.alpha == 5) permute_hybrid<T, 5>(s, sc, tb, pp.c, pp.one, pp.f);
-        else if (pp.c.alpha == 17) permute_hybrid<T, 17>(s, sc, tb, pp.c, pp.one, pp.f);
-        else permute_hybrid<T, 0>(s, sc, tb, pp.c, pp.one, pp.f);
-        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
-    }
-}
-
-// The matrix-core form of the wide hybrids (HybridEngine<3..9, alpha, true>): the same round loop with its dense layers - and the
-// partial section as windows closed by one layer each (pmx_mfma.hpp: PMX_MFMA_WINDOW) - through pmx_mfma.hpp's tables, byte
-// strings and row finish; the GEMM itself as plain integer sums (no matrix cores on the host).
+// The window engines (HybridEngine<3..9, alpha>): the round loop of pmx_permute.hpp with its dense layers - and the partial section as
+// windows closed by one layer each (pmx_mfma.hpp: PMX_MFMA_WINDOW) - through pmx_mfma.hpp's tables, byte strings and row finish; the GEMM
+// itself as plain integer sums (no matrix cores on the host).
 template <int T>
 static int permute_hybrid_mfma_t(const Prepared &pp, uint64_t *states, size_t n) {
     OptTables tb;
     tb.ark = pp.consts.data() + pp.opt_offset;
-    tb.mds = pp.consts.data() + pp.mds_offset;
-    tb.full = pp.consts.data() + pp.opt_full_offset;
-    tb.sparse = pp.consts.data() + pp.opt_sparse_offset;
-    tb.bdense = pp.consts.data() + pp.opt_bdense_offset;
-    tb.tab_full = pp.consts.data() + pp.tab_full_offset;
-    tb.tab_sparse = pp.consts.data() + pp.tab_sparse_offset;
-    tb.tab_bdense = pp.consts.data() + pp.tab_bdense_offset;
     tb.mfma = pp.consts.data() + pp.mfma_offset;
     tb.win = pp.consts.data() + pp.win_offset;
     constexpr int KW = mfma_window_for(T);   // the partial section as windows when the width takes them
@@ -181,8 +123,8 @@ static int permute_hybrid_mfma_t(const Prepared &pp, uint64_t *states, size_t n)
         // a state whose lane 0 is zero takes the shortcut the compress / hash kernels take for a fresh sponge (lane0_zero)
         const uint64_t *lane0 = states + (k * T) * 4;
         const bool z0 = KW > 0 && !(lane0[0] | lane0[1] | lane0[2] | lane0[3]);
-        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, true, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, z0);
-        else permute_hybrid<T, 0, HostScratch<T>, true, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, z0);
+        if (pp.c.alpha == 5) permute_hybrid<T, 5, HostScratch<T>, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, z0);
+        else permute_hybrid<T, 0, HostScratch<T>, KW>(s, sc, tb, pp.c, pp.one, pp.f, 0, T, z0);
         for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi_scaled(s[i], pp.f));
     }
     return PMX_OK;
@@ -226,76 +168,6 @@ extern "C" int hc_window_small_history(const pmx_config *cfg, uint32_t out[5]) {
 // the window size this library was compiled with (tests build one library per size)
 extern "C" int hc_mfma_window(int t) { return mfma_window_for(t); }
 
-// register + scratch hybrid on the optimised schedule (what HybridEngine runs)
-extern "C" int hc_permute_hybrid(const pmx_config *cfg, uint64_t *states, size_t n) {
-    Prepared pp;
-    std::string err;
-    int rc = prepare(cfg, pp, err);
-    if (rc) return rc;
-    if (!pp.has_opt) return PMX_ERR_UNSUPPORTED;
-    switch (pp.t) {
-        case 3: permute_hybrid_t<3>(pp, states, n); break;
-        case 4: permute_hybrid_t<4>(pp, states, n); break;
-        case 5: permute_hybrid_t<5>(pp, states, n); break;
-        case 6: permute_hybrid_t<6>(pp, states, n); break;
-        case 7: permute_hybrid_t<7>(pp, states, n); break;
-        case 8: permute_hybrid_t<8>(pp, states, n); break;
-        case 9: permute_hybrid_t<9>(pp, states, n); break;
-        default: return PMX_ERR_UNSUPPORTED;
-    }
-    return PMX_OK;
-}
-
-// optimised (sparse partial rounds) schedule; PMX_ERR_UNSUPPORTED when the tables cannot be derived
-extern "C" int hc_permute_opt(const pmx_config *cfg, uint64_t *states, size_t n) {
-    Prepared pp;
-    std::string err;
-    int rc = prepare(cfg, pp, err);
-    if (rc) return rc;
-    if (!pp.has_opt) return PMX_ERR_UNSUPPORTED;
-    switch (pp.t) {
-        case 2: permute_opt_t<2>(pp, states, n); break;
-        case 3: permute_opt_t<3>(pp, states, n); break;
-        case 4: permute_opt_t<4>(pp, states, n); break;
-        case 5: permute_opt_t<5>(pp, states, n); break;
-        case 9: permute_opt_t<9>(pp, states, n); break;
-        default: return PMX_ERR_UNSUPPORTED;
-    }
-    return PMX_OK;
-}
-
-// the same schedule on shifted tables (permute_opt_tab)
-extern "C" int hc_permute_opt_tab(const pmx_config *cfg, uint64_t *states, size_t n) {
-    Prepared pp;
-    std::string err;
-    int rc = prepare(cfg, pp, err);
-    if (rc) return rc;
-    if (!pp.has_opt) return PMX_ERR_UNSUPPORTED;
-    switch (pp.t) {
-        case 2: permute_opt_t<2, true>(pp, states, n); break;
-        case 3: permute_opt_t<3, true>(pp, states, n); break;
-        case 4: permute_opt_t<4, true>(pp, states, n); break;
-        case 5: permute_opt_t<5, true>(pp, states, n); break;
-        case 9: permute_opt_t<9, true>(pp, states, n); break;
-        default: return PMX_ERR_UNSUPPORTED;
-    }
-    return PMX_OK;
-}
-
-template <int T>
-static void permute_t(const Prepared &pp, uint64_t *states, size_t n) {
-    const uint32_t *ark = pp.consts.data();
-    const uint32_t *mds = pp.consts.data() + pp.mds_offset;
-    for (size_t k = 0; k < n; ++k) {
-        Fe s[T];
-        for (int i = 0; i < T; ++i) s[i] = fe_from_abi(load_abi(states + (k * T + i) * 4), pp.f);
-        if (pp.c.alpha == 5) permute_dense<T, 5>(s, ark, mds, pp.c, pp.one, pp.f);
-        else if (pp.c.alpha == 17) permute_dense<T, 17>(s, ark, mds, pp.c, pp.one, pp.f);
-        else permute_dense<T, 0>(s, ark, mds, pp.c, pp.one, pp.f);
-        for (int i = 0; i < T; ++i) store_abi(states + (k * T + i) * 4, fe_to_abi(s[i], pp.f));
-    }
-}
-
 // run-time-width path (what LdsEngine runs), state in two plain arrays
 struct HostState {
     Fe cur[PMX_MAX_WIDTH], nxt[PMX_MAX_WIDTH];
@@ -324,21 +196,8 @@ extern "C" int hc_permute_rt(const pmx_config *cfg, uint64_t *states, size_t n) 
     return PMX_OK;
 }
 
-extern "C" int hc_permute(const pmx_config *cfg, uint64_t *states, size_t n) {
-    Prepared pp;
-    std::string err;
-    int rc = prepare(cfg, pp, err);
-    if (rc) return rc;
-    switch (pp.t) {
-        case 2: permute_t<2>(pp, states, n); break;
-        case 3: permute_t<3>(pp, states, n); break;
-        case 4: permute_t<4>(pp, states, n); break;
-        case 5: permute_t<5>(pp, states, n); break;
-        case 9: permute_t<9>(pp, states, n); break;
-        default: return PMX_ERR_UNSUPPORTED;
-    }
-    return PMX_OK;
-}
+// (the reference's dense schedule exists once, at run-time width: what LdsEngine runs)
+extern "C" int hc_permute(const pmx_config *cfg, uint64_t *states, size_t n) { return hc_permute_rt(cfg, states, n); }
 
 // op: 0 mul, 1 sqr(a), 2 dot3(a[0..3), b[0..3)), 3 round trip abi->internal->abi
 extern "C" int hc_field_op(const uint64_t modulus[4], int op, const uint64_t *a, const uint64_t *b, uint64_t *out) {
@@ -375,36 +234,24 @@ extern "C" int hc_field_op(const uint64_t modulus[4], int op, const uint64_t *a,
 // Products by constants through shifted tables (pmx_field.hpp: tab_dot and the streamed forms), checked one
 // operation at a time.  a: n variable elements, c: n constants (both ABI Montgomery), s: addend.
 //   form 0: tab_dot<n, false>          sum_i a_i * c_i            n in {1, 3, 6, 9}
-//   form 1: tab_dot<1, true>           a_0 * c_0 + s
-//   form 2: tab_dot_stream<n>          sum_i a_i * c_i            n in {3, 4, 9}
-//   form 3: tab_lanes_stream<n>        out_i = s_i + a_0 * c_i    n in {2, 8}   (s, out: n elements)
+// out_i = s_i + a * c_i for n single constants through shifted tables (tab_lanes_stream<n>: the history term of a t = 3 window is n = 1)
 template <int N>
-static void tab_case(const Prepared &pp, const HostField &hf, int form, const uint64_t *a, const uint64_t *c, const uint64_t *s, uint64_t *out) {
+static void tab_case(const Prepared &pp, const HostField &hf, const uint64_t *a, const uint64_t *c, const uint64_t *s, uint64_t *out) {
     const FieldRt &f = pp.f;
-    Fe z[N], add[N];
+    Fe add[N];
     U256 cm[N];
+    const Fe z = fe_from_abi(load_abi(a), f);
     for (int i = 0; i < N; ++i) {
-        z[i] = fe_from_abi(load_abi(a + 4 * (form == 3 ? 0 : i)), f);
-        add[i] = fe_from_abi(load_abi(s + 4 * (form == 3 ? i : 0)), f);
+        add[i] = fe_from_abi(load_abi(s + 4 * i), f);
         std::memcpy(cm[i].l, c + 4 * i, 32);
     }
-    if (form == 3) {
-        std::vector<uint32_t> tab((size_t)N * kTabOneWords, 0u);
-        for (int i = 0; i < N; ++i) put_shifted_row(hf, &cm[i], 1, &tab[(size_t)i * kTabOneWords]);
-        tab_lanes_stream<N>(z[0], tab.data(), add, f);
-        for (int i = 0; i < N; ++i) store_abi(out + 4 * i, fe_to_abi(add[i], f));
-        return;
-    }
-    std::vector<uint32_t> tab((size_t)tab_row_words(N), 0u);
-    put_shifted_row(hf, cm, N, tab.data());
-    Fe r;
-    if (form == 0) r = tab_dot<N, false>(z, tab.data(), add[0], f);
-    else if (form == 2) r = tab_dot_stream<N>(z, tab.data(), f);
-    else r = fe_zero();
-    store_abi(out, fe_to_abi(r, f));
+    std::vector<uint32_t> tab((size_t)N * kTabOneWords, 0u);
+    for (int i = 0; i < N; ++i) put_shifted_row(hf, &cm[i], 1, &tab[(size_t)i * kTabOneWords]);
+    tab_lanes_stream<N>(z, tab.data(), add, f);
+    for (int i = 0; i < N; ++i) store_abi(out + 4 * i, fe_to_abi(add[i], f));
 }
 
-extern "C" int hc_tab_op(const uint64_t modulus[4], int form, int n, const uint64_t *a, const uint64_t *c, const uint64_t *s, uint64_t *out) {
+extern "C" int hc_tab_op(const uint64_t modulus[4], int n, const uint64_t *a, const uint64_t *c, const uint64_t *s, uint64_t *out) {
     pmx_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     std::memcpy(cfg.modulus, modulus, 32);
@@ -415,22 +262,11 @@ extern "C" int hc_tab_op(const uint64_t modulus[4], int form, int n, const uint6
     std::string err;
     int rc = prepare(&cfg, pp, err);
     if (rc) return rc;
-    const HostField &hf = pp.hf;
-    if (form == 1 && n == 1) {
-        U256 cm;
-        std::memcpy(cm.l, c, 32);
-        std::vector<uint32_t> tab(kTabOneWords, 0u);
-        put_shifted_row(hf, &cm, 1, tab.data());
-        const Fe z = fe_from_abi(load_abi(a), pp.f), add = fe_from_abi(load_abi(s), pp.f);
-        store_abi(out, fe_to_abi(tab_dot<1, true>(&z, tab.data(), add, pp.f), pp.f));
-        return PMX_OK;
-    }
-#define PMX_TAB_CASE(F, N) if (form == (F) && n == (N)) { tab_case<N>(pp, hf, form, a, c, s, out); return PMX_OK; }
-    PMX_TAB_CASE(0, 1) PMX_TAB_CASE(0, 3) PMX_TAB_CASE(0, 6) PMX_TAB_CASE(0, 9)
-    PMX_TAB_CASE(2, 3) PMX_TAB_CASE(2, 4) PMX_TAB_CASE(2, 9)
-    PMX_TAB_CASE(3, 2) PMX_TAB_CASE(3, 8)
-#undef PMX_TAB_CASE
-    return PMX_ERR_ARG;
+    if (n == 1) tab_case<1>(pp, pp.hf, a, c, s, out);
+    else if (n == 2) tab_case<2>(pp, pp.hf, a, c, s, out);
+    else if (n == 8) tab_case<8>(pp, pp.hf, a, c, s, out);
+    else return PMX_ERR_ARG;
+    return PMX_OK;
 }
 
 // Largest value a column accumulator of a table product can reach: `terms` terms of nine products each (every column
@@ -458,41 +294,6 @@ extern "C" void hc_worst_column(int terms, uint32_t amax, uint32_t bmax, uint64_
         acc += (unsigned __int128)nred * kMask * kMask;
         if (acc > worst) worst = acc;
         acc >>= kW;
-    }
-    *hi = (uint64_t)(worst >> 64);
-    *lo = (uint64_t)worst;
-}
-
-// matrix_row<T> (pmx_permute.hpp) replayed with 128-bit columns and every limb of every operand, of p and of every m at
-// 2^29 - 1: the largest value any of its 18 columns holds at any point, same schedule constants as the kernel code.
-extern "C" void hc_worst_matrix_row(int terms, uint64_t *hi, uint64_t *lo) {
-    unsigned __int128 c[2 * kN] = {0}, worst = 0;
-    auto note = [&]() {
-        for (int k = 0; k < 2 * kN; ++k)
-            if (c[k] > worst) worst = c[k];
-    };
-    const unsigned __int128 prod = (unsigned __int128)kMask * kMask;
-    for (int j = 0; j < terms; ++j) {
-        for (int i = 0; i < kN; ++i)
-            for (int l = 0; l < kN; ++l) c[i + l] += prod;
-        note();
-        if (terms > kRowFreeTerms && j == kRowMidTerm - 1) {
-            for (int k = kRowMidLo; k <= kRowMidHi; ++k) {
-                c[k + 1] += c[k] >> kW;
-                c[k] &= kMask;
-            }
-            note();
-        }
-    }
-    for (int k = 0; k < kN; ++k) {   // cols_redc
-        for (int jj = 0; jj < kN; ++jj) c[k + jj] += prod;
-        note();
-        c[k + 1] += c[k] >> kW;
-        note();
-    }
-    for (int k = kN; k < 2 * kN - 1; ++k) {
-        c[k + 1] += c[k] >> kW;
-        note();
     }
     *hi = (uint64_t)(worst >> 64);
     *lo = (uint64_t)worst;

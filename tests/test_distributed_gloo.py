@@ -1,9 +1,8 @@
-"""The torch.distributed helpers of sponge_amd/distributed.py on CPU: world_size-2 gloo processes exercise the shard arithmetic, the
-equal and the ragged (host-staged) gather and the sharded Merkle reduction that `bench.py --allow-torch-gather` / PMX_BENCH_REHEARSAL=1
-fall back to.  What this file tests is those Python helpers - the per-rank engine here is the oracle's C restatement, so that no GPU is
-needed.  It does NOT test the product's multi-rank path: that is pmx_mgpu_* in the C ABI, whose every world > 1 branch runs on a GPU
-behind the stand-in collective library (tests/test_gpu_mgpu_standin.py: in-process slots, one process per rank, and bench.py's own
-`--gpus N` forms) and on real RCCL with as many ranks as the box has GPUs (tests/test_gpu_mgpu.py)."""
+"""World-size-2 gloo processes on CPU: the shard arithmetic, the equal and the ragged gather layout and the sharded Merkle reduction of
+the multi-GPU path, restated on torch.distributed in tests/gloo_model.py (test support).  The per-rank engine here is the oracle's C
+restatement, so that no GPU is needed.  It does NOT test the product's multi-rank path itself: that is pmx_mgpu_* in the C ABI, whose
+every world > 1 branch runs on a GPU behind the stand-in collective library (tests/test_gpu_mgpu_standin.py: in-process slots, one
+process per rank, and bench.py's own `--gpus N` forms) and on real RCCL with as many ranks as the box has GPUs (tests/test_gpu_mgpu.py)."""
 import os
 import socket
 
@@ -14,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import sponge_amd as S
-from sponge_amd import distributed as D
+import gloo_model as D
 from sponge_amd import synth
 from oracle import cref
 

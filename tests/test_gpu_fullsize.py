@@ -143,8 +143,7 @@ def test_wide_and_narrow_compression_kernels_agree_at_the_switch():
 def test_every_large_batch_kernel_of_t3_vs_c_oracle(alpha, rf, rp):
     """t = 3 launches that fill the device (2^17 units and more; the small-batch tests stay below): every entry point for the
     exponent with a dedicated chain and two on the generic S-box, against the C port: permute, hash, mid-stream absorb +
-    squeeze with mixed modes, and a Merkle tree whose widest level has 2^18 compressions.  (The register engine's table form,
-    which ran these sizes until round 4, is kept for moduli without int8 tables: tests/test_gpu_parity.py.)"""
+    squeeze with mixed modes, and a Merkle tree whose widest level has 2^18 compressions - all on the window engine of t = 3."""
     from oracle import cref
     from oracle import poseidon_oracle as O
     f = S.BLS12_381_FR

@@ -276,16 +276,21 @@ def test_odd_full_rounds_vs_c_oracle(rate, rf, rp):
 
 @pytest.mark.parametrize("field_name,modulus", [("pallas_fp", 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001),
                                                 ("p25519", (1 << 255) - 19)])
-def test_t9_dense_layers_on_and_off_the_matrix_cores(field_name, modulus):
-    """The wave-uniform t = 9 kernels run their dense layers on the matrix cores when the modulus' residues fit 32 balanced bytes
-    (top byte <= 126: pmx_prepare.hpp, pmx_mfma.hpp) and on the element-form rows otherwise.  A third field on each side of that
-    rule - neither is a benchmarked one - through permutation (sizes that leave a workgroup, a wave and a lane pair l / l + 32
-    partly empty), hash driver and compression, against the C port."""
+def test_t9_layers_on_the_matrix_cores_for_moduli_on_both_sides_of_the_32_byte_range(field_name, modulus):
+    """pmx_mfma.hpp stores a layer's constants in 32 balanced signed bytes, which reach 0.996 * 2^255: every residue of Pallas (top byte
+    0x40), but not every residue of 2^255 - 19 (0x7f), whose larger ones are stored as Y - p with 255 p in the row's correction
+    (pmx_prepare.hpp: put_mfma_layer_io; until round 6 such moduli ran on VALU rows).  Both - neither is a benchmarked field - on the
+    window engine, through permutation (sizes that leave a workgroup, a wave and a lane pair l / l + 32 partly empty), hash driver and
+    compression, against the C port."""
     from oracle import cref
     from oracle import poseidon_oracle as O
     f = S.Field(field_name, modulus)
     cfg = S.poseidon_config_from_lfsr(f, 8, 5, 8, 57)
     cr = cref.CRef(O.make_config(modulus, 255, 8, 5, 8, 57))
+    import ctypes
+    info = _lib.PmxEngineInfo()
+    _lib.check(_lib.lib().pmx_ctx_engine_info(cfg.context()._h, _lib.OP_PERMUTE, 1000, 0, ctypes.byref(info)))
+    assert info.engine == b"HybridEngine<9,5,mfma,windows of 9>" and info.mfma_dense == 1, info.engine
     for n in (1, 33, 70, 255, 257, 1000):
         states = synth.random_elements(f, n * 9, seed=900 + n).reshape(n, 9, 4)
         assert np.array_equal(cfg.context().permute_batch(states), cr.permute_batch(states, threads=0)), (field_name, n)
@@ -391,15 +396,17 @@ def test_many_paths_verify_on_the_device():
 
 
 def test_pinned_host_buffers_take_the_pipelined_path_and_agree():
-    """Page-locked host buffers (pmx_host_alloc) switch pmx_permute_batch / pmx_hash_batch to the chunked two-stream
-    pipeline; results must equal the pageable path and the oracle, also for batch sizes that do not divide evenly."""
+    """Page-locked host buffers (pmx_host_alloc) switch pmx_permute_batch / pmx_hash_batch to the chunked three-stream pipeline (upload,
+    kernel and download of different chunks at once); pageable buffers of 16 MiB and more are page-locked for the length of the call and
+    take the same pipeline.  Results must equal each other and the oracle, also for batch sizes that do not divide evenly (the 2^18
+    states here are 24 MiB: the registered path)."""
     import ctypes
     from sponge_amd import _lib
     cfg = product_config("bls_t3_a5_8_31")
     ctx = cfg.context()
-    for n in (100, (1 << 16) + 77, 1 << 17):
+    for n in (100, (1 << 16) + 77, 1 << 17, (1 << 18) + 5):
         states = synth.random_elements(cfg.field, n * 3, seed=n).reshape(n, 3, 4)
-        want = ctx.permute_batch(states)                       # pageable
+        want = ctx.permute_batch(states)                       # pageable (page-locked by the call from 16 MiB)
         pin = S.pinned_empty((n, 3, 4))
         pin[:] = states
         ctx.permute_batch_inplace(pin)
@@ -576,11 +583,10 @@ def test_sponge_driver_at_the_quad_kernel_switch(n):
 
 
 @pytest.mark.parametrize("alpha", [5, 17, 3])
-def test_register_engine_kernels_of_a_modulus_without_matrix_core_tables(alpha):
-    """Since round 5 every t = 3 call of a config WITH the int8 tables runs on the quad kernels (<= 32768 units) or the window engine
-    (above).  The one-lane-per-state register engine - element form below 2^17 units (2^18 for compress), shifted tables from there -
-    keeps the configs whose modulus has no tables (top byte > 126: pmx_mfma.hpp): 2^255 - 19 here.  40000 units (element form) and
-    2^17 + 77 (table form) through permute, the hash driver and a tree, whole batches against the C port."""
+def test_t3_window_engine_on_a_modulus_whose_residues_exceed_32_balanced_bytes(alpha):
+    """2^255 - 19 at t = 3: calls above the quad kernels' range run on the window engine like every other modulus (round 6: residues
+    above what 32 balanced bytes reach are stored as Y - p; until then this modulus had a register engine of its own).  40000 units and
+    2^17 + 77 through permute, the hash driver and a tree, whole batches against the C port."""
     from oracle import cref
     from oracle import poseidon_oracle as O
     import ctypes
@@ -592,12 +598,12 @@ def test_register_engine_kernels_of_a_modulus_without_matrix_core_tables(alpha):
     for n in (40000, (1 << 17) + 77):
         info = _lib.PmxEngineInfo()
         _lib.check(_lib.lib().pmx_ctx_engine_info(ctx._h, _lib.OP_PERMUTE, n, 0, ctypes.byref(info)))
-        assert info.engine.startswith(b"RegEngine<3,") and info.mfma_dense == 0, info.engine
+        assert info.engine.startswith(b"HybridEngine<3,") and info.mfma_dense == 1 and info.partial_window == 3, info.engine
         states = synth.random_elements(f, n * 3, seed=0x5EED0060 + alpha).reshape(n, 3, 4)
         assert np.array_equal(ctx.permute_batch(states), cr.permute_batch(states, threads=0)), n
         msgs = synth.random_elements(f, n * 5, seed=0x5EED0061 + alpha).reshape(n, 5, 4)
         assert np.array_equal(ctx.hash_batch(msgs, 5, 3), cr.hash_batch(msgs, 5, 3, threads=0)), n
-    leaves = synth.random_elements(f, 1 << 19, seed=alpha)          # levels of 2^18 (table form) and 2^17, 2^16 (element form) compressions
+    leaves = synth.random_elements(f, 1 << 19, seed=alpha)          # levels of 2^18 ... 2^16 compressions on the window engine, the rest on the quad kernels
     nodes, _ = ctx.merkle_2to1(leaves)
     assert np.array_equal(nodes, cr.merkle(leaves, threads=0))
 

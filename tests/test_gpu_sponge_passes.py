@@ -23,8 +23,8 @@ CASES = [
     ("bls12_381_fr", None, 255, 8, 17, 8, 57, True),     # the generic-exponent build of the hybrid engines
     ("bls12_381_fr", None, 255, 7, 5, 8, 57, True),
     ("bls12_381_fr", None, 255, 6, 5, 8, 57, True),
-    ("pallas_fp", PALLAS, 255, 8, 5, 8, 57, True),       # a third field on the matrix-core side of the modulus rule ...
-    ("p25519", P25519, 255, 8, 5, 8, 57, False),         # ... and one on the other (top byte 127: VALU rows)
+    ("pallas_fp", PALLAS, 255, 8, 5, 8, 57, True),       # a third field ...
+    ("p25519", P25519, 255, 8, 5, 8, 57, True),          # ... and one whose residues exceed 32 balanced bytes (top byte 127: stored as Y - p)
     ("bls12_381_fr", None, 255, 5, 5, 8, 57, True),      # t = 6, 5, 4: the matrix-core engines of the narrower hybrids
     ("bls12_381_fr", None, 255, 4, 5, 8, 56, True),
     ("bls12_381_fr", None, 255, 3, 3, 8, 56, True),

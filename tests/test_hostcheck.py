@@ -25,18 +25,14 @@ def hc():
     lib = ctypes.CDLL(os.environ.get("PMX_HOSTCHECK_LIB") or os.path.join(HERE, "libpmx_hostcheck.so"))
     lib.hc_permute.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_rt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
-    lib.hc_permute_opt.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
-    lib.hc_permute_opt_tab.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
-    lib.hc_permute_hybrid.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_coop.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_permute_hybrid_mfma.argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     lib.hc_field_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_sqr_column.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_tab_column.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
-    lib.hc_worst_matrix_row.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.hc_worst_dense_rt_row.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    lib.hc_tab_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.hc_tab_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
 
@@ -88,9 +84,9 @@ def test_column_accumulators_cannot_overflow(hc):
 
 @pytest.mark.parametrize("p", [O.BLS12_381_FR, O.BN254_FR, (1 << 230) + 0x1D])
 def test_shifted_table_products_match_bigint(hc, p):
-    """tab_dot / tab_dot_stream / tab_lanes_stream one operation at a time: a product by a constant through its nine
-    shifted residues plus two Montgomery steps is the same field element as the full product, for every form and
-    width the kernels instantiate, on edge operands (0, 1, p-1, values with all-ones limbs) and random ones."""
+    """tab_lanes_stream one operation at a time (the history term of a t = 3 window is its single-constant form): s_i + a * c_i through
+    the nine shifted residues of c_i plus two Montgomery steps is the same field element as the full product and sum, for one, two and
+    eight constants in a row, on edge operands (0, 1, p-1, values with all-ones limbs) and random ones."""
     rng = random.Random(17)
     mod = np.array(O.to_limbs(p), dtype=np.uint64)
     edge = [0, 1, p - 1, p - 2, ((1 << 29) - 1) * sum(1 << (29 * i) for i in range(8)) % p, (1 << 229) - 1]
@@ -98,34 +94,23 @@ def test_shifted_table_products_match_bigint(hc, p):
     def pick():
         return rng.choice(edge) if rng.random() < 0.4 else rng.randrange(p)
 
-    def run(form, n, a, c, s, n_out):
-        out = np.zeros(4 * n_out, dtype=np.uint64)
-        la, lc, ls = (mont_limbs(v, p) for v in (a, c, s))
-        assert hc.hc_tab_op(mod.ctypes.data, form, n, la.ctypes.data, lc.ctypes.data, ls.ctypes.data, out.ctypes.data) == 0
+    def run(n, a, c, s_):
+        out = np.zeros(4 * n, dtype=np.uint64)
+        la, lc, ls = (mont_limbs(v, p) for v in (a, c, s_))
+        assert hc.hc_tab_op(mod.ctypes.data, n, la.ctypes.data, lc.ctypes.data, ls.ctypes.data, out.ctypes.data) == 0
         return cref.limbs_to_elems(out, p)
 
     for _ in range(60):
-        for form, n in [(0, 1), (0, 3), (0, 6), (0, 9), (2, 3), (2, 4), (2, 9)]:
-            a, c = [pick() for _ in range(n)], [pick() for _ in range(n)]
-            assert run(form, n, a, c, [0], 1) == [sum(x * y for x, y in zip(a, c)) % p], (form, n)
-        a, c, s = pick(), pick(), pick()
-        assert run(1, 1, [a], [c], [s], 1) == [(a * c + s) % p]
-        for n in (2, 8):
-            a, c, s = pick(), [pick() for _ in range(n)], [pick() for _ in range(n)]
-            assert run(3, n, [a], c, s, n) == [(a * ci + si) % p for ci, si in zip(c, s)], n
+        for n in (1, 2, 8):
+            a, c, s_ = pick(), [pick() for _ in range(n)], [pick() for _ in range(n)]
+            assert run(n, [a], c, s_) == [(a * ci + si) % p for ci, si in zip(c, s_)], n
 
 
-def test_matrix_row_columns_cannot_overflow(hc):
-    """The explicit-column rows of the wide engines (t = 6 .. 9) propagate carries only where they must: no compression
-    up to six terms, columns 6 .. 10 once for longer rows, the rest inside the reduction.  Replay of the exact schedule
-    with every limb (operands, p, m) at 2^29 - 1: every column stays below 2^64 for every row length in use."""
+def test_run_time_width_rows_cannot_overflow(hc):
+    """Rows of the run-time-width engine (lazy operands, explicit 64-bit columns): compression before every fourth term, the tail left to
+    the reduction.  Replay of the exact schedule with every limb (operands, p, m) at its maximum: every column stays below 2^64 for
+    every row length the engine takes (t <= 16)."""
     hi, lo = np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint64)
-    for terms in range(1, 10):
-        hc.hc_worst_matrix_row(terms, hi.ctypes.data, lo.ctypes.data)
-        assert int(hi[0]) == 0, terms
-    hc.hc_worst_matrix_row(9, hi.ctypes.data, lo.ctypes.data)
-    assert int(lo[0]) > (1 << 63)            # ... and the budget is really used (the replay is not vacuous)
-    # rows of the run-time-width engine (lazy operands): compression before every fourth term, the tail left to the reduction
     for terms in range(1, 17):
         hc.hc_worst_dense_rt_row(terms, hi.ctypes.data, lo.ctypes.data)
         assert int(hi[0]) == 0, terms
@@ -133,7 +118,7 @@ def test_matrix_row_columns_cannot_overflow(hc):
 
 def test_table_column_accumulators_cannot_overflow(hc):
     """Every column of a table product holds nine products per term: six normalised terms (+ 2 reduction products, the
-    addend, the carry) fit 64 bits, seven do not - tab_dot splits wider rows over two accumulators; a lazily added
+    addend, the carry) fit 64 bits, seven do not (the kernels use one term: the t = 3 history product); a lazily added
     operand (limbs < 2^30) would fit three terms only, which is why the operands must be normalised."""
     hi = np.zeros(1, dtype=np.uint64)
     lo = np.zeros(1, dtype=np.uint64)
@@ -143,7 +128,9 @@ def test_table_column_accumulators_cannot_overflow(hc):
         assert (int(hi[0]) == 0) == ok, (terms, zmax, int(hi[0]))
 
 
-def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False, tab=False, mfma=False):
+def run_permute(hc, name, states, coop=False, mfma=False):
+    """the host build of one schedule: the reference's dense one at run-time width (what LdsEngine runs; default), the quad engine's
+    (coop, t = 3), the window engines' (mfma: HybridEngine<3..9>)"""
     cfg = oracle_config(name)
     p = cfg.p
     ark = mont_limbs([v for row in cfg.ark for v in row], p)
@@ -156,8 +143,7 @@ def run_permute(hc, name, states, rt=False, opt=False, hybrid=False, coop=False,
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
     out = np.ascontiguousarray(states, dtype=np.uint64).copy()
     n = out.size // (cfg.t * 4)
-    fn = hc.hc_permute_hybrid_mfma if mfma else hc.hc_permute_opt_tab if tab else hc.hc_permute_coop if coop else hc.hc_permute_hybrid if hybrid else (
-        hc.hc_permute_opt if opt else (hc.hc_permute_rt if rt else hc.hc_permute))
+    fn = hc.hc_permute_hybrid_mfma if mfma else hc.hc_permute_coop if coop else hc.hc_permute_rt
     assert fn(ctypes.byref(c), out.ctypes.data, n) == 0
     return out
 
@@ -170,21 +156,13 @@ def test_permutation_templates_match_golden(hc, name):
     vecs = golden("permute_vectors.json")[name]
     states = mont_limbs([x for v in vecs for x in ints(v["in"])], cfg.p).reshape(len(vecs), cfg.t, 4)
     want = [x for v in vecs for x in ints(v["out"])]
-    for rt in (False, True):     # compile-time-width template and run-time-width (LDS engine) template
-        out = run_permute(hc, name, states, rt=rt)
-        assert cref.limbs_to_elems(out, cfg.p) == want, ("rt" if rt else "static")
-    out = run_permute(hc, name, states, opt=True)     # optimised schedule (sparse partial rounds)
-    assert cref.limbs_to_elems(out, cfg.p) == want, "opt"
-    out = run_permute(hc, name, states, tab=True)     # the same on shifted tables (tab_dot)
-    assert cref.limbs_to_elems(out, cfg.p) == want, "opt_tab"
-    out = run_permute(hc, name, states, hybrid=True)  # register + scratch hybrid (HybridEngine)
-    assert cref.limbs_to_elems(out, cfg.p) == want, "hybrid"
+    out = run_permute(hc, name, states)                 # the reference's dense schedule at run-time width (LdsEngine)
+    assert cref.limbs_to_elems(out, cfg.p) == want, "dense, run-time width"
     if cfg.t == 3:
-        out = run_permute(hc, name, states, coop=True)  # three-lanes-per-state schedule (small Merkle levels)
+        out = run_permute(hc, name, states, coop=True)  # one state per quad of lanes (small calls at t = 3)
         assert cref.limbs_to_elems(out, cfg.p) == want, "coop"
-    if cfg.t in (3, 4, 9) and cfg.alpha in (5, 17):
-        out = run_permute(hc, name, states, mfma=True)  # dense layers as the matrix-core engine computes them (pmx_mfma.hpp)
-        assert cref.limbs_to_elems(out, cfg.p) == want, "hybrid, dense layers on the int8 tables"
+    out = run_permute(hc, name, states, mfma=True)      # the window engines: every layer through the int8 tables and the row finish
+    assert cref.limbs_to_elems(out, cfg.p) == want, "windows, layers on the int8 tables"
 
 
 def test_permutation_templates_match_c_oracle_on_random_batch(hc):
@@ -194,14 +172,12 @@ def test_permutation_templates_match_c_oracle_on_random_batch(hc):
         states = synth.random_elements(f, 512 * 3, seed=77).reshape(512, 3, 4)
         want = cref.CRef(oracle_config(name)).permute_batch(states, threads=0)
         assert np.array_equal(run_permute(hc, name, states), want)
-        assert np.array_equal(run_permute(hc, name, states, opt=True), want)
-        assert np.array_equal(run_permute(hc, name, states, tab=True), want)
-        assert np.array_equal(run_permute(hc, name, states, hybrid=True), want)
+        assert np.array_equal(run_permute(hc, name, states, mfma=True), want)
         assert np.array_equal(run_permute(hc, name, states, coop=True), want)
     from sponge_amd import synth as sy
     states = sy.random_elements(S.BN254_FR, 64 * 9, seed=78).reshape(64, 9, 4)
     want = cref.CRef(oracle_config("bn254_t9_a5_8_57")).permute_batch(states, threads=0)
-    assert np.array_equal(run_permute(hc, "bn254_t9_a5_8_57", states, hybrid=True), want)
+    assert np.array_equal(run_permute(hc, "bn254_t9_a5_8_57", states), want)
     assert np.array_equal(run_permute(hc, "bn254_t9_a5_8_57", states, mfma=True), want)
     # edge states: every element 0, 1 (Montgomery), p - 1
     from oracle import poseidon_oracle as Oo
@@ -212,36 +188,17 @@ def test_permutation_templates_match_c_oracle_on_random_batch(hc):
 
 
 def test_identity_lane_magnitudes_stay_inside_their_bounds(hc):
-    """The identity lanes of the sparse partial rounds are updated without a magnitude cap (mont_mul_add): they grow
-    by at most 1.0204 p per round and must stay below 2^261 (normalised limbs).  The host build reports every lane and
-    every row-0 output of the partial section: limbs < 2^29, lanes inside the worst-case line pmx_prepare.hpp budgets
-    for, row 0 small."""
+    """The identity lanes of the quad engine's sparse partial rounds (t = 3) are updated without a magnitude cap (mont_mul_add): they grow
+    by at most 1.0204 p per round and must stay below 2^261 (normalised limbs).  The host build reports every lane and every row-0
+    output of the partial section: limbs < 2^29, lanes inside the worst-case line pmx_prepare.hpp budgets for (opt_schedule_lane_headroom),
+    row 0 small."""
     from sponge_amd import synth
     import sponge_amd as S
     hc.hc_track_reset.argtypes = []
     hc.hc_track_get.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    worst = {}
-    for name, f, t, hybrid in [("bls_t3_a5_8_31", S.BLS12_381_FR, 3, False), ("bls_t4_a5_8_56", S.BLS12_381_FR, 4, True),
-                               ("bls_t9_a5_8_57", S.BLS12_381_FR, 9, True), ("bn254_t9_a5_8_57", S.BN254_FR, 9, True),
-                               ("bn254_t3_a5_8_57", S.BN254_FR, 3, False)]:
+    for name in ("bls_t3_a5_8_31", "bn254_t3_a5_8_57"):
         cfg = oracle_config(name)
-        states = synth.random_elements(f, 96 * t, seed=5).reshape(96, t, 4)
-        edge = cref.elems_to_limbs([cfg.p - 1] * t + [0] * t + [1] * t, cfg.p).reshape(3, t, 4)
-        states = np.concatenate([states, edge])
-        hc.hc_track_reset()
-        want = cref.CRef(cfg).permute_batch(states, threads=0)
-        assert np.array_equal(run_permute(hc, name, states, opt=not hybrid, hybrid=hybrid), want)
-        assert np.array_equal(run_permute(hc, name, states, tab=True), want)       # the table form tracks the same tags
         assert 2.2 + (1 + 1.3 * cfg.p / (1 << 261)) * (cfg.partial_rounds - 1) + 1.5 < (1 << 261) / cfg.p     # what prepare() checks
-        for tag, limit in [(0, 10.0), (1, 2.2 + 1.0204 * (cfg.partial_rounds - 1))]:
-            limb = np.zeros(1, dtype=np.uint32)
-            b = np.zeros(1, dtype=np.float64)
-            hc.hc_track_get(tag, limb.ctypes.data, b.ctypes.data)
-            assert 0 < int(limb[0]) < (1 << 29), (name, tag, int(limb[0]))
-            assert 0 < float(b[0]) < limit, (name, tag, float(b[0]))
-            worst[(name, tag)] = float(b[0])
-    # the lanes really do run uncapped for tens of rounds (the check above is not vacuous)
-    assert worst[("bls_t9_a5_8_57", 1)] > 8.0
     # the quad engine's folded sparse rounds (t = 3, alpha 5 / 17) accumulate their lanes the same way; row 0 there is
     # x^4 (x m00) + (v_1 s_1 + v_2 s_2): below 6 p, limbs normalised
     for name, f in [("bls_t3_a5_8_31", S.BLS12_381_FR), ("bls_t3_a17_8_31", S.BLS12_381_FR), ("bn254_t3_a5_8_57", S.BN254_FR)]:
@@ -284,13 +241,13 @@ def test_long_partial_sections_leave_the_optimised_schedule(hc):
         c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
         out = limbs.copy()
         hc.hc_track_reset()
-        rc = hc.hc_permute_opt(ctypes.byref(c), out.ctypes.data, len(states))
+        rc = hc.hc_permute_coop(ctypes.byref(c), out.ctypes.data, len(states))     # (the quad engine: the schedule with the uncapped lanes)
         assert (rc == 0) == expect_opt, (bits, rp, alpha, rc)
-        out_tab = limbs.copy()
-        assert (hc.hc_permute_opt_tab(ctypes.byref(c), out_tab.ctypes.data, len(states)) == 0) == expect_opt
+        out_win = limbs.copy()
+        assert (hc.hc_permute_hybrid_mfma(ctypes.byref(c), out_win.ctypes.data, len(states)) == 0) == expect_opt
         if expect_opt:
             assert cref.limbs_to_elems(out, p) == want
-            assert cref.limbs_to_elems(out_tab, p) == want
+            assert cref.limbs_to_elems(out_win, p) == want
             limb = np.zeros(1, dtype=np.uint32)
             b = np.zeros(1, dtype=np.float64)
             hc.hc_track_get(1, limb.ctypes.data, b.ctypes.data)
@@ -312,7 +269,7 @@ def _odd_modulus_config(p, bits, rate, alpha, rf, rp):
 @pytest.mark.parametrize("p", [PALLAS_FP])
 def test_other_255_bit_prime(hc, p):
     """Nothing in the arithmetic is specific to the two benchmarked fields: a third 255-bit prime (Pallas base field),
-    constants from the same Grain-LFSR procedure, all four schedules against the big-integer oracle."""
+    constants from the same Grain-LFSR procedure, every schedule against the big-integer oracle."""
     from sponge_amd._lib import PmxConfig
     cfg = O.make_config(p, 255, 2, 5, 8, 56)
     rng = random.Random(99)
@@ -326,17 +283,18 @@ def test_other_255_bit_prime(hc, p):
     for i, l in enumerate(O.to_limbs(p)):
         c.modulus[i] = l
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
-    for fn in (hc.hc_permute, hc.hc_permute_rt, hc.hc_permute_opt, hc.hc_permute_opt_tab, hc.hc_permute_hybrid, hc.hc_permute_coop):
+    for fn in (hc.hc_permute, hc.hc_permute_rt, hc.hc_permute_hybrid_mfma, hc.hc_permute_coop):
         out = limbs.copy()
         assert fn(ctypes.byref(c), out.ctypes.data, len(states)) == 0
         assert cref.limbs_to_elems(out, p) == want, fn.__name__
 
 
-def test_matrix_core_tables_only_for_moduli_whose_residues_fit_32_balanced_bytes(hc):
-    """pmx_mfma.hpp stores residues in 32 balanced signed bytes, which needs the modulus' top byte <= 126; 2^255 - 19 (0x7f) does
-    not qualify: prepare() then builds no such tables, the matrix-core form refuses and the element-form rows (what the product
-    dispatches to in that case) still agree with the big-integer oracle at t = 9.  Pallas (top byte 0x40) qualifies."""
-    for p, ok in ((P25519, False), (PALLAS_FP, True)):
+def test_matrix_core_tables_for_every_modulus_also_one_whose_residues_exceed_32_balanced_bytes(hc):
+    """pmx_mfma.hpp stores residues in 32 balanced signed bytes, which reach 127 (256^32 - 1) / 255 = 0.996 * 2^255: a residue of
+    2^255 - 19 (top byte 0x7f) can lie above that and is then stored as Y - p, with 255 p in the row's correction (pmx_prepare.hpp:
+    put_mfma_layer_io; until round 6 such moduli had no tables).  Both the matrix-core form and the dense schedule agree with the
+    big-integer oracle at t = 9 - 2^255 - 19, and Pallas (top byte 0x40) where no residue needs the second form."""
+    for p, ok in ((P25519, True), (PALLAS_FP, True)):
         cfg = O.make_config(p, 255, 8, 5, 8, 57)
         rng = random.Random(4242)
         states = [[rng.randrange(p) for _ in range(9)] for _ in range(3)] + [[p - 1] * 9]
@@ -350,7 +308,7 @@ def test_matrix_core_tables_only_for_moduli_whose_residues_fit_32_balanced_bytes
             c.modulus[i] = l
         c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
         out = limbs.copy()
-        assert hc.hc_permute_hybrid(ctypes.byref(c), out.ctypes.data, len(states)) == 0
+        assert hc.hc_permute(ctypes.byref(c), out.ctypes.data, len(states)) == 0
         assert cref.limbs_to_elems(out, p) == want
         out = limbs.copy()
         rc = hc.hc_permute_hybrid_mfma(ctypes.byref(c), out.ctypes.data, len(states))
@@ -366,7 +324,7 @@ def test_small_exponents_on_every_schedule(hc, t, alpha):
     bound of a Montgomery PRODUCT (below 1.3 p).  alpha = 1 used to hand its lazy input through - wrong results on the hybrid engines of
     t >= 6 - and is formed as the product x * 1 since (pmx_field.hpp: fe_sbox); alpha = 0 is the constant 1.  Every schedule of the host
     build against the oracle (the reference accepts any alpha: src/poseidon/mod.rs:63-74)."""
-    for name in ("hc_permute_hybrid_mfma", "hc_permute_hybrid", "hc_permute_rt"):
+    for name in ("hc_permute_hybrid_mfma", "hc_permute_rt"):
         getattr(hc, name).argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     p, rate = O.BLS12_381_FR, t - 1
     cfg = O.make_config(p, 255, rate, alpha, 8, 57)
@@ -381,7 +339,7 @@ def test_small_exponents_on_every_schedule(hc, t, alpha):
     for i, l in enumerate(O.to_limbs(p)):
         c.modulus[i] = l
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
-    for name in ("hc_permute_hybrid_mfma", "hc_permute_hybrid", "hc_permute_rt") + (("hc_permute",) if t in (3, 4, 9) else ()):
+    for name in ("hc_permute_hybrid_mfma", "hc_permute_rt") + (("hc_permute",) if t in (3, 4, 9) else ()):
         out = limbs.copy()
         assert getattr(hc, name)(ctypes.byref(c), out.ctypes.data, len(states)) == 0, (name, t, alpha)
         assert cref.limbs_to_elems(out, p) == want, (name, t, alpha)
@@ -395,7 +353,7 @@ def test_small_moduli_on_every_schedule(hc, bits, p, t):
     """The library takes primes of 225 ... 255 bits (pmx_prepare.hpp).  The bounds of the matrix-core rows are stated for the largest
     (a row is below 2^248 + p) but scale with the modulus - V < (bytes of the inputs) * 255 * p - so the exit's two conditional
     subtractions also do for the smallest.  Every host schedule against the oracle over three primes far below the benchmarked sizes."""
-    for name in ("hc_permute_hybrid_mfma", "hc_permute_hybrid", "hc_permute_rt", "hc_permute"):
+    for name in ("hc_permute_hybrid_mfma", "hc_permute_rt", "hc_permute"):
         getattr(hc, name).argtypes = [ctypes.POINTER(PmxConfig), ctypes.c_void_p, ctypes.c_size_t]
     cfg = O.make_config(p, bits, t - 1, 5, 8, 22)
     rng = random.Random(bits + t)
@@ -409,7 +367,7 @@ def test_small_moduli_on_every_schedule(hc, bits, p, t):
     for i, l in enumerate(O.to_limbs(p)):
         c.modulus[i] = l
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
-    for name in ("hc_permute_hybrid_mfma", "hc_permute_hybrid", "hc_permute_rt", "hc_permute"):
+    for name in ("hc_permute_hybrid_mfma", "hc_permute_rt", "hc_permute"):
         out = limbs.copy()
         assert getattr(hc, name)(ctypes.byref(c), out.ctypes.data, len(states)) == 0, (name, bits, t)
         assert cref.limbs_to_elems(out, p) == want, (name, bits, t)
@@ -533,7 +491,7 @@ def test_odd_full_rounds_follow_the_reference_split(hc, rate, rf, rp):
         c.modulus[i] = l
     c.ark, c.mds = ark.ctypes.data, mds.ctypes.data
     has_opt = rf >= 2 and rp >= 1
-    fns = [hc.hc_permute, hc.hc_permute_rt, hc.hc_permute_opt, hc.hc_permute_opt_tab, hc.hc_permute_hybrid]
+    fns = [hc.hc_permute, hc.hc_permute_rt, hc.hc_permute_hybrid_mfma]
     if t == 3:
         fns.append(hc.hc_permute_coop)
     for fn in fns:

@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "sponge_amd", "csrc")
 def test_permute_kernel_keeps_its_occupancy_without_scratch(t, alpha, max_vgprs, waves):
     subprocess.check_call(["make", "-C", CSRC, "asm1", f"T={t}", f"ALPHA={alpha}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rpt = open(os.path.join(CSRC, "build", f"one_t{t}.rpt")).read()
-    assert f"HybridEngineILi{t}ELi{alpha}ELb1EEE" in rpt
+    assert f"HybridEngineILi{t}ELi{alpha}EEE" in rpt
     get = lambda key: int(re.search(key + r": (\d+)", rpt).group(1))
     assert get(r"ScratchSize \[bytes/lane\]") == 0, rpt[-1500:]
     assert get("VGPRs") + get("AGPRs") <= max_vgprs and get(r"Occupancy \[waves/SIMD\]") >= waves, rpt[-1500:]

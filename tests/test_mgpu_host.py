@@ -7,7 +7,7 @@ import pytest
 
 import sponge_amd as S
 from sponge_amd import _lib, mgpu
-from sponge_amd import distributed as D
+import gloo_model as D
 from sponge_amd.poseidon import c_config
 
 

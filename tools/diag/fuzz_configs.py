@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Seeded random Poseidon configurations on the GPU against the C port (oracle/), aimed at ENGINES: every exponent class (0, 1, small,
 the usual, 64-bit), odd and zero round counts, every rate / capacity split of widths 2 ... 12, both benchmarked fields and (every fourth
-config) a random prime of 225 ... 255 bits - every other one of those with top byte 127, the moduli that have no int8 tables; per config
+config) a random prime of 225 ... 255 bits - every other one of those with top byte 127, whose larger residues the int8 tables store as
+Y - p; per config
 whole permutations at several batch sizes, the fixed-shape hash, a small tree and (every other config) the duplex driver on sponges in
-mixed modes; at t = 3 one LARGE call per config (32769 ... 2^18 + units: the other side of every size threshold of the dispatch in
+mixed modes; at t = 3 one LARGE call per config (32769 ... 2^18 + units: the other side of the quad kernels' threshold in
 pmx_device.hip), rotating through permute / hash / compress / absorb + squeeze.
 
 pmx_ctx_engine_info is asked before every call, and the run keeps the matrix  engine family x operation -> calls checked.  With --matrix
@@ -31,15 +32,12 @@ rng = random.Random(SEED)
 FIELDS = {"bls12_381_fr": (O.BLS12_381_FR, 255), "bn254_fr": (O.BN254_FR, 254)}
 OPS = {_lib.OP_PERMUTE: "permute", _lib.OP_HASH: "hash", _lib.OP_COMPRESS: "compress", _lib.OP_ABSORB: "absorb", _lib.OP_SQUEEZE: "squeeze"}
 # engine family (pmx_ctx_engine_info's name, reduced: see family()) x operation: every cell must be reached when --matrix is given
-FAMILIES = ["QuadEngine", "HybridEngine mfma", "HybridEngine mfma x passes", "HybridEngine valu", "HybridEngine valu x passes",
-            "RegEngine opt", "RegEngine opt,tab", "RegEngine dense", "LdsEngine"]
+FAMILIES = ["QuadEngine", "HybridEngine mfma", "HybridEngine mfma x passes", "LdsEngine"]
 REQUIRED = {(fam, op) for fam in FAMILIES for op in OPS.values()}
-# cells that do not exist: the pass form is the absorb / squeeze driver only; the other operations of those engines are single launches
-REQUIRED -= {(fam, op) for fam in FAMILIES if fam.endswith("passes") for op in ("permute", "hash", "compress")}
-REQUIRED -= {(fam, op) for fam in ("HybridEngine mfma", "HybridEngine valu") for op in ("absorb", "squeeze")}
-# the register engine's element form (alpha 5 / 17 below 2^17 units) never serves a t = 3 call the quad kernels or the window engine take;
-# what is left for it: splits other than (capacity 1, rate 2) and moduli without tables - reached, but not for every operation at every seed
-OPTIONAL = {("RegEngine dense", "compress"), ("RegEngine dense", "absorb"), ("RegEngine dense", "squeeze")}
+# cells that do not exist: the pass form is the absorb / squeeze driver, and the only form of it on the window engines
+REQUIRED -= {("HybridEngine mfma x passes", op) for op in ("permute", "hash", "compress")}
+REQUIRED -= {("HybridEngine mfma", op) for op in ("absorb", "squeeze")}
+OPTIONAL = set()
 matrix = collections.Counter()
 
 
@@ -47,9 +45,7 @@ def family(info):
     name = info.engine.decode()
     head = name.split("<")[0]
     if head == "HybridEngine":
-        head += " mfma" if "mfma" in name else " valu"
-    elif head == "RegEngine":
-        head += " opt,tab" if "opt,tab" in name else " opt" if "opt" in name else " dense"
+        head += " mfma" if "mfma" in name else " ?"
     if info.launches > 1 or name.endswith("x passes"):
         head += " x passes"
     return head
@@ -98,20 +94,20 @@ ALPHAS = [0, 1, 1, 2, 3, 4, 5, 5, 5, 6, 7, 11, 17, 17, 257, 65537, (1 << 32) + 1
 # (field: a name of FIELDS or "p127" = a random 255-bit prime with top byte 127; large = (operation, units) of the one large call at t = 3).
 # The constants, states and messages stay seeded-random; the rest of the run is random in everything.
 DIRECTED = [
-    dict(field="p127", t=3, capacity=1, alpha=5, rf=8, rp=31, large=("permute", 32769)),            # register engine, element form
+    dict(field="p127", t=3, capacity=1, alpha=5, rf=8, rp=31, large=("permute", 32769)),            # residues stored as Y - p (pmx_prepare.hpp): t = 3 window engine
     dict(field="p127", t=3, capacity=1, alpha=17, rf=8, rp=31, large=("hash", 40001)),
     dict(field="p127", t=3, capacity=1, alpha=5, rf=8, rp=31, large=("tree", 1 << 17)),
     dict(field="p127", t=3, capacity=1, alpha=5, rf=8, rp=31, large=("sponges", 32769 + 77)),
-    dict(field="p127", t=3, capacity=1, alpha=3, rf=8, rp=31, large=("permute", 32769 + 130)),      # ... shifted tables (any other exponent; 5 / 17 from 2^17)
+    dict(field="p127", t=3, capacity=1, alpha=3, rf=8, rp=31, large=("permute", 32769 + 130)),      # ... the generic S-box
     dict(field="p127", t=3, capacity=1, alpha=5, rf=8, rp=31, large=("hash", (1 << 17) + 1)),
     dict(field="p127", t=3, capacity=1, alpha=7, rf=8, rp=31, large=("tree", 1 << 17)),
     dict(field="p127", t=3, capacity=1, alpha=257, rf=8, rp=13, large=("sponges", 32769 + 200)),
     dict(field="bls12_381_fr", t=3, capacity=1, alpha=5, rf=8, rp=31, large=("sponges", 32769 + 5)),  # the window engine at t = 3, as passes
     dict(field="bls12_381_fr", t=3, capacity=1, alpha=17, rf=8, rp=31, large=("tree", 1 << 17)),
     dict(field="bn254_fr", t=3, capacity=1, alpha=5, rf=8, rp=57, large=("hash", 32769)),
-    dict(field="bls12_381_fr", t=3, capacity=1, alpha=5, rf=8, rp=0, large=("permute", 32769)),       # no partial section: the dense schedule
+    dict(field="bls12_381_fr", t=3, capacity=1, alpha=5, rf=8, rp=0, large=("permute", 32769)),       # no partial section: the dense schedule (run-time-width engine)
     dict(field="bls12_381_fr", t=3, capacity=0, alpha=5, rf=8, rp=31, large=("hash", 20000)),         # a split the quad kernels do not take
-    dict(field="p127", t=5, capacity=1, alpha=5, rf=8, rp=56, large=None),                            # the VALU-row hybrids
+    dict(field="p127", t=5, capacity=1, alpha=5, rf=8, rp=56, large=None),                            # the wide window engines on such a modulus
     dict(field="p127", t=9, capacity=1, alpha=17, rf=8, rp=57, large=None),
     dict(field="p127", t=7, capacity=2, alpha=5, rf=7, rp=22, large=None),
     dict(field="bn254_fr", t=9, capacity=1, alpha=5, rf=8, rp=57, large=None),                        # BASELINE configs[2]'s shape
@@ -247,8 +243,7 @@ for k in range(N):
         check_sponges(what, f, cfg, cr, 90, t, rate,
                       [("absorb", rng.randint(1, 2 * r + 1)), ("squeeze", rng.randint(1, 2 * r + 1)), ("squeeze", 1), ("absorb", 1)], k)
     if t == 3:
-        # one LARGE call: the far side of the t = 3 thresholds (32769: quad kernels -> window engine / register engine; 2^17, 2^18: the register
-        # engine's element form -> shifted tables)
+        # one LARGE call: the far side of the t = 3 threshold (32769: quad kernels -> window engine)
         turn, large_turn = large_turn % 5, large_turn + 1
         pick = {0: "permute", 1: "hash", 2: "tree"}.get(turn, "sponges")
         big = None

@@ -50,5 +50,5 @@ for f in sorted(glob.glob(os.path.join(out, "c?_n*_*.json"))):
               "%.3f" % d["gather_ms"] if d.get("gather_ms") is not None else "-", (d.get("rccl") or {}).get("ranks"), d["verified"]))
     except Exception as e:
         print("%-24s no JSON line (%s): %s" % (os.path.basename(f), e, open(f[:-5] + ".err").read()[-300:].replace("\n", " | ")))
-print("(DESIGN.md section 6 predicts ~1.3 ms for the C4 gather at N = 8: 192 MiB per peer, each over its own xGMI link)")
+print("(the lines carry gather_ms_predicted: one shard over one xGMI link at 153 GB/s - ~1.3 ms for the C4 gather at N = 8)")
 PY

@@ -41,6 +41,28 @@ int main() {
             CK(hipStreamSynchronize(st[0])); CK(hipStreamSynchronize(st[1]));
             printf("rep %d chunks %2d: %.2f ms\n", rep, chunks, (now() - t0) * 1e3);
         }
+        {
+            static hipStream_t up = nullptr, run = nullptr, down = nullptr;
+            static hipEvent_t eu[64], ek[64];
+            if (!up) {
+                CK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&run, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+                for (int i = 0; i < 64; ++i) { CK(hipEventCreateWithFlags(&eu[i], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ek[i], hipEventDisableTiming)); }
+            }
+            for (int chunks : {4, 8, 16, 32}) {
+                t0 = now();
+                const size_t cn = n / chunks;
+                for (int k = 0; k < chunks; ++k) {
+                    char *h = (char *)host.data() + (size_t)k * cn * 96, *d = (char *)dev + (size_t)k * cn * 96;
+                    CK(hipMemcpyAsync(d, h, cn * 96, hipMemcpyHostToDevice, up));
+                    CK(hipEventRecord(eu[k], up)); CK(hipStreamWaitEvent(run, eu[k], 0));
+                    pmx_permute_batch_dev(ctx, (uint64_t *)d, cn, run);
+                    CK(hipEventRecord(ek[k], run)); CK(hipStreamWaitEvent(down, ek[k], 0));
+                    CK(hipMemcpyAsync(h, d, cn * 96, hipMemcpyDeviceToHost, down));
+                }
+                CK(hipStreamSynchronize(down)); CK(hipStreamSynchronize(run)); CK(hipStreamSynchronize(up));
+                printf("rep %d three streams, chunks %2d: %.2f ms\n", rep, chunks, (now() - t0) * 1e3);
+            }
+        }
         t0 = now(); CK(hipHostUnregister(host.data())); double tun = now() - t0;
         printf("rep %d: pageable %.2f ms | register %.2f ms, one round trip %.2f ms, unregister %.2f ms\n", rep, ta * 1e3, treg * 1e3, tb * 1e3, tun * 1e3);
     }

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Copies the summaries of gpurun_out/<tags...> (tools/gpu_r05.sh sessions of ONE build) into profiles/r05/<prefix>_*: bench lines, kernel stats,
+# Copies the summaries of gpurun_out/<tags...> (tools/gpu_r06.sh sessions of ONE build) into profiles/r06/<prefix>_*: bench lines, kernel stats,
 # counter summaries, test tails.  Scratch stays in gpurun_out/.   usage: tools/install_evidence.sh <prefix> <tag> [<tag> ...]
 set -e
 P=$1; shift
-R=$(cd $(dirname $0)/.. && pwd); D=$R/profiles/r05
+R=$(cd $(dirname $0)/.. && pwd); D=$R/profiles/r06
 strip() { grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname \|^Librccl path\|amdgpu.ids" "$1" > "$2" || true; }
 for TAG in "$@"; do
   S=$R/gpurun_out/$TAG
@@ -18,14 +18,15 @@ for TAG in "$@"; do
   [ -f $S/traffic.log ] && strip $S/traffic.log $D/${P}_hbm_traffic.txt
   if [ -d $S/group_rehearsal ]; then rm -rf $D/${P}_group_rehearsal; mkdir -p $D/${P}_group_rehearsal; cp $S/group_rehearsal/*.json $S/group_rehearsal/*.txt $D/${P}_group_rehearsal/ 2>/dev/null || true; [ -f $S/group_rehearsal.txt ] && strip $S/group_rehearsal.txt $D/${P}_group_rehearsal/summary.txt; fi
 done
-# (profiles/r05/<prefix>_pmc_fetch_smem_lds_levels_c3_c2.txt is made by hand from tools/pmc_fetch_levels.sh: see profiles/r05/README.md)
+# (profiles/r06/<prefix>_pmc_fetch_smem_lds_levels_c3_c2.txt is made by hand from tools/pmc_fetch_levels.sh: see profiles/r05/README.md)
 # the counter JSONs bench.py quotes: say where they were taken
 python3 - "$P" <<PY
 import json, sys
 p = "$R/profiles/hbm_traffic.json"
 d = json.load(open(p))
 for k in d:
-    d[k].setdefault("taken", "round 5 (profiles/r05/%s_*), profiles/r05/%s_hbm_traffic.txt" % (sys.argv[1], sys.argv[1]))
+    if isinstance(d[k], dict):
+        d[k].setdefault("taken", "round 6 (profiles/r06/%s_*), profiles/r06/%s_hbm_traffic.txt" % (sys.argv[1], sys.argv[1]))
 json.dump(d, open(p, "w"), indent=1)
 PY
 ls $D | grep "^${P}_" | wc -l
