@@ -804,7 +804,8 @@ def clock_normalised(kernel_s, clock_hz, compute_units, permutations_per_gpu_ste
            "permutations_per_s_at_2.2GHz": permutations_per_gpu_step / kernel_s * (2.2e9 / clock_hz), "kernel_ms_at_2.2GHz": 1e3 * kernel_s * clock_hz / 2.2e9}
     per = (valu_issue or {}).get("valu_instructions_per_permutation")
     if per:
-        out["clocks_per_valu_instruction_and_simd"] = simd_clocks / (permutations_per_gpu_step * per)     # 4.0 = every issue slot taken
+        # (a wave instruction serves the 64 permutations of its lanes)
+        out["clocks_per_valu_instruction_and_simd"] = simd_clocks / (permutations_per_gpu_step / 64.0 * per)     # ~4.0 = every issue slot taken
     return out
 
 

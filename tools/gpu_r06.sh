@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-6 GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_r06.sh <tag> [stages]
 # stages: any of  test testlib fuzz smoke bench widths prof slots pmc hostpath rehearsal rates stalls   (default: "test smoke bench")
+# Order inside a session: tests, the counter passes (prof slots pmc stalls) and their JSONs, THEN the bench lines - which therefore
+# carry this lease's own valu_issue / traffic figures (evidence of one build from one lease at one clock).
 TAG=${1:-r06z}
 STAGES=${2:-"test smoke bench"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -20,34 +22,7 @@ if has testlib; then   # the same suite once more with libposeidon_mi355x_test.s
 fi
 if has fuzz; then ( timeout 1500 python tools/diag/fuzz_configs.py 600 501 --matrix; timeout 900 python tools/diag/alpha1_widths.py | grep -c "pairs: 0 of" ) > $OUT/fuzz_configs.txt 2>&1; fi
 if has smoke; then timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; fi
-B() { local name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
-if has bench; then
-  B c2 --steps 20 --warmup 5
-  B c3 --workload c3 --steps 5 --warmup 1 --cpu-seconds 6
-  B c5_2e21 --workload c5 --total-log2 21 --steps 10 --warmup 2 --no-cpu-baseline
-  B c5 --workload c5 --steps 3 --warmup 1 --no-cpu-baseline
-  B c2_2e21 --workload c2 --total-log2 21 --steps 10 --warmup 2 --no-cpu-baseline
-  B k3 --workload k3 --steps 20 --warmup 5 --no-cpu-baseline
-  B h3 --workload h3 --steps 10 --warmup 2 --no-cpu-baseline
-  B h9 --workload h9 --steps 5 --warmup 1 --no-cpu-baseline
-  B d3 --workload d3 --steps 10 --warmup 2 --no-cpu-baseline
-  B d9 --workload d9 --steps 5 --warmup 2 --no-cpu-baseline
-fi
-if has widths; then for w in w4 w5 w6 w7 w8; do B $w --workload $w --steps 5 --warmup 1 --no-cpu-baseline; done; fi
-if has rates; then
-  WIDE="--field bn254_fr --rate 8 --rounds 8 57 --log2 18"
-  ( timeout 300 python tools/sponge_rate.py $WIDE --absorb 11 --squeeze 9
-    timeout 300 python tools/sponge_rate.py $WIDE --absorb 11 --squeeze 9 --mixed
-    timeout 300 python tools/sponge_rate.py --rate 7 --log2 18 --absorb 10 --squeeze 8 --mixed
-    timeout 300 python tools/sponge_rate.py --rate 4 --log2 19 --absorb 7 --squeeze 5 --mixed
-    timeout 300 python tools/sponge_rate.py
-    timeout 300 python tools/sponge_rate.py --mixed ) > $OUT/sponge_rate.txt 2>&1
-  timeout 600 python tools/merkle_levels.py 21 > $OUT/merkle_levels.txt 2>&1
-fi
-if has hostpath; then
-  ( timeout 600 python tools/host_path_rate.py 20; timeout 600 python tools/host_path_rate.py 21 ) > $OUT/host_path.txt 2>&1
-fi
-if has rehearsal; then bash tools/gpu_group_rehearsal.sh $OUT/group_rehearsal > $OUT/group_rehearsal.txt 2>&1; fi
+# ---- the counter passes come FIRST: the bench lines of this session then quote the instruction counts and traffic of this very lease
 cd /tmp && export TMPDIR=/tmp
 PMC_ARGS() {  # workload -> bench arguments of its counter passes
   case $1 in
@@ -91,6 +66,7 @@ if has slots; then
   V $OUT/slots_h3 hash_kernel h3 2097152 "HybridEngine<3,5,mfma,windows of 3>" 4 $J "profiles/r06" 2
   V $OUT/slots_h9 hash_kernel h9 262144 "HybridEngine<9,5,mfma,windows of 9>" 2 $J "profiles/r06"
   cat $OUT/valu_count.log
+  cp $J $R/profiles/valu_instructions.json   # (on the box: the bench lines below quote the counts of THIS session, same lease, same clock)
   for w in d3 d9 c5_2e21; do echo "== $w (every kernel of the step)"; python3 tools/pmc_kernel_summary.py $OUT/slots_$w 2>&1 | head -60; done > $OUT/valu_driver_and_tree_kernels.txt
 fi
 if has pmc; then
@@ -111,7 +87,37 @@ if has pmc; then
   X $OUT/pmc_fetch_d3 $OUT/pmc_write_d3 "<pmx::HybridEngine" d3 $T 4 4194304
   X $OUT/pmc_fetch_d9 $OUT/pmc_write_d9 "<pmx::HybridEngine" d9 $T 4 1048576
   cat $OUT/traffic.log
+  cp $T $R/profiles/hbm_traffic.json
 fi
+cd $R
+B() { local name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
+if has bench; then
+  B c2 --steps 20 --warmup 5
+  B c3 --workload c3 --steps 5 --warmup 1 --cpu-seconds 6
+  B c5_2e21 --workload c5 --total-log2 21 --steps 10 --warmup 2 --no-cpu-baseline
+  B c5 --workload c5 --steps 3 --warmup 1 --no-cpu-baseline
+  B c2_2e21 --workload c2 --total-log2 21 --steps 10 --warmup 2 --no-cpu-baseline
+  B k3 --workload k3 --steps 20 --warmup 5 --no-cpu-baseline
+  B h3 --workload h3 --steps 10 --warmup 2 --no-cpu-baseline
+  B h9 --workload h9 --steps 5 --warmup 1 --no-cpu-baseline
+  B d3 --workload d3 --steps 10 --warmup 2 --no-cpu-baseline
+  B d9 --workload d9 --steps 5 --warmup 2 --no-cpu-baseline
+fi
+if has widths; then for w in w4 w5 w6 w7 w8; do B $w --workload $w --steps 5 --warmup 1 --no-cpu-baseline; done; fi
+if has rates; then
+  WIDE="--field bn254_fr --rate 8 --rounds 8 57 --log2 18"
+  ( timeout 300 python tools/sponge_rate.py $WIDE --absorb 11 --squeeze 9
+    timeout 300 python tools/sponge_rate.py $WIDE --absorb 11 --squeeze 9 --mixed
+    timeout 300 python tools/sponge_rate.py --rate 7 --log2 18 --absorb 10 --squeeze 8 --mixed
+    timeout 300 python tools/sponge_rate.py --rate 4 --log2 19 --absorb 7 --squeeze 5 --mixed
+    timeout 300 python tools/sponge_rate.py
+    timeout 300 python tools/sponge_rate.py --mixed ) > $OUT/sponge_rate.txt 2>&1
+  timeout 600 python tools/merkle_levels.py 21 > $OUT/merkle_levels.txt 2>&1
+fi
+if has hostpath; then
+  ( timeout 600 python tools/host_path_rate.py 20; echo "--- the C ABI without the Python wrapper (tools/host_path_probe.cpp)"; timeout 300 ./tools/host_path_probe ) > $OUT/host_path.txt 2>&1
+fi
+if has rehearsal; then bash tools/gpu_group_rehearsal.sh $OUT/group_rehearsal > $OUT/group_rehearsal.txt 2>&1; fi
 for f in sponge_rate merkle_levels host_path group_rehearsal; do [ -f $OUT/$f.txt ] && tail -30 $OUT/$f.txt; done
 [ -f $OUT/pytest_gpu.log ] && tail -25 $OUT/pytest_gpu.log
 [ -f $OUT/pytest_gpu_test_library.log ] && tail -5 $OUT/pytest_gpu_test_library.log

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The table of DESIGN.md section 3.5 from committed evidence: profiles/r05/<prefix>bench_*.json (bench lines), profiles/hbm_traffic.json
+"""The table of DESIGN.md section 3.5 from committed evidence: profiles/r06/<prefix>bench_*.json (bench lines), profiles/hbm_traffic.json
 (FETCH_SIZE / WRITE_SIZE passes) and profiles/valu_instructions.json (SQ_INSTS_VALU passes).  usage: tools/roofline_table.py [prefix = z_]"""
 import json
 import os
@@ -20,19 +20,23 @@ LINES = [("c2", "**c2**: BLS12-381 Fr t = 3, 8 + 31, 2^20 states (BASELINE confi
          ("d3", "**d3**: duplex driver, `absorb(4)` + `squeeze(3)` per step, 2^20 sponges (4 permutations each)"),
          ("d9", "**d9**: `absorb(11)` + `squeeze(9)`, t = 9, 2^18 sponges")]
 LINES += [("w%d" % t, "**w%d**: BLS12-381 Fr t = %d, 8 + %d, 2^%d states" % (t, t, 56 if t < 6 else 57, 19 if t < 6 else 18)) for t in (4, 5, 6, 7, 8)]
-print("| workload (`bench.py --workload`) | engine (`HE` = `HybridEngine`) | permutations/s | kernel time per step | algorithmic HBM rate = fraction of 8 TB/s "
-      "| HBM traffic (PMC) / algorithmic | VALU instructions per permutation | `valu_issue.frac` |")
-print("|---|---|---|---|---|---|---|---|")
+print("| workload (`bench.py --workload`) | engine (`HE` = `HybridEngine`) | permutations/s (at the box's clock) | at 2.2 GHz | kernel time per step | algorithmic HBM rate = fraction of 8 TB/s "
+      "| HBM traffic (PMC) / algorithmic | VALU instructions per permutation | clocks per VALU instruction and SIMD (4.0 = every slot) | `valu_issue.frac` |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 for name, label in LINES:
-    path = os.path.join(ROOT, "profiles", "r05", "%sbench_%s.json" % (prefix, name))
+    path = os.path.join(ROOT, "profiles", "r06", "%sbench_%s.json" % (prefix, name))
     if not os.path.exists(path):
         continue
     d = json.load(open(path))
     t, v = tr.get(name), vi.get(name)
+    t = t if isinstance(t, dict) else None
     algo = d["roofline"]["algorithmic_bytes_per_launch"]
     traffic = "%.1f / %.1f MB = %.2f×" % (t["bytes_per_launch"] / 1e6, algo / 1e6, t["bytes_per_launch"] / algo) if t else "not measured"
     valu = "%d" % v["valu_instructions_per_permutation"] if v else "see `%svalu_driver_and_tree_kernels.txt`" % prefix
     frac = (d.get("valu_issue") or {}).get("frac")
-    print("| %s | %s | %.3g | %.3f ms | %.1f GB/s = %.4f | %s | %s | %s |" % (
-        label, d["engine"]["name"].replace("HybridEngine", "HE"), d["value"], d["roofline"]["kernel_ms"], d["roofline"]["achieved"],
-        d["roofline"]["frac"], traffic, valu, "%.2f" % frac if frac else "-"))
+    cn = d.get("clock_normalised") or {}
+    clk = cn.get("shader_clock_hz") or d["int_valu"]["shader_clock_hz"]
+    cpi = cn.get("clocks_per_valu_instruction_and_simd")
+    print("| %s | %s | %.3g (%.2f GHz) | %.3g | %.3f ms | %.1f GB/s = %.4f | %s | %s | %s | %s |" % (
+        label, d["engine"]["name"].replace("HybridEngine", "HE"), d["value"], clk / 1e9, d["value"] * 2.2e9 / clk, d["roofline"]["kernel_ms"], d["roofline"]["achieved"],
+        d["roofline"]["frac"], traffic, valu, "%.2f" % cpi if cpi else "-", "%.2f" % frac if frac else "-"))
