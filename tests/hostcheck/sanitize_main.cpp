@@ -30,10 +30,10 @@ int main() {
         std::vector<uint64_t> base(n * t * 4);
         for (size_t i = 0; i < base.size(); ++i) base[i] = (i % 4 == 3) ? (0x0123456789abcdefull >> 3) % (c.p[3]) : 0x9e3779b97f4a7c15ull * (i + 1);
         std::vector<uint64_t> a = base, b = base, d = base, e = base;
-        if (hc_permute(&cfg, a.data(), n)) { if (t != 2 && t != 3 && t != 4 && t != 5 && t != 9) {} else return 2; }
+        if (hc_permute(&cfg, a.data(), n)) return 2;
         if (hc_permute_rt(&cfg, b.data(), n)) return 3;
-        if (hc_permute_opt(&cfg, d.data(), n)) return 4;
-        if (hc_permute_hybrid(&cfg, e.data(), n)) return 5;
+        if (hc_permute_hybrid_mfma(&cfg, d.data(), n)) return 4;      // the window engines' schedule (int8 tables, row finish)
+        e = d;
         if (a != b || a != d || a != e) { std::printf("schedules disagree\n"); return 6; }
         if (t == 3) {
             std::vector<uint64_t> g = base;
