@@ -738,6 +738,8 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
     mad_rate = mads * per_gpu_units / kernel_s
     traffic, traffic_src = load_traffic(args.workload, per_gpu_units)
     valu_issue = load_valu_issue(args.workload, per_gpu_units, kernel_s, peak.compute_units, mads, info, slot)
+    if mfma_dense and not (merkle or hashing or duplex):
+        price_products(valu_issue, matrix_products_per_permutation(t, rf, rp, int(info.partial_window), int(info.row_tables) == 2), peak.shader_clock_hz)
     out = {
         "metric": "Poseidon permutations/sec (%s, t=%d)" % ({"bls12_381_fr": "BLS12-381 Fr", "bn254_fr": "BN254 Fr"}[field_name], t),
         "value": value, "unit": "permutations/s",
@@ -793,6 +795,39 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
     if launcher:
         out["config"]["launcher"] = launcher
     return out
+
+
+def matrix_products_per_permutation(t, rf, rp, window, hist_rows):
+    """v_mfma_i32_32x32x32_i8 instructions one wave issues per permutation batch of 64 (pmx_permute.hpp: permute_hybrid): two per k-step
+    (states 0-31 and 32-63 of the wave), one k-step per input element of a row.  Every full round closes with a layer of t rows over t
+    inputs; the partial rounds run as ceil(rp / K) windows - the first the short one - each closed by a layer of t rows over t - 1 + K
+    inputs, and (t >= 4) the S-box inputs x_3 .. x_K of a window are rows of 2 .. K - 1 inputs.  (C3: 1296 + 2142 + 424 = 3862, the
+    count of the SQ_INSTS_VALU_MFMA pass in profiles/r06/z_2.27GHz_pmc_c3_stalls.txt.)"""
+    products = rf * t * 2 * t
+    if window and rp:
+        n_win = -(-rp // window)
+        first = rp - (n_win - 1) * window
+        products += n_win * t * 2 * (t - 1 + window)
+        if hist_rows:
+            for kw in [first] + [window] * (n_win - 1):
+                products += sum(2 * k for k in range(2, window) if k < kw)
+    return products
+
+
+def price_products(valu_issue, products, clock_hz):
+    """The floor of `valu_issue` prices VALU instructions only.  A matrix-core product is not free on that port: spread evenly through
+    a wave's multiplies it takes 11.6 clocks of it, issued as a layer issues them - a burst of 2 x n_in per row from two free-running
+    waves per SIMD - 19.5 (tools/mfma_burst_microbench.hip -> profiles/r06/d_mfma_burst_microbench.txt; constants of the part, measured
+    once, scaled by this run's clock).  `frac_products_priced`: (instructions x slot + products x price) / measured time, at both prices."""
+    per, ns, floor = (valu_issue.get(k) for k in ("valu_instructions_per_permutation", "ns_per_instruction_and_simd", "floor_ns_per_instruction_and_simd"))
+    valu_issue["matrix_products_per_permutation"] = products
+    if not (per and ns and floor and clock_hz):
+        return
+    priced = {}
+    for name, clocks in (("spread through the VALU work (11.6 clocks of the port)", 11.6), ("in a layer's bursts (19.5 clocks of the port)", 19.5)):
+        priced[name] = (per * floor + products * clocks / clock_hz * 1e9) / (per * ns)
+    valu_issue["frac_products_priced"] = priced
+    valu_issue["products_price_source"] = "profiles/r06/d_mfma_burst_microbench.txt (tools/mfma_burst_microbench.hip), clocks x this run's shader clock"
 
 
 def clock_normalised(kernel_s, clock_hz, compute_units, permutations_per_gpu_step, valu_issue):
