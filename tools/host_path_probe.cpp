@@ -63,6 +63,44 @@ int main() {
                 printf("rep %d three streams, chunks %2d: %.2f ms\n", rep, chunks, (now() - t0) * 1e3);
             }
         }
+        {   // graded chunks: small first and last pieces (the pipeline's fill and drain are one upload + one kernel and one kernel + one download of those)
+            static hipStream_t up = nullptr, run = nullptr, down = nullptr;
+            static hipEvent_t eu[64], ek[64];
+            if (!up) {
+                CK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&run, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+                for (int i = 0; i < 64; ++i) { CK(hipEventCreateWithFlags(&eu[i], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ek[i], hipEventDisableTiming)); }
+            }
+            const std::vector<std::vector<int>> shapes = {{1, 2, 4, 9, 9, 4, 2, 1}, {1, 3, 6, 6, 6, 6, 3, 1}, {2, 4, 5, 5, 5, 5, 4, 2}, {1, 1, 2, 4, 8, 8, 4, 2, 1, 1}, {1, 2, 3, 4, 6, 6, 4, 3, 2, 1}, {1, 1, 2, 2, 4, 6, 6, 4, 2, 2, 1, 1}};
+            for (const auto &shape : shapes) {
+                int total = 0; for (int w : shape) total += w;
+                t0 = now();
+                size_t at = 0;
+                for (size_t k = 0; k < shape.size(); ++k) {
+                    const size_t cn = k + 1 == shape.size() ? n - at : n * shape[k] / total;
+                    char *h = (char *)host.data() + at * 96, *d = (char *)dev + at * 96;
+                    CK(hipMemcpyAsync(d, h, cn * 96, hipMemcpyHostToDevice, up));
+                    CK(hipEventRecord(eu[k], up)); CK(hipStreamWaitEvent(run, eu[k], 0));
+                    pmx_permute_batch_dev(ctx, (uint64_t *)d, cn, run);
+                    CK(hipEventRecord(ek[k], run)); CK(hipStreamWaitEvent(down, ek[k], 0));
+                    CK(hipMemcpyAsync(h, d, cn * 96, hipMemcpyDeviceToHost, down));
+                    at += cn;
+                }
+                CK(hipStreamSynchronize(down)); CK(hipStreamSynchronize(run)); CK(hipStreamSynchronize(up));
+                printf("rep %d three streams, graded chunks", rep); for (int w : shape) printf(" %d", w); printf(" / %d: %.2f ms\n", total, (now() - t0) * 1e3);
+            }
+        }
+        {   // zero copy: the kernel itself reads the states out of the page-locked host buffer and writes them back there (both directions
+            // of the link at once, no staging, no chunks) - the registered range's device address IS the host address on this platform
+            void *mapped = nullptr;
+            CK(hipHostGetDevicePointer(&mapped, host.data(), 0));
+            for (int chunks : {1, 2, 4}) {
+                t0 = now();
+                const size_t cn = n / chunks;
+                for (int k = 0; k < chunks; ++k) pmx_permute_batch_dev(ctx, (uint64_t *)((char *)mapped + (size_t)k * cn * 96), cn, st[k & 1]);
+                CK(hipStreamSynchronize(st[0])); CK(hipStreamSynchronize(st[1]));
+                printf("rep %d zero copy (kernel on the mapped host buffer), %d launch(es): %.2f ms\n", rep, chunks, (now() - t0) * 1e3);
+            }
+        }
         t0 = now(); CK(hipHostUnregister(host.data())); double tun = now() - t0;
         printf("rep %d: pageable %.2f ms | register %.2f ms, one round trip %.2f ms, unregister %.2f ms\n", rep, ta * 1e3, treg * 1e3, tb * 1e3, tun * 1e3);
     }
