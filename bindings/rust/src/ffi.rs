@@ -120,6 +120,10 @@ extern "C" {
     pub fn pmx_mgpu_permute_shards_dev(g: *mut pmx_mgpu, d_shards: *const *mut u64, n_total: usize) -> c_int;
     pub fn pmx_mgpu_all_gather_dev(g: *mut pmx_mgpu, d_shards: *const *const u64, d_all: *const *mut u64, n_total: usize,
                                    row_elems: usize) -> c_int;
+    pub fn pmx_mgpu_gather_dev(g: *mut pmx_mgpu, d_shards: *const *const u64, d_all: *const *mut u64, n_total: usize, row_elems: usize,
+                               root: c_int) -> c_int;
+    pub fn pmx_mgpu_permute_gather_dev(g: *mut pmx_mgpu, d_shards: *const *mut u64, d_all: *const *mut u64, n_total: usize, root: c_int,
+                                       chunks: c_int) -> c_int;
     pub fn pmx_mgpu_merkle_2to1_dev(g: *mut pmx_mgpu, d_nodes: *const *mut u64, d_top: *const *mut u64, n_leaves: usize) -> c_int;
     pub fn pmx_mgpu_merkle_2to1(g: *mut pmx_mgpu, leaves: *const u64, n_leaves: usize, root: *mut u64) -> c_int;
 }

@@ -41,8 +41,9 @@ extern "C" {
 /* 3: PMX_ERR_HOST, pmx_merkle_verify_paths_dev, indices >= 2^depth fail verification, pmx_ctx_engine_info,
  *    pmx_merkle_2to1_forest[_dev]; the test hooks left this header (poseidon_mi355x_testing.h).
  * 4: the benchmark diagnostics (pmx_diag_*) left the library for libposeidon_mi355x_diag.so (poseidon_mi355x_diag.h); the host-buffer
- *    absorb / squeeze take any length (they cut a call longer than 65536 rates into pieces). */
-#define PMX_ABI_VERSION 4
+ *    absorb / squeeze take any length (they cut a call longer than 65536 rates into pieces).
+ * 5: pmx_mgpu_gather_dev (the result to one rank), pmx_mgpu_permute_gather_dev (the last step and its gather, overlapped). */
+#define PMX_ABI_VERSION 5
 #define PMX_LIMBS 4        /* uint64_t limbs per field element */
 #define PMX_MAX_WIDTH 16   /* largest rate+capacity accepted (reference default table uses 3..9) */
 
@@ -241,8 +242,8 @@ int pmx_merkle_verify_paths_dev(pmx_ctx *ctx, const uint64_t *d_leaves, const ui
  * The reference is single-threaded and has no distributed code; nothing in src/poseidon/mod.rs:62-183 couples one
  * sponge state to another, so n states are cut into `world` contiguous shards (pmx_shard_bounds), one per GPU, and
  * the permutation itself needs NO collective.  RCCL over xGMI is used for the final gather of the result shards
- * (ncclAllGather; a group of ncclBroadcasts when n is not a multiple of world) and for the 32-byte subtree roots of
- * the sharded Merkle reduction.
+ * (to every rank: ncclAllGather, a group of ncclBroadcasts when n is not a multiple of world; to one rank, or piece by piece
+ * behind the last step: grouped ncclSend / ncclRecv) and for the 32-byte subtree roots of the sharded Merkle reduction.
  *
  * A group is either all GPUs of ONE process (pmx_mgpu_create = ncclCommInitAll; this is what a Rust caller uses:
  * BatchPoseidon::new_multi in INTEGRATION.md) or ONE rank of a multi-process job (pmx_mgpu_create_rank =
@@ -298,6 +299,16 @@ int pmx_mgpu_permute_shards_dev(pmx_mgpu *g, uint64_t *const *d_shards, size_t n
  * (row_elems = t for states, 1 for digests).  RCCL; only enqueues. */
 int pmx_mgpu_all_gather_dev(pmx_mgpu *g, const uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total,
                             size_t row_elems);
+/* The gather to ONE rank: only `root` ends with all shards (d_all of its slot; the other slots' entries are not read and may be
+ * NULL).  Every other rank sends its shard over its own link to the root - 1 / world of the all-gather's bytes per link.  Grouped
+ * ncclSend / ncclRecv; only enqueues. */
+int pmx_mgpu_gather_dev(pmx_mgpu *g, const uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total, size_t row_elems,
+                        int root);
+/* The LAST step of a job and its gather, overlapped: pmx_mgpu_permute_shards_dev in `chunks` pieces per shard (1 .. 16), piece i's
+ * transfers - to rank `root`, or to every rank when root < 0 - posted on a second stream of each slot behind piece i's kernel, so
+ * the links carry piece i while pieces i + 1 ... are computed.  To the streams of pmx_mgpu_stream the call is the permutation
+ * followed by the gather (they wait for the transfers at the end).  d_all as above.  Only enqueues. */
+int pmx_mgpu_permute_gather_dev(pmx_mgpu *g, uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total, int root, int chunks);
 /* 2-to-1 Merkle tree of n_leaves = world * m leaves (both powers of two): d_nodes[local] = [2m-1][4] holds that rank's
  * m leaves in its first m rows and receives its subtree (pmx_merkle_2to1_dev); the `world` subtree roots are
  * all-gathered into d_top[local] = [2*world-1][4], which then receives the top levels, root last (world = 1: [1][4]).

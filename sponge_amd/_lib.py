@@ -22,7 +22,7 @@ PMX_ERR_UNSUPPORTED = -4
 PMX_ERR_RCCL = -5
 PMX_ERR_HOST = -6
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 UNIQUE_ID_BYTES = 128
 MAX_LOCAL_DEVICES = 16
 
@@ -143,6 +143,8 @@ SIGNATURES = {
     "pmx_mgpu_hash_batch": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p, _sz, _sz]),
     "pmx_mgpu_permute_shards_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _sz]),
     "pmx_mgpu_all_gather_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
+    "pmx_mgpu_gather_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz, ctypes.c_int]),
+    "pmx_mgpu_permute_gather_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, ctypes.c_int, ctypes.c_int]),
     "pmx_mgpu_merkle_2to1_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz]),
     "pmx_mgpu_merkle_2to1": (ctypes.c_int, [ctypes.c_void_p, _u64p, _sz, _u64p]),
 }

@@ -467,10 +467,14 @@ struct ScopedPin {
     static constexpr size_t kMinBytes = (size_t)16 << 20;   // below this the registration costs more than it saves
 };
 
-// chunks of a batch for the pinned pipeline: rows per chunk (multiple of 256), at most 8 chunks
+// chunks of a batch for the pinned pipeline: rows per chunk (a multiple of 256).  A chunk is a kernel launch of its own: at least 65536
+// rows (below that a launch is bound by one permutation's latency, at t = 3 on the lone-permutation kernels), at most kPipeChunks chunks
+// (2^20 t = 3 states: 16 chunks 2.50 ms, 8 chunks 2.56, 32 chunks 4.2 - profiles/r06/g_host_path_probe_graded_chunks_and_zero_copy_not_kept.txt)
 static size_t pipeline_rows(size_t n) {
-    if (n < ((size_t)1 << 16)) return n;
-    const size_t rows = (n + 7) / 8;
+    size_t chunks = n >> 16;
+    if (chunks <= 1) return n;
+    if (chunks > (size_t)pmx_ctx::kPipeChunks) chunks = pmx_ctx::kPipeChunks;
+    const size_t rows = (n + chunks - 1) / chunks;
     return (rows + 255) / 256 * 256;
 }
 

@@ -18,7 +18,7 @@ struct pmx_ctx {
     hipStream_t stream = nullptr;    // used by the host-buffer entry points (and by a device group for this device)
     hipStream_t stream2 = nullptr;   // the pinned-memory pipeline: `stream` only uploads, `stream2` only computes, `stream3` only downloads
     hipStream_t stream3 = nullptr;
-    static constexpr int kPipeChunks = 8;
+    static constexpr int kPipeChunks = 16;
     hipEvent_t pipe_up[kPipeChunks] = {}, pipe_done[kPipeChunks] = {};   // chunk i uploaded / computed (created with the context)
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // grow-only device staging for the host-buffer entry points
     size_t scratch_bytes[4] = {0, 0, 0, 0};

@@ -2,8 +2,10 @@
 //
 // Sponge states are independent - the reference has no cross-state data flow anywhere in src/poseidon/mod.rs:62-183 -
 // so the batch is cut into contiguous shards [g n / G, (g+1) n / G), one per GPU, and the data path needs NO
-// collective.  RCCL moves data in exactly two places: the final gather of the result shards (ncclAllGather, or a group
-// of ncclBroadcasts when the shards are ragged) and the 32-byte subtree roots of the sharded Merkle reduction.
+// collective.  RCCL moves data in exactly two places: the final gather of the result shards - to every rank (ncclAllGather, or a
+// group of ncclBroadcasts when the shards are ragged) or to one (grouped ncclSend / ncclRecv: 1 / world of the bytes per link),
+// as one call behind the last step or piece by piece behind the pieces of that step - and the 32-byte subtree roots of the
+// sharded Merkle reduction.
 //
 // A group is either every GPU of one process (pmx_mgpu_create: ncclCommInitAll, one host thread drives all devices)
 // or one rank of a multi-process job (pmx_mgpu_create_rank: ncclCommInitRank with an id made by pmx_mgpu_unique_id
@@ -54,6 +56,8 @@ struct Rccl {
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -99,6 +103,8 @@ Rccl &rccl_lib() {
         r->CommUserRank = (decltype(r->CommUserRank))sym("ncclCommUserRank");
         r->AllGather = (decltype(r->AllGather))sym("ncclAllGather");
         r->Broadcast = (decltype(r->Broadcast))sym("ncclBroadcast");
+        r->Send = (decltype(r->Send))sym("ncclSend");
+        r->Recv = (decltype(r->Recv))sym("ncclRecv");
         r->GroupStart = (decltype(r->GroupStart))sym("ncclGroupStart");
         r->GroupEnd = (decltype(r->GroupEnd))sym("ncclGroupEnd");
         r->GetErrorString = (decltype(r->GetErrorString))sym("ncclGetErrorString");
@@ -454,6 +460,126 @@ extern "C" int pmx_mgpu_all_gather_dev(pmx_mgpu *g, const uint64_t *const *d_sha
     ncclResult_t e = rccl_lib().GroupEnd();
     if (r != ncclSuccess) return rccl_fail(r, equal ? "ncclAllGather" : "ncclBroadcast");
     if (e != ncclSuccess) return rccl_fail(e, "ncclGroupEnd");
+    return PMX_OK;
+    PMX_ABI_END
+}
+
+// ---- gather to one rank, and the gather piece by piece behind the last step ---------------------------------------------
+// piece i of `chunks` of a shard of `count` units
+static void piece_span(size_t count, int chunks, int i, size_t *first, size_t *cnt) {
+    const size_t lo = count / (size_t)chunks * (size_t)i + count % (size_t)chunks * (size_t)i / (size_t)chunks;
+    const size_t hi = count / (size_t)chunks * (size_t)(i + 1) + count % (size_t)chunks * (size_t)(i + 1) / (size_t)chunks;
+    *first = lo;
+    *cnt = hi - lo;
+}
+
+// Inside an open group: the transfers of piece i of every shard, on the slots' first or second stream.  root >= 0: every other
+// rank's piece goes to `root` (one ncclSend per rank, world - 1 ncclRecv on the root); root < 0: to every rank.  A rank that receives
+// also copies its own piece into its copy of the result.  Every rank derives every other rank's piece from (n_total, world, chunks, i)
+// alone, so the sends and the receives of a pair always agree.
+static int post_piece(pmx_mgpu *g, const uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total, size_t words, int root, int chunks, int i,
+                      bool second_stream, ncclResult_t *nr, const char **what) {
+    for (size_t l = 0; l < g->ctx.size(); ++l) {
+        const int me = g->first_rank + (int)l;
+        const bool i_receive = root < 0 || root == me;
+        DeviceGuard guard(g->device[l]);
+        if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+        hipStream_t st = second_stream ? g->ctx[l]->stream2 : g->ctx[l]->stream;
+        size_t start = 0, count = 0, pf = 0, pc = 0;
+        (void)pmx_shard_bounds(n_total, g->world, me, &start, &count);
+        piece_span(count, chunks, i, &pf, &pc);
+        const uint64_t *mine = d_shards[l] + pf * words;
+        if (i_receive && pc && d_all[l] + (start + pf) * words != mine)
+            PMX_HIP(hipMemcpyAsync(d_all[l] + (start + pf) * words, mine, pc * words * 8, hipMemcpyDeviceToDevice, st));
+        for (int peer = 0; peer < g->world; ++peer) {
+            if (peer == me) continue;
+            if ((root < 0 || root == peer) && pc) {
+                *nr = rccl_lib().Send(mine, pc * words, ncclUint64, peer, g->comm[l], st);
+                if (*nr != ncclSuccess) { *what = "ncclSend"; return PMX_OK; }
+            }
+            if (i_receive) {
+                size_t qs = 0, qn = 0, qf = 0, qc = 0;
+                (void)pmx_shard_bounds(n_total, g->world, peer, &qs, &qn);
+                piece_span(qn, chunks, i, &qf, &qc);
+                if (qc) {
+                    *nr = rccl_lib().Recv(d_all[l] + (qs + qf) * words, qc * words, ncclUint64, peer, g->comm[l], st);
+                    if (*nr != ncclSuccess) { *what = "ncclRecv"; return PMX_OK; }
+                }
+            }
+        }
+    }
+    return PMX_OK;
+}
+
+// one group: GroupStart, the piece, GroupEnd - with the error of whichever call failed first
+static int gather_piece(pmx_mgpu *g, const uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total, size_t words, int root, int chunks, int i,
+                        bool second_stream) {
+    if (g->world == 1) {   // nobody to talk to: the copy of the own piece is all there is (and RCCL is not entered with an empty group)
+        ncclResult_t nr = ncclSuccess;
+        const char *what = "";
+        return post_piece(g, d_shards, d_all, n_total, words, root, chunks, i, second_stream, &nr, &what);
+    }
+    PMX_RCCL(rccl_lib().GroupStart());
+    ncclResult_t nr = ncclSuccess;
+    const char *what = "";
+    const int rc = post_piece(g, d_shards, d_all, n_total, words, root, chunks, i, second_stream, &nr, &what);
+    const ncclResult_t e = rccl_lib().GroupEnd();
+    if (rc) return rc;
+    if (nr != ncclSuccess) return rccl_fail(nr, what);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupEnd");
+    return PMX_OK;
+}
+
+static int gather_args(const pmx_mgpu *g, const void *d_shards, uint64_t *const *d_all, int root, const char *who) {
+    if (!g || !d_shards || !d_all) return set_error(PMX_ERR_ARG, "%s: null pointer", who);
+    if (root >= g->world) return set_error(PMX_ERR_ARG, "%s: root %d out of range [0,%d) (negative: every rank)", who, root, g->world);
+    for (size_t l = 0; l < g->ctx.size(); ++l)
+        if ((root < 0 || root == g->first_rank + (int)l) && !d_all[l]) return set_error(PMX_ERR_ARG, "%s: slot %zu receives the result and has no buffer for it", who, l);
+    return PMX_OK;
+}
+
+extern "C" int pmx_mgpu_gather_dev(pmx_mgpu *g, const uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total, size_t row_elems, int root) {
+    PMX_ABI_BEGIN("pmx_mgpu_gather_dev")
+    if (int rc = gather_args(g, d_shards, d_all, root, "pmx_mgpu_gather_dev")) return rc;
+    if (root < 0) return set_error(PMX_ERR_ARG, "pmx_mgpu_gather_dev: root %d out of range [0,%d) (pmx_mgpu_all_gather_dev gathers to every rank)", root, g->world);
+    if (row_elems == 0 || n_total == 0) return PMX_OK;
+    if (n_total > SIZE_MAX / (row_elems * 32)) return set_error(PMX_ERR_ARG, "gather byte size overflows size_t");
+    return gather_piece(g, d_shards, d_all, n_total, row_elems * 4, root, 1, 0, false);
+    PMX_ABI_END
+}
+
+// The last step of a job and its gather in one call.  Every local shard is permuted in `chunks` pieces on the slot's stream; piece i's
+// transfers are posted on the slot's SECOND stream behind an event of piece i's kernel, so that the links carry piece i while the
+// kernels of pieces i + 1 ... run; at the end the slot's stream waits for its second stream - to the caller's stream order the call
+// is pmx_mgpu_permute_shards_dev followed by the gather.  The transfers are point to point whatever the root: a piece lands inside its
+// rank's span, which one ncclAllGather cannot do (its layout is rank-major per call).
+extern "C" int pmx_mgpu_permute_gather_dev(pmx_mgpu *g, uint64_t *const *d_shards, uint64_t *const *d_all, size_t n_total, int root, int chunks) {
+    PMX_ABI_BEGIN("pmx_mgpu_permute_gather_dev")
+    if (int rc = gather_args(g, d_shards, d_all, root, "pmx_mgpu_permute_gather_dev")) return rc;
+    if (chunks < 1 || chunks > pmx_ctx::kPipeChunks) return set_error(PMX_ERR_ARG, "pmx_mgpu_permute_gather_dev: chunks %d out of range [1,%d]", chunks, pmx_ctx::kPipeChunks);
+    if (n_total == 0) return PMX_OK;
+    if (n_total > SIZE_MAX / ((size_t)g->t * 32)) return set_error(PMX_ERR_ARG, "gather byte size overflows size_t");
+    const size_t words = (size_t)g->t * 4;
+    for (int i = 0; i < chunks; ++i) {
+        for (size_t l = 0; l < g->ctx.size(); ++l) {
+            size_t start = 0, count = 0, pf = 0, pc = 0;
+            int rc = local_span(g, n_total, l, &start, &count);
+            if (rc) return rc;
+            piece_span(count, chunks, i, &pf, &pc);
+            pmx_ctx *c = g->ctx[l];
+            if (pc && (rc = pmx_permute_batch_dev(c, d_shards[l] + pf * words, pc, c->stream))) return rc;
+            PMX_BIND(c);
+            PMX_HIP(hipEventRecord(c->pipe_done[i], c->stream));
+            PMX_HIP(hipStreamWaitEvent(c->stream2, c->pipe_done[i], 0));
+        }
+        if (int rc = gather_piece(g, d_shards, d_all, n_total, words, root, chunks, i, true)) return rc;
+    }
+    for (size_t l = 0; l < g->ctx.size(); ++l) {
+        pmx_ctx *c = g->ctx[l];
+        PMX_BIND(c);
+        PMX_HIP(hipEventRecord(c->pipe_up[0], c->stream2));
+        PMX_HIP(hipStreamWaitEvent(c->stream, c->pipe_up[0], 0));
+    }
     return PMX_OK;
     PMX_ABI_END
 }

@@ -138,5 +138,13 @@ class DeviceGroup:
     def all_gather_dev(self, d_shards: Sequence[int], d_all: Sequence[int], n_total: int, row_elems: int) -> None:
         _lib.check(_lib.lib().pmx_mgpu_all_gather_dev(self._h, _ptr_array(d_shards), _ptr_array(d_all), n_total, row_elems))
 
+    def gather_dev(self, d_shards: Sequence[int], d_all: Sequence[int], n_total: int, row_elems: int, root: int) -> None:
+        """the result to ONE rank (d_all entries of the other slots are not read: pass 0)"""
+        _lib.check(_lib.lib().pmx_mgpu_gather_dev(self._h, _ptr_array(d_shards), _ptr_array(d_all), n_total, row_elems, root))
+
+    def permute_gather_dev(self, d_shards: Sequence[int], d_all: Sequence[int], n_total: int, root: int = -1, chunks: int = 8) -> None:
+        """the last step and its gather (root < 0: to every rank), the transfers of piece i behind piece i's kernel"""
+        _lib.check(_lib.lib().pmx_mgpu_permute_gather_dev(self._h, _ptr_array(d_shards), _ptr_array(d_all), n_total, root, chunks))
+
     def merkle_2to1_dev(self, d_nodes: Sequence[int], d_top: Sequence[int], n_leaves: int) -> None:
         _lib.check(_lib.lib().pmx_mgpu_merkle_2to1_dev(self._h, _ptr_array(d_nodes), _ptr_array(d_top), n_leaves))

@@ -3,7 +3,7 @@
 // Why it exists: the device-group code of the product (sponge_amd/csrc/pmx_mgpu.cpp) binds RCCL with
 // dlopen("librccl.so.1").  The development boxes have ONE GPU and RCCL refuses two ranks on one device, so every
 // world > 1 branch of that file - shard offsets, the `mine` test of the ragged gather, the d_top layout of the sharded
-// tree, the host fan-out with more than one worker thread - could not execute there.  This library exports the twelve
+// tree, the host fan-out with more than one worker thread - could not execute there.  This library exports the fourteen
 // entry points the product binds, with communicators that are plain structs whose "ranks" may all live on the same
 // device: a collective is performed as device-to-device hipMemcpyAsync on the streams the caller gave, ordered with
 // events exactly as far as RCCL's stream semantics promise (a rank's receive buffer is complete when ITS stream reaches
@@ -23,6 +23,12 @@
 //                                      send == recv + rank * count
 //   ncclBroadcast(send, recv, count, root)   every rank's recv = the root's send; the non-roots' send is ignored; in
 //                                      place on the root when send == recv
+//   ncclSend(send, count, peer) / ncclRecv(recv, count, peer)   point to point: the i-th message rank a ever sends to rank b is the
+//                                      i-th rank b ever receives from rank a (same count and type, or both calls are refused).  Only the
+//                                      two ranks of a message take part - a rank with nothing to send or receive posts nothing, as with
+//                                      RCCL.  A rank's group returns when all its messages have been matched and enqueued; a message
+//                                      whose other half does not appear within 30 s is an error where RCCL would hang.  A group holds
+//                                      collectives or point-to-point calls, not both (the product never mixes them)
 //   ncclGroupStart / ncclGroupEnd      calls inside a group are queued per communicator and performed at the outermost
 //                                      GroupEnd; the k-th queued call of every rank of a communicator is one collective
 //   ncclCommInitAll                    one thread owns all ranks;   ncclCommInitRank   ranks are joined by id, inside ONE
@@ -45,7 +51,10 @@
 
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -55,7 +64,8 @@
 
 namespace {
 
-enum Kind { kAllGather = 0, kBroadcast = 1 };
+enum Kind { kAllGather = 0, kBroadcast = 1, kSend = 2, kRecv = 3 };   // (kSend / kRecv: `root` is the peer)
+inline bool is_p2p(Kind k) { return k == kSend || k == kRecv; }
 
 struct Op {
     Kind kind;
@@ -79,7 +89,18 @@ struct Clique {
     std::vector<std::vector<Op>> posted;     // by rank
     ncclResult_t last_result = ncclSuccess;  // result of the round that ended at `epoch`
     std::vector<hipEvent_t> events;          // every event a collective made; destroyed with the last communicator
+    // point to point: halves of messages whose other half has not been posted yet, by (source, destination), oldest first
+    std::map<std::pair<int, int>, std::deque<struct Half *>> open_sends, open_recvs;
 };
+
+// one posted ncclSend / ncclRecv of a rank of a clique (owned by the posting communicator until matched or given up)
+struct Half {
+    Op op;
+    int rank = 0;
+    bool matched = false;
+    ncclResult_t rc = ncclSuccess;
+};
+constexpr double kP2PTimeout = 30.0;   // seconds a posted half waits for the other one
 
 }  // namespace
 
@@ -93,18 +114,19 @@ struct ncclComm {
     int device = 0;
     std::vector<Op> pending;                 // queued inside a group by the owning thread
     uint64_t post_epoch = 0;
+    std::vector<std::unique_ptr<Half>> halves;   // the point-to-point calls of the group being flushed
 };
 
 namespace {
 
 // ---- statistics and fault injection (read by the tests through fake_rccl_* below) --------------------------------------
 struct Stats {
-    std::atomic<long> all_gathers{0}, broadcasts{0}, groups{0}, copies{0}, inplace_skips{0}, comms_created{0}, comms_destroyed{0};
+    std::atomic<long> all_gathers{0}, broadcasts{0}, groups{0}, copies{0}, inplace_skips{0}, comms_created{0}, comms_destroyed{0}, messages{0};
     std::atomic<long long> bytes{0};
 };
 Stats g_stats;
 // fail the n-th next call (1 = the very next) of one entry point: 0 none, 1 AllGather, 2 Broadcast, 3 GroupEnd,
-// 4 CommInitAll, 5 CommInitRank, 6 GetUniqueId, 7 GroupStart
+// 4 CommInitAll, 5 CommInitRank, 6 GetUniqueId, 7 GroupStart, 8 Send, 9 Recv
 std::atomic<int> g_fail_which{0}, g_fail_countdown{0};
 bool injected(int which) {
     if (g_fail_which.load() != which) return false;
@@ -254,6 +276,101 @@ ncclResult_t perform(Clique *c, const std::vector<Op> &op) {
     return ncclSuccess;
 }
 
+// one message: both halves are posted.  Called with the clique's lock held, by whichever rank posted second.
+void deliver(Clique *c, Half *sh, Half *rh) {
+    const Op &so = sh->op, &ro = rh->op;
+    const int s = sh->rank, d = rh->rank;
+    auto both = [&](ncclResult_t rc) { sh->rc = rh->rc = rc; sh->matched = rh->matched = true; };
+    if (so.count != ro.count || so.type != ro.type) {
+        char msg[200];
+        std::snprintf(msg, sizeof msg, "a message from rank %d to rank %d: sent as %zu elements, received as %zu", s, d, so.count, ro.count);
+        return both(fail(ncclInvalidArgument, msg));
+    }
+    const size_t esz = type_bytes(so.type), bytes = so.count * esz;
+    if (esz == 0) return both(fail(ncclInvalidArgument, "unsupported datatype"));
+    ncclResult_t rc;
+    { DeviceScope ds(c->member[(size_t)s]->device); rc = check_range(so.send, bytes, "ncclSend sendbuff", s); }
+    if (rc == ncclSuccess) { DeviceScope ds(c->member[(size_t)d]->device); rc = check_range(ro.recv, bytes, "ncclRecv recvbuff", d); }
+    if (rc != ncclSuccess) return both(rc);
+    if (bytes == 0) return both(ncclSuccess);
+    auto enqueue_copy = [&]() -> ncclResult_t {
+        hipEvent_t ready = nullptr, done = nullptr;
+        {
+            DeviceScope ds(c->member[(size_t)s]->device);
+            FAKE_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+            c->events.push_back(ready);
+            FAKE_HIP(hipEventRecord(ready, so.stream));          // the send buffer holds the data (the sender's thread is inside its group: nothing newer is on its stream)
+        }
+        {
+            DeviceScope ds(c->member[(size_t)d]->device);
+            FAKE_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            c->events.push_back(done);
+            FAKE_HIP(hipStreamWaitEvent(ro.stream, ready, 0));
+            FAKE_HIP(hipMemcpyAsync(ro.recv, so.send, bytes, hipMemcpyDeviceToDevice, ro.stream));
+            FAKE_HIP(hipEventRecord(done, ro.stream));
+        }
+        {
+            DeviceScope ds(c->member[(size_t)s]->device);
+            FAKE_HIP(hipStreamWaitEvent(so.stream, done, 0));     // the sender's stream may not overwrite the buffer before it was read
+        }
+        return ncclSuccess;
+    };
+    rc = enqueue_copy();
+    if (rc == ncclSuccess) {
+        g_stats.copies++;
+        g_stats.messages++;
+        g_stats.bytes += (long long)bytes;
+    }
+    both(rc);
+}
+
+// a rank posts the point-to-point calls of its group: every half whose other half is already there is delivered now
+ncclResult_t post_halves(ncclComm *comm, std::vector<Op> &&ops) {
+    Clique *c = comm->clique;
+    std::lock_guard<std::mutex> l(c->m);
+    for (const Op &o : ops) {
+        if (o.root < 0 || o.root >= c->world) return fail(ncclInvalidArgument, "peer " + std::to_string(o.root) + " out of range on rank " + std::to_string(comm->rank));
+        comm->halves.emplace_back(new Half{o, comm->rank});
+        Half *h = comm->halves.back().get();
+        const bool send = o.kind == kSend;
+        const std::pair<int, int> key = send ? std::make_pair(comm->rank, o.root) : std::make_pair(o.root, comm->rank);
+        auto &mine = send ? c->open_sends[key] : c->open_recvs[key];
+        auto &other = send ? c->open_recvs[key] : c->open_sends[key];
+        if (mine.empty() && !other.empty()) {      // (mine not empty: an older half of this pair is still waiting - order is kept)
+            Half *o2 = other.front();
+            other.pop_front();
+            deliver(c, send ? h : o2, send ? o2 : h);
+        } else {
+            mine.push_back(h);
+        }
+    }
+    c->cv.notify_all();
+    return ncclSuccess;
+}
+
+// ... and waits until all of them have been (a half nobody answers within kP2PTimeout is given up: RCCL would hang there)
+ncclResult_t wait_halves(ncclComm *comm) {
+    Clique *c = comm->clique;
+    std::unique_lock<std::mutex> l(c->m);
+    auto all_matched = [&] { for (auto &h : comm->halves) if (!h->matched) return false; return true; };
+    const bool in_time = c->cv.wait_for(l, std::chrono::duration<double>(kP2PTimeout), all_matched);
+    ncclResult_t result = ncclSuccess;
+    if (!in_time) {
+        int left = 0;
+        for (auto &h : comm->halves) {
+            if (h->matched) continue;
+            ++left;
+            const bool send = h->op.kind == kSend;
+            auto &q = send ? c->open_sends[{comm->rank, h->op.root}] : c->open_recvs[{h->op.root, comm->rank}];
+            for (auto it = q.begin(); it != q.end(); ++it) if (*it == h.get()) { q.erase(it); break; }
+        }
+        result = fail(ncclInvalidUsage, "rank " + std::to_string(comm->rank) + ": " + std::to_string(left) + " point-to-point calls of a group found no partner within 30 s (RCCL would hang here)");
+    }
+    for (auto &h : comm->halves) if (h->matched && h->rc != ncclSuccess && result == ncclSuccess) result = h->rc;
+    comm->halves.clear();
+    return result;
+}
+
 // every rank has posted: the k-th call of each rank is one collective
 ncclResult_t run_round(Clique *c) {
     const size_t n_ops = c->posted[0].size();
@@ -290,6 +407,32 @@ ncclResult_t flush_group() {
         const ncclResult_t rc = x_perform(comm, ops);
         if (rc != ncclSuccess) x_result = rc;
     }
+    // point-to-point groups: only the ranks of a message take part - every communicator of this thread posts its halves, then waits for them
+    // (a thread that owns both ranks of a message has delivered it by the time it waits)
+    ncclResult_t p2p_result = ncclSuccess;
+    {
+        std::vector<ncclComm *> collectives, p2p;
+        for (ncclComm *comm : touched) {
+            size_t n = 0;
+            for (const Op &o : comm->pending) n += is_p2p(o.kind);
+            if (n && n != comm->pending.size()) {
+                comm->pending.clear();
+                p2p_result = fail(ncclInvalidUsage, "a group with collectives AND point-to-point calls: not something the stand-in models");
+            } else (n ? p2p : collectives).push_back(comm);
+        }
+        for (ncclComm *comm : p2p) {
+            std::vector<Op> ops;
+            ops.swap(comm->pending);
+            const ncclResult_t rc = post_halves(comm, std::move(ops));
+            if (rc != ncclSuccess) p2p_result = rc;
+        }
+        for (ncclComm *comm : p2p) {
+            const ncclResult_t rc = wait_halves(comm);
+            if (rc != ncclSuccess) p2p_result = rc;
+        }
+        touched.swap(collectives);
+    }
+    if (p2p_result != ncclSuccess) x_result = p2p_result;
     // post everything this thread queued (a thread that owns all ranks of a communicator completes the round itself)
     for (ncclComm *comm : touched) {
         Clique *c = comm->clique;
@@ -335,12 +478,22 @@ struct XDesc {
     int kind, root, type, rc;
     unsigned long long count, n_ops;
 };
+constexpr int kXRing = 32;           // messages one rank may have in flight to one peer
+struct XMessage {
+    unsigned long long count, offset;   // offset into the sender's staging object
+    int type, rc;                       // rc: the receiver's verdict, written before it counts the message as taken
+};
+struct XPair {                          // source -> destination
+    std::atomic<unsigned long long> sent, taken;   // messages ever posted by the source / consumed by the destination
+    XMessage ring[kXRing];
+};
 struct XShared {
     std::atomic<unsigned> magic;
     int world;
     std::atomic<int> joined, left;
     std::atomic<int> bar_count, bar_sense;
     XDesc desc[kXMaxWorld];
+    XPair pair[kXMaxWorld][kXMaxWorld]; // [source][destination] (pages nobody touches are never backed)
 };
 struct XComm {
     XShared *sh = nullptr;
@@ -393,23 +546,110 @@ ncclResult_t x_stage(ncclComm *c, size_t bytes) {
 }
 
 // copy `bytes` of rank j's staging object to dst (device) on st
-ncclResult_t x_fetch(ncclComm *c, int j, void *dst, size_t bytes, hipStream_t st) {
+ncclResult_t x_fetch(ncclComm *c, int j, void *dst, size_t bytes, hipStream_t st, size_t offset = 0) {
     XComm *x = c->x;
     if (j == c->rank) {
-        FAKE_HIP(hipMemcpyAsync(dst, x->data, bytes, hipMemcpyHostToDevice, st));
+        FAKE_HIP(hipMemcpyAsync(dst, (const char *)x->data + offset, bytes, hipMemcpyHostToDevice, st));
         FAKE_HIP(hipStreamSynchronize(st));
         return ncclSuccess;
     }
     const int fd = shm_open(x_data_name(x->token, j).c_str(), O_RDONLY, 0);
     if (fd < 0) return fail(ncclSystemError, "rank " + std::to_string(j) + "'s staging object cannot be opened: " + std::strerror(errno));
-    void *m = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
+    void *m = mmap(nullptr, offset + bytes, PROT_READ, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return fail(ncclSystemError, std::string("mmap of a peer's staging object: ") + std::strerror(errno));
-    hipError_t e = hipMemcpyAsync(dst, m, bytes, hipMemcpyHostToDevice, st);
+    hipError_t e = hipMemcpyAsync(dst, (const char *)m + offset, bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    munmap(m, bytes);
+    munmap(m, offset + bytes);
     if (e != hipSuccess) return fail(ncclUnhandledCudaError, std::string("copy from a peer's staging object: ") + hipGetErrorString(e));
     return ncclSuccess;
+}
+
+// a group of point-to-point calls, ranks in different processes.  Only the two ranks of a message meet: the sender stages the data in its
+// own object and lists the message in the pair's ring; the receiver waits for the ring entry, takes the data out of the sender's object,
+// leaves its verdict and counts the message as taken; the sender returns when all its messages were taken.
+ncclResult_t x_p2p(ncclComm *c, const std::vector<Op> &ops) {
+    XShared *sh = c->x->sh;
+    const int W = c->world, me = c->rank;
+    ncclResult_t mine = ncclSuccess;
+    size_t total = 0;
+    std::vector<size_t> offset(ops.size(), 0);
+    for (size_t k = 0; k < ops.size() && mine == ncclSuccess; ++k) {
+        const Op &o = ops[k];
+        const size_t esz = type_bytes(o.type), bytes = o.count * esz;
+        if (esz == 0) mine = fail(ncclInvalidArgument, "unsupported datatype");
+        else if (o.root < 0 || o.root >= W) mine = fail(ncclInvalidArgument, "peer " + std::to_string(o.root) + " out of range on rank " + std::to_string(me));
+        else if (o.kind == kSend) {
+            mine = check_range(o.send, bytes, "ncclSend sendbuff", me);
+            offset[k] = total;
+            total += (bytes + 15) & ~(size_t)15;
+        } else {
+            mine = check_range(o.recv, bytes, "ncclRecv recvbuff", me);
+        }
+    }
+    if (mine != ncclSuccess) return mine;
+    if (total && (mine = x_stage(c, total)) != ncclSuccess) return mine;
+    // post the sends
+    std::vector<std::pair<int, unsigned long long>> posted;   // (destination, sequence number)
+    for (size_t k = 0; k < ops.size(); ++k) {
+        const Op &o = ops[k];
+        if (o.kind != kSend) continue;
+        const size_t bytes = o.count * type_bytes(o.type);
+        hipError_t e = hipStreamSynchronize(o.stream);            // everything enqueued before the call has happened
+        if (e == hipSuccess && bytes) e = hipMemcpy((char *)c->x->data + offset[k], o.send, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(ncclUnhandledCudaError, std::string("staging a send buffer: ") + hipGetErrorString(e));
+        XPair &p = sh->pair[me][o.root];
+        const unsigned long long seq = p.sent.load(std::memory_order_relaxed);
+        if (seq - p.taken.load(std::memory_order_acquire) >= (unsigned long long)kXRing)
+            return fail(ncclInvalidUsage, "more messages in flight to one peer than the stand-in's ring holds");
+        p.ring[seq % kXRing] = XMessage{o.count, offset[k], (int)o.type, 0};
+        p.sent.store(seq + 1, std::memory_order_release);
+        posted.emplace_back(o.root, seq);
+    }
+    auto wait_for = [&](std::atomic<unsigned long long> &counter, unsigned long long above, const std::string &what) -> ncclResult_t {
+        const double t0 = now_s();
+        for (unsigned spin = 0; counter.load(std::memory_order_acquire) <= above; ++spin) {
+            if (spin > 1000) usleep(100);
+            if ((spin & 1023) == 1023 && now_s() - t0 > 30.0) return fail(ncclInvalidUsage, "rank " + std::to_string(me) + ": " + what + " within 30 s (RCCL would hang here)");
+        }
+        return ncclSuccess;
+    };
+    // take what the receives name
+    for (const Op &o : ops) {
+        if (o.kind != kRecv) continue;
+        XPair &p = sh->pair[o.root][me];
+        const unsigned long long seq = p.taken.load(std::memory_order_relaxed);
+        ncclResult_t rc = wait_for(p.sent, seq, "a receive from rank " + std::to_string(o.root) + " found no send");
+        if (rc != ncclSuccess) { mine = rc; break; }
+        XMessage &m = p.ring[seq % kXRing];
+        ncclResult_t verdict = ncclSuccess;
+        if (m.count != o.count || m.type != (int)o.type) {
+            char msg[200];
+            std::snprintf(msg, sizeof msg, "a message from rank %d to rank %d: sent as %llu elements, received as %zu", o.root, me, m.count, o.count);
+            verdict = fail(ncclInvalidArgument, msg);
+        } else if (o.count) {
+            const size_t bytes = o.count * type_bytes(o.type);
+            if (hipStreamSynchronize(o.stream) != hipSuccess) verdict = fail(ncclUnhandledCudaError, "the receiver's stream failed");
+            else verdict = x_fetch(c, o.root, o.recv, bytes, o.stream, (size_t)m.offset);
+            if (verdict == ncclSuccess) {
+                g_stats.copies++;
+                g_stats.messages++;
+                g_stats.bytes += (long long)bytes;
+            }
+        }
+        m.rc = (int)verdict;
+        p.taken.store(seq + 1, std::memory_order_release);
+        if (verdict != ncclSuccess && mine == ncclSuccess) mine = verdict;
+    }
+    // the staging object may be reused once every message was taken
+    for (const auto &ps : posted) {
+        XPair &p = sh->pair[me][ps.first];
+        ncclResult_t rc = wait_for(p.taken, ps.second, "a send to rank " + std::to_string(ps.first) + " found no receive");
+        if (rc != ncclSuccess) { if (mine == ncclSuccess) mine = rc; continue; }
+        const int verdict = p.ring[ps.second % kXRing].rc;
+        if (verdict != 0 && mine == ncclSuccess) mine = fail((ncclResult_t)verdict, "rank " + std::to_string(ps.first) + " refused a message (its process has the reason)");
+    }
+    return mine;
 }
 
 // the calls one rank queued in a group (or one call outside a group); every rank of the communicator is in here with its own
@@ -417,6 +657,10 @@ ncclResult_t x_perform(ncclComm *c, const std::vector<Op> &ops) {
     XShared *sh = c->x->sh;
     const int W = c->world, me = c->rank;
     ncclResult_t rc;
+    size_t p2p = 0;
+    for (const Op &o : ops) p2p += is_p2p(o.kind);
+    if (p2p && p2p != ops.size()) return fail(ncclInvalidUsage, "a group with collectives AND point-to-point calls: not something the stand-in models");
+    if (p2p) return x_p2p(c, ops);      // (only the ranks of a message meet: no barrier over the communicator)
     sh->desc[me].n_ops = ops.size();
     if ((rc = x_barrier(c, "the start of a group")) != ncclSuccess) return rc;
     ncclResult_t verdict = ncclSuccess;
@@ -711,6 +955,16 @@ ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, n
 }
 #endif
 
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    if (injected(8)) { t_group_failed = t_depth > 0; return fail(ncclInternalError, "injected failure (ncclSend)"); }
+    return enqueue(comm, Op{kSend, sendbuff, nullptr, count, datatype, peer, stream});
+}
+
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    if (injected(9)) { t_group_failed = t_depth > 0; return fail(ncclInternalError, "injected failure (ncclRecv)"); }
+    return enqueue(comm, Op{kRecv, nullptr, recvbuff, count, datatype, peer, stream});
+}
+
 ncclResult_t ncclGroupStart() {
     if (injected(7)) return fail(ncclInternalError, "injected failure (ncclGroupStart)");
     ++t_depth;
@@ -758,6 +1012,7 @@ void fake_rccl_stats(long long out[8]) {
     out[0] = g_stats.all_gathers; out[1] = g_stats.broadcasts; out[2] = g_stats.groups; out[3] = g_stats.copies;
     out[4] = g_stats.inplace_skips; out[5] = g_stats.bytes; out[6] = g_stats.comms_created; out[7] = g_stats.comms_destroyed;
 }
+long long fake_rccl_messages(void) { return g_stats.messages; }   // point-to-point messages delivered
 // the `countdown`-th next call of entry point `which` (see g_fail_which) fails; which = 0 clears
 void fake_rccl_fail(int which, int countdown) {
     g_fail_countdown.store(countdown);

@@ -4,7 +4,7 @@
 
 Everything goes through the C ABI as a Rust / C++ caller would use it - pmx_mgpu_unique_id / pmx_mgpu_create_rank
 (ncclCommInitRank), the library's own device-memory helpers, pmx_mgpu_permute_shards_dev, pmx_mgpu_all_gather_dev,
-pmx_mgpu_merkle_2to1_dev - with no torch in the process.  Rank 0 makes the communicator id and hands it to the other
+pmx_mgpu_gather_dev, pmx_mgpu_permute_gather_dev, pmx_mgpu_merkle_2to1_dev - with no torch in the process.  Rank 0 makes the communicator id and hands it to the other
 ranks through UID_FILE.  Each rank then checks ITS copy of the gathered buffer (every rank's span, in full) and the
 sharded Merkle root against the C restatement and writes a verdict to OUT_JSON."""
 import ctypes
@@ -83,6 +83,27 @@ def main():
             if not np.array_equal(got[s_r:s_r + c_r], want[s_r:s_r + c_r]):
                 bad.append(r)
         res["gather_bad_spans"] = bad
+        # ---- the same result to ONE rank (grouped ncclSend / ncclRecv), then the last step with its gather piece by piece ------------
+        p2p_bad = []
+        root = world - 1
+        if count:
+            upload(d_shard, np.ascontiguousarray(mine))
+        upload(d_all, np.zeros((n_total, t, 4), dtype=np.uint64))
+        g.permute_shards_dev([d_shard.value], n_total)
+        g.gather_dev([d_shard.value], [d_all.value if rank == root else 0], n_total, t, root)
+        download(got, d_all)
+        if not np.array_equal(got, want if rank == root else np.zeros_like(want)):      # only the root's buffer is written
+            p2p_bad.append("gather_dev")
+        for gather_root, chunks in ((-1, 4), (0, 3)):
+            if count:
+                upload(d_shard, np.ascontiguousarray(mine))
+            upload(d_all, np.zeros((n_total, t, 4), dtype=np.uint64))
+            receives = gather_root < 0 or gather_root == rank
+            g.permute_gather_dev([d_shard.value], [d_all.value if receives else 0], n_total, gather_root, chunks)
+            download(got, d_all)
+            if not np.array_equal(got, want if receives else np.zeros_like(want)):
+                p2p_bad.append(f"permute_gather_dev(root {gather_root}, {chunks} pieces)")
+        res["p2p_bad"] = p2p_bad
         # ---- sharded Merkle tree: subtree per rank, all-gather of the roots, top levels on every rank --------------------
         tree_ok = None
         if world & (world - 1) == 0:
@@ -104,7 +125,7 @@ def main():
         for p in (d_shard, d_all):
             lib.pmx_device_free(device, p)
         g.close()
-        res["ok"] = (not bad) and tree_ok is not False
+        res["ok"] = (not bad) and (not p2p_bad) and tree_ok is not False
     except Exception as e:       # noqa: BLE001
         import traceback
         res["error"] = repr(e) + "\n" + traceback.format_exc()[-1500:]

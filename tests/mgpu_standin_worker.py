@@ -38,6 +38,7 @@ def main():
 
     def record(name, ok, detail=""):
         res["scenarios"].append({"name": name, "ok": bool(ok), "detail": str(detail)[-1500:]})
+        print(("ok      " if ok else "FAILED  ") + name, flush=True)      # (a run that hangs shows how far it came)
 
     try:
         from sponge_amd import _lib
@@ -275,6 +276,123 @@ def main():
                 assert np.array_equal(download((n_total, T, 4), alls[l], streams[l]), want), f"rank {l}"
             dfree(*alls)
             return json.dumps(d)
+
+        # ---- the gather to one rank, and the last step with its gather piece by piece (grouped ncclSend / ncclRecv) ----------
+        fake.fake_rccl_messages.restype = ctypes.c_longlong
+
+        def root_case(n_total, root, chunks=None, label=""):
+            """chunks None: permute_shards_dev + gather_dev(root); else permute_gather_dev(root, chunks) (root < 0: every rank).
+            Slots that do not receive get a NULL d_all; the receivers' copies must be the whole permuted batch, and - gather_dev -
+            nobody else's buffers are touched."""
+            whole = synth.random_elements(cfg.field, n_total * T, seed=0x5EED0070 + n_total + 31 * (root + 1)).reshape(n_total, T, 4)
+            want = cr.permute_batch(whole, threads=0)
+            receivers = list(range(world)) if root < 0 else [root]
+            shards, alls = [], []
+            for l in range(world):
+                start, count = g.local_span(n_total, l)
+                d = dalloc(count * T * 32)
+                upload(d, whole[start:start + count], streams[l])
+                shards.append(d)
+                if l in receivers:
+                    a = dalloc(n_total * T * 32)
+                    upload(a, np.full((n_total, T, 4), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64), streams[l])
+                    alls.append(a)
+                else:
+                    alls.append(ctypes.c_void_p(0))
+            before, m0 = stats(), fake.fake_rccl_messages()
+            ptrs = [a.value or 0 for a in alls]
+            if chunks is None:
+                g.permute_shards_dev([s.value for s in shards], n_total)
+                g.gather_dev([s.value for s in shards], ptrs, n_total, T, root)
+            else:
+                g.permute_gather_dev([s.value for s in shards], ptrs, n_total, root, chunks)
+            # (no synchronize: the downloads below run on the slots' own streams, which must have waited for the transfers)
+            for l in receivers:
+                got = download((n_total, T, 4), alls[l], streams[l])
+                assert np.array_equal(got, want), f"{label}: copy of rank {l} (n_total {n_total}, root {root}, chunks {chunks})"
+            for l in range(world):                                  # every shard holds its own permuted span
+                start, count = g.local_span(n_total, l)
+                assert np.array_equal(download((count, T, 4), shards[l], streams[l]), want[start:start + count]), f"{label}: shard {l}"
+            g.synchronize()
+            d = {k: stats()[k] - before[k] for k in before}
+            d["messages"] = fake.fake_rccl_messages() - m0
+            dfree(*shards, *[a for a in alls if a.value])
+            return d
+
+        @scenario("gather_to_one_rank_is_world_minus_one_messages")
+        def _():
+            out = []
+            for root in sorted({0, world - 1}):
+                for n_total in (world * 2048, world * 1500 + 1, world * 1500 + world - 1):
+                    d = root_case(n_total, root, label="to one rank")
+                    per = [g.local_span(n_total, l)[1] for l in range(world)]
+                    assert d["messages"] == world - 1 and d["groups"] == 1 and d["all_gathers"] == 0 and d["broadcasts"] == 0, d
+                    assert d["bytes"] == (n_total - per[root]) * T * 32, d      # 1 / world of the all-gather's bytes per link
+                    out.append(d)
+            return json.dumps(out[-1])
+
+        @scenario("gather_to_one_rank_with_empty_shards_and_bad_arguments")
+        def _():
+            d = root_case(world - 1, 0, label="fewer units than ranks")     # the last rank sends nothing, the root posts no receive for it
+            assert d["messages"] == world - 2, d
+            d = root_case(world - 1, world - 1, label="the root's own shard is the empty one")
+            assert d["messages"] == world - 1, d
+            empty = (ctypes.c_void_p * world)()
+            some = dalloc(64)
+            full = (ctypes.c_void_p * world)(*([some.value] * world))
+            assert lib.pmx_mgpu_gather_dev(g._h, full, full, 0, T, 0) == _lib.PMX_OK
+            assert lib.pmx_mgpu_gather_dev(g._h, full, full, 5, 0, 0) == _lib.PMX_OK
+            assert lib.pmx_mgpu_gather_dev(g._h, None, full, 5, T, 0) == _lib.PMX_ERR_ARG
+            assert lib.pmx_mgpu_gather_dev(g._h, full, full, 5, T, world) == _lib.PMX_ERR_ARG
+            assert lib.pmx_mgpu_gather_dev(g._h, full, full, 5, T, -1) == _lib.PMX_ERR_ARG       # (every rank: pmx_mgpu_all_gather_dev)
+            assert lib.pmx_mgpu_gather_dev(g._h, full, empty, 5, T, 0) == _lib.PMX_ERR_ARG and b"no buffer" in lib.pmx_last_error()
+            assert lib.pmx_mgpu_gather_dev(g._h, full, full, 1 << 62, 1 << 10, 0) == _lib.PMX_ERR_ARG
+            assert lib.pmx_mgpu_permute_gather_dev(g._h, full, full, 5, 0, 0) == _lib.PMX_ERR_ARG
+            assert lib.pmx_mgpu_permute_gather_dev(g._h, full, full, 5, 0, 17) == _lib.PMX_ERR_ARG
+            assert lib.pmx_mgpu_permute_gather_dev(g._h, full, full, 5, world, 2) == _lib.PMX_ERR_ARG
+            assert lib.pmx_mgpu_permute_gather_dev(g._h, full, empty, 5, -1, 2) == _lib.PMX_ERR_ARG
+            assert lib.pmx_mgpu_permute_gather_dev(g._h, full, full, 0, -1, 2) == _lib.PMX_OK
+            dfree(some)
+
+        @scenario("last_step_with_its_gather_piece_by_piece")
+        def _():
+            out = []
+            for root in (-1, 0, world - 1):
+                for n_total, chunks in ((world * 4096, 4), (world * 3000 + 1, 8), (world * 1000 + world - 1, 3), (world * 2 + 1, 16), (world * 4096, 1)):
+                    d = root_case(n_total, root, chunks=chunks, label="piece by piece")
+                    per = [g.local_span(n_total, l)[1] for l in range(world)]
+                    pieces = lambda c: sum(1 for i in range(chunks) if (c // chunks) * (i + 1) + (c % chunks) * (i + 1) // chunks > (c // chunks) * i + (c % chunks) * i // chunks)
+                    if root < 0:
+                        assert d["messages"] == sum(pieces(c) for c in per) * (world - 1), (d, per, chunks)
+                        assert d["bytes"] == (world - 1) * n_total * T * 32, d       # (a rank's own span is a copy on its device, not a message)
+                    else:
+                        assert d["messages"] == sum(pieces(c) for l, c in enumerate(per) if l != root), (d, per, chunks)
+                    assert d["groups"] == chunks and d["all_gathers"] == 0 and d["broadcasts"] == 0, d
+                    out.append(d)
+            return json.dumps(out[:2])
+
+        @scenario("stand_in_refuses_a_send_nobody_receives")
+        def _():
+            """The checker checks: a failure injected into the root's first ncclRecv voids the group (nothing hangs, the error comes back as
+            PMX_ERR_RCCL), and the group works afterwards."""
+            n_total = world * 64
+            shards = [dalloc(g.local_span(n_total, l)[1] * T * 32) for l in range(world)]
+            a = dalloc(n_total * T * 32)
+            alls = [a.value] + [0] * (world - 1)
+            fake.fake_rccl_fail(9, 1)
+            rc = lib.pmx_mgpu_gather_dev(g._h, mgpu._ptr_array([s.value for s in shards]), mgpu._ptr_array(alls), n_total, T, 0)
+            msg = lib.pmx_last_error().decode()
+            fake.fake_rccl_fail(0, 0)
+            assert rc == _lib.PMX_ERR_RCCL and "ncclRecv" in msg, (rc, msg)
+            fake.fake_rccl_fail(8, 1)
+            rc = lib.pmx_mgpu_permute_gather_dev(g._h, mgpu._ptr_array([s.value for s in shards]), mgpu._ptr_array([a.value] * world), n_total, -1, 2)
+            msg = lib.pmx_last_error().decode()
+            fake.fake_rccl_fail(0, 0)
+            assert rc == _lib.PMX_ERR_RCCL and "ncclSend" in msg, (rc, msg)
+            g.synchronize()
+            dfree(*shards, a)
+            root_case(world * 256, 0, label="after the refused groups")
+            return msg
 
         @scenario("stand_in_catches_a_gather_buffer_that_is_too_small")
         def _():

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.pmx_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.pmx_abi_version() == _lib.ABI_VERSION == 5
     # the benchmark diagnostics are a library of their own (include/poseidon_mi355x_diag.h): nothing of them in the shipped one
     diag = declared_functions("poseidon_mi355x_diag.h")
     assert sorted(_lib.DIAG_SIGNATURES) == diag and len(diag) == 3 and not set(diag) & set(names)
