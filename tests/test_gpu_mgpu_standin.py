@@ -153,6 +153,9 @@ except S.PmxError as e:
 
 
 @pytest.mark.parametrize("world,extra", [(2, ["--workload", "c2", "--total-units", "50001", "--gather", "step"]),
+                                         (3, ["--workload", "c2", "--total-units", "50001", "--gather", "root"]),
+                                         (3, ["--workload", "c2", "--total-units", "50001", "--gather", "overlap", "--gather-chunks", "5"]),
+                                         (2, ["--workload", "c2", "--total-log2", "15", "--gather", "overlap-root"]),
                                          (4, ["--workload", "c5", "--total-log2", "14"])])
 def test_bench_multi_rank_path_runs_through_the_device_group(world, extra, tmp_path):
     """`bench.py --gpus N` under torch.distributed.run, N > 1, on one GPU (PMX_BENCH_REHEARSAL=group): the ranks share
@@ -179,6 +182,9 @@ def test_bench_multi_rank_path_runs_through_the_device_group(world, extra, tmp_p
                                               (8, "ranks", ["--workload", "c2", "--total-units", "100003"]),
                                               (2, "single", ["--workload", "c2", "--total-units", "50001"]),
                                               (8, "single", ["--workload", "c2", "--total-log2", "17"]),
+                                              (3, "single", ["--workload", "c2", "--total-units", "50001", "--gather", "root"]),
+                                              (4, "single", ["--workload", "c2", "--total-units", "50001", "--gather", "overlap"]),
+                                              (3, "single", ["--workload", "c2", "--total-log2", "15", "--gather", "overlap-root", "--gather-chunks", "3"]),
                                               (8, "single", ["--workload", "c5", "--total-log2", "17"]),
                                               (4, "ranks", ["--workload", "c5", "--total-log2", "14"])])
 def test_bench_gpus_n_needs_no_launcher(world, form, extra, tmp_path):

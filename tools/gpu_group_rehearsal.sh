@@ -2,7 +2,7 @@
 # bench.py's N > 1 code path on a ONE-GPU box THROUGH THE PRODUCT'S DEVICE GROUP (PMX_BENCH_REHEARSAL=group): W ranks under
 # torch.distributed.run share cuda:0, torch.distributed's control plane runs on gloo, and every data-path call is the one
 # a real multi-GPU run makes - pmx_mgpu_create_rank, pmx_mgpu_permute_shards_dev, pmx_mgpu_all_gather_dev (equal and ragged),
-# pmx_mgpu_merkle_2to1_dev - with the collective library named by PMX_RCCL_LIBRARY: the tests' stand-in (tests/fake_rccl, ranks
+# pmx_mgpu_gather_dev, pmx_mgpu_permute_gather_dev, pmx_mgpu_merkle_2to1_dev - with the collective library named by PMX_RCCL_LIBRARY: the tests' stand-in (tests/fake_rccl, ranks
 # in different processes; RCCL itself refuses two ranks on one device).  Every rank verifies its whole gathered copy.
 # (PMX_BENCH_REHEARSAL=group makes bench.py bind the test-hook build of the library, libposeidon_mi355x_test.so: only that build
 # reads PMX_RCCL_LIBRARY.)  The numbers are meaningless; what counts is rc = 0, "verified": true and rccl.ranks = W on every line.
@@ -40,6 +40,9 @@ run c2_w2_step 2 --workload c2 --total-log2 16 --gather step
 run c2_w3_ragged 3 --workload c2 --total-units 100003
 run c2_w8_final 8 --workload c2 --total-log2 18
 run c2_w8_ragged 8 --workload c2 --total-units 100003 --gather step
+run c2_w3_root 3 --workload c2 --total-units 100003 --gather root
+run c2_w8_overlap 8 --workload c2 --total-log2 18 --gather overlap
+run c2_w3_overlap_root 3 --workload c2 --total-units 100003 --gather overlap-root --gather-chunks 5
 run c3_w2 2 --workload c3 --total-log2 14
 run c5_w2 2 --workload c5 --total-log2 16
 run c5_w8 8 --workload c5 --total-log2 18
@@ -66,6 +69,9 @@ bare bare_c5_w8 8 --workload c5 --total-log2 18
 ( unset FAKE_RCCL_XPROC
 bare single_c2_w2 2 --single-process --workload c2 --total-units 100003
 bare single_c2_w8 8 --single-process --workload c2 --total-log2 18
+bare single_c2_w3_root 3 --single-process --workload c2 --total-units 100003 --gather root
+bare single_c2_w8_overlap 8 --single-process --workload c2 --total-log2 18 --gather overlap
+bare single_c2_w3_overlap_root 3 --single-process --workload c2 --total-units 100003 --gather overlap-root --gather-chunks 3
 bare single_c5_w8 8 --single-process --workload c5 --total-log2 18 )
 ls /dev/shm | grep -c '^fake_rccl_' | sed 's/^/leftover shared-memory objects: /'
 echo "failures: $fails"
