@@ -78,3 +78,44 @@ def merkle_root_sharded(leaves_local: torch.Tensor, subtree_root: Callable[[torc
         return root_local.reshape(4)
     roots = all_gather_equal(root_local)              # [world][4], rank order = leaf order
     return subtree_root(roots).reshape(4)
+
+
+def piece_span(count: int, chunks: int, i: int) -> Tuple[int, int]:
+    """Piece i of `chunks` of a shard of `count` units (pmx_mgpu.cpp: piece_span): [first, first + cnt), pieces differ by at most one unit."""
+    lo = count // chunks * i + count % chunks * i // chunks
+    hi = count // chunks * (i + 1) + count % chunks * (i + 1) // chunks
+    return lo, hi - lo
+
+
+def gather_in_pieces(local: torch.Tensor, out: torch.Tensor | None, root: int, chunks: int, step: Callable[[torch.Tensor], None]) -> None:
+    """pmx_mgpu_permute_gather_dev restated: the last step on `local` ([count, ...], in place through `step`) in `chunks` pieces, piece i's
+    transfers - to `root`, or to every rank when root < 0 - posted right behind piece i's step as point-to-point messages; `out`
+    ([n_total, ...]) is written on the receivers only.  Every rank derives every peer's piece from (n_total, world, chunks, i) alone."""
+    world, me = dist.get_world_size(), dist.get_rank()
+    n_total = out.shape[0] if out is not None else None
+    if n_total is None:                       # a rank that does not receive still needs the total to know nothing about the others: it only sends
+        assert root >= 0 and root != me
+    i_receive = root < 0 or root == me
+    pending = []
+    for i in range(chunks):
+        pf, pc = piece_span(local.shape[0], chunks, i)
+        if pc:
+            step(local[pf:pf + pc])
+        ops = []
+        if i_receive:
+            start, _ = shard_bounds(n_total, world, me)
+            out[start + pf:start + pf + pc].copy_(local[pf:pf + pc])
+        for peer in range(world):
+            if peer == me:
+                continue
+            if (root < 0 or root == peer) and pc:
+                ops.append(dist.P2POp(dist.isend, local[pf:pf + pc].contiguous(), peer))
+            if i_receive:
+                qs, qn = shard_bounds(n_total, world, peer)
+                qf, qc = piece_span(qn, chunks, i)
+                if qc:
+                    ops.append(dist.P2POp(dist.irecv, out[qs + qf:qs + qf + qc], peer))
+        if ops:
+            pending += dist.batch_isend_irecv(ops)      # (the next piece's step runs while these are in flight)
+    for w in pending:
+        w.wait()

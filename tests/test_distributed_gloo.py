@@ -59,6 +59,18 @@ def _worker(rank, port, results):
         whole = torch.zeros((n_ragged, t, 4), dtype=torch.int64)
         D.all_gather_rows(torch.from_numpy(cr.permute_batch(mine, threads=1).view(np.int64)), whole, host_staged=True)
         results[f"ragged{rank}"] = whole.numpy().view(np.uint64).copy()
+        # 4. the last step and its gather piece by piece (pmx_mgpu_permute_gather_dev's bookkeeping): ragged shards, to every rank and to rank 1
+        for to, chunks in ((-1, 3), (1, 4)):
+            mine = torch.from_numpy(synth.random_elements(f, r_count * t, SEED + 2, offset=r_start * t).reshape(r_count, t, 4).view(np.int64).copy())
+            receives = to < 0 or to == rank
+            whole = torch.zeros((n_ragged, t, 4), dtype=torch.int64) if receives else None
+
+            def step(piece: torch.Tensor) -> None:
+                piece.copy_(torch.from_numpy(cr.permute_batch(piece.numpy().view(np.uint64), threads=1).view(np.int64)))
+
+            D.gather_in_pieces(mine, whole, to, chunks, step)
+            if receives:
+                results[f"pieces{to}_{rank}"] = whole.numpy().view(np.uint64).copy()
         if rank == 0:
             results["gathered"] = gathered.numpy().view(np.uint64).copy()
             results["root"] = root.numpy().view(np.uint64).copy()
@@ -81,6 +93,17 @@ def test_two_rank_shard_gather_and_merkle():
     want = cr.permute_batch(synth.random_elements(f, n_ragged * 3, SEED + 2).reshape(n_ragged, 3, 4), threads=2)
     for rank in range(WORLD):
         assert np.array_equal(results[f"ragged{rank}"].reshape(-1, 3, 4), want), rank
+        assert np.array_equal(results[f"pieces-1_{rank}"].reshape(-1, 3, 4), want), rank       # to every rank, three pieces
+    assert np.array_equal(results["pieces1_1"].reshape(-1, 3, 4), want) and "pieces1_0" not in results   # to rank 1 only, four pieces
+
+
+@pytest.mark.parametrize("count,chunks", [(0, 4), (1, 16), (7, 3), (16, 16), (100003, 8), (65536, 5)])
+def test_pieces_partition_a_shard(count, chunks):
+    spans = [D.piece_span(count, chunks, i) for i in range(chunks)]
+    assert spans[0][0] == 0 and sum(c for _, c in spans) == count
+    for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+        assert s0 + c0 == s1
+    assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
 
 
 @pytest.mark.parametrize("n,world", [(10, 3), (8, 8), (7, 8), (1 << 24, 8), (5, 1)])
