@@ -279,7 +279,7 @@ def main_single_process(args):
     group = mgpu.DeviceGroup.single_process(cfg, devices=devices)
     info = group.info()
     rccl = {"ranks": info["comm_ranks"], "version": info["rccl_version_str"], "rank0_is": info["comm_first_rank"],
-            "via": "pmx_mgpu_create (ncclCommInitAll, one process); gather = pmx_mgpu_all_gather_dev (ncclAllGather / grouped ncclBroadcast)"}
+            "via": "pmx_mgpu_create (ncclCommInitAll, one process); gather = " + gather_entry(args)}
     if rehearsal:
         rccl["via"] += "; REHEARSAL: the slots share GPUs, collective library = " + os.environ.get("PMX_RCCL_LIBRARY", "librccl.so.1 on the search path")
     ctx = group.context(0)
@@ -544,7 +544,7 @@ def main():
             group = mgpu.DeviceGroup.one_rank(cfg, local_rank, rank, world, uid[0])
             info = group.info()
             rccl = {"ranks": info["comm_ranks"], "version": info["rccl_version_str"], "rank0_is": info["comm_first_rank"],
-                    "via": "pmx_mgpu_create_rank (ncclCommInitRank); gather = pmx_mgpu_all_gather_dev (ncclAllGather)"}
+                    "via": "pmx_mgpu_create_rank (ncclCommInitRank); gather = " + gather_entry(args)}
         except S.PmxError as e:
             group_error = str(e)
         if group is not None and rehearsal:
@@ -829,6 +829,14 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
     return out
 
 
+def gather_entry(args):
+    """the C ABI entry point (and RCCL calls) behind --gather"""
+    return {"root": "pmx_mgpu_gather_dev (grouped ncclSend / ncclRecv)",
+            "overlap": "pmx_mgpu_permute_gather_dev, to every rank (grouped ncclSend / ncclRecv, piece by piece)",
+            "overlap-root": "pmx_mgpu_permute_gather_dev, to rank 0 (grouped ncclSend / ncclRecv, piece by piece)",
+            "none": "none"}.get(args.gather, "pmx_mgpu_all_gather_dev (ncclAllGather / grouped ncclBroadcast)")
+
+
 def gather_model(args, world, n, t, not_a_permutation_batch):
     """(milliseconds, text): what the gather should ADD to the K steps if every shard travels over its own xGMI link at the link's rate
     (MI355X: 7 links x ~153 GB/s per GPU and direction, point to point).  To every rank or to rank 0 alike, a receiver takes world - 1
@@ -854,7 +862,7 @@ def matrix_products_per_permutation(t, rf, rp, window, hist_rows):
     (states 0-31 and 32-63 of the wave), one k-step per input element of a row.  Every full round closes with a layer of t rows over t
     inputs; the partial rounds run as ceil(rp / K) windows - the first the short one - each closed by a layer of t rows over t - 1 + K
     inputs, and (t >= 4) the S-box inputs x_3 .. x_K of a window are rows of 2 .. K - 1 inputs.  (C3: 1296 + 2142 + 424 = 3862, the
-    count of the SQ_INSTS_VALU_MFMA pass in profiles/r06/z_2.27GHz_pmc_c3_stalls.txt.)"""
+    count of the SQ_INSTS_VALU_MFMA pass in profiles/r06/z_2.24GHz_pmc_c3_stalls.txt.)"""
     products = rf * t * 2 * t
     if window and rp:
         n_win = -(-rp // window)
