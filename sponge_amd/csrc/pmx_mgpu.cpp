@@ -330,6 +330,7 @@ extern "C" int pmx_mgpu_synchronize(pmx_mgpu *g) {
         if (!g->ctx[l]) continue;
         PMX_BIND(g->ctx[l]);
         PMX_HIP(hipStreamSynchronize(g->ctx[l]->stream));
+        PMX_HIP(hipStreamSynchronize(g->ctx[l]->stream2));   // (pmx_mgpu_permute_gather_dev's transfers: joined into `stream` by the call itself unless it failed half way)
     }
     return PMX_OK;
     PMX_ABI_END
