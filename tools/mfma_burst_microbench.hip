@@ -109,31 +109,37 @@ static double run(int waves, int n_cu, size_t cu_lds, uint32_t *d_out) {
     return ms[3 + (ms.size() - 3) / 2] * 1e6 / trips / waves;   // ns of SIMD time per unit
 }
 
-// the same with the accumulators in ACCUMULATION registers (the upper half of the unified file; results would come back through v_accvgpr_read)
-#define OPS_ACC : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [d1] "+a"(d1), [d2] "+a"(d2) : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [y] "v"(y), [p] "v"(p), [q] "v"(q), [b] "v"(b) : "vcc"
-template <int KIND>
+// the same with operands in ACCUMULATION registers (the upper half of the unified file): WHICH bit 0 the accumulators (results would come
+// back through v_accvgpr_read), bit 1 the A operand (a load can land there directly), bit 2 the B operand (a v_accvgpr_write per word)
+#define OPS_X(CC, AC, BC) : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [d1] CC(d1), [d2] CC(d2) : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [y] "v"(y), [p] AC(p), [q] AC(q), [b] BC(b) : "vcc"
+template <int KIND, int WHICH>
 __global__ void __launch_bounds__(256) bench_acc(uint32_t *out, int trips, uint32_t seed) {
     uint64_t a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3;
     uint32_t x0 = threadIdx.x | 1, x1 = x0 + 2, x2 = x0 + 4, x3 = x0 + 6, y = seed * 2654435761u | 1;
     v16i d1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d2 = d1;
     v4i p = {(int)x0, (int)x1, (int)x2, (int)x3}, q = {(int)x3, (int)x2, (int)x1, (int)x0}, b = {(int)y, (int)x1, (int)y, (int)x3};
     lds_pin[threadIdx.x] = make_uint4(x0, x1, x2, x3);
-    for (int i = 0; i < trips; ++i) {
-        if constexpr (KIND == MFMA_ONLY) asm volatile(R16(MF(d1, p) MF(d2, p)) OPS_ACC);
-        if constexpr (KIND == ALT) asm volatile(R8(MF(d1, p) MF(d2, p) MF(d1, q) MF(d2, q)) MADS OPS_ACC);
-        if constexpr (KIND == SPREAD) asm volatile(R16(MF(d1, p) MAD26 MF(d2, p) MAD26) OPS_ACC);
+#define BODY(OPS_)                                                                                       \
+    for (int i = 0; i < trips; ++i) {                                                                    \
+        if constexpr (KIND == MFMA_ONLY) asm volatile(R16(MF(d1, p) MF(d2, p)) OPS_);                    \
+        if constexpr (KIND == ALT) asm volatile(R8(MF(d1, p) MF(d2, p) MF(d1, q) MF(d2, q)) MADS OPS_);  \
+        if constexpr (KIND == SPREAD) asm volatile(R16(MF(d1, p) MAD26 MF(d2, p) MAD26) OPS_);           \
     }
+    if constexpr (WHICH == 1) { BODY(OPS_X("+a", "v", "v")) }
+    if constexpr (WHICH == 2) { BODY(OPS_X("+v", "a", "v")) }
+    if constexpr (WHICH == 6) { BODY(OPS_X("+v", "a", "a")) }
+    if constexpr (WHICH == 7) { BODY(OPS_X("+a", "a", "a")) }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     uint32_t r = (uint32_t)(a0 ^ a1 ^ a2 ^ a3) ^ (uint32_t)((a0 ^ a1 ^ a2 ^ a3) >> 32);
     for (int k = 0; k < 16; ++k) r ^= (uint32_t)d1[k] ^ (uint32_t)d2[k];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r ^ lds_pin[0].x;
 }
-template <int KIND>
+template <int KIND, int WHICH = 1>
 static double run_acc(int waves, int n_cu, size_t cu_lds, uint32_t *d_out) {
     const int blocks = n_cu * waves;
     size_t lds = std::min(cu_lds / waves - 1024, (size_t)64 * 1024);
     if (waves == 1) lds = 64 * 1024;
-    CHECK(hipFuncSetAttribute((const void *)bench_acc<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute((const void *)bench_acc<KIND, WHICH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int trips = 256;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -141,7 +147,7 @@ static double run_acc(int waves, int n_cu, size_t cu_lds, uint32_t *d_out) {
     std::vector<double> ms;
     for (int rep = 0; rep < 10; ++rep) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(bench_acc<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, trips, 1u + rep);
+        hipLaunchKernelGGL((bench_acc<KIND, WHICH>), dim3(blocks), dim3(256), lds, 0, d_out, trips, 1u + rep);
         CHECK(hipGetLastError());
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
@@ -281,6 +287,10 @@ int main() {
         printf("  %8.1f  matrix only\n", run_acc<MFMA_ONLY>(w, n_cu, cu_lds, d_out));
         { const double t = run_acc<ALT>(w, n_cu, cu_lds, d_out); printf("  %8.1f  alt: a product costs %5.2f ns\n", t, (t - v) / 32); }
         { const double t = run_acc<SPREAD>(w, n_cu, cu_lds, d_out); printf("  %8.1f  spread: a product costs %5.2f ns\n", t, (t - v) / 32); }
+        printf("    the A operand in accumulation registers (a load can land there): alt %5.2f ns, spread %5.2f ns per product\n",
+               (run_acc<ALT, 2>(w, n_cu, cu_lds, d_out) - v) / 32, (run_acc<SPREAD, 2>(w, n_cu, cu_lds, d_out) - v) / 32);
+        printf("    A and B there: alt %5.2f, spread %5.2f;  A, B and the accumulators: alt %5.2f, spread %5.2f\n", (run_acc<ALT, 6>(w, n_cu, cu_lds, d_out) - v) / 32,
+               (run_acc<SPREAD, 6>(w, n_cu, cu_lds, d_out) - v) / 32, (run_acc<ALT, 7>(w, n_cu, cu_lds, d_out) - v) / 32, (run_acc<SPREAD, 7>(w, n_cu, cu_lds, d_out) - v) / 32);
         const double ms_ = run<SMALL_ONLY>(w, n_cu, cu_lds, d_out);
         printf("  %8.1f  %s  (%.2f ns per two = the multiply-adds of one 32x32x32)\n", ms_, kNames[SMALL_ONLY], ms_ / 32);
         line(SMALL_ALT, run<SMALL_ALT>(w, n_cu, cu_lds, d_out));
