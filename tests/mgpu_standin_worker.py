@@ -371,6 +371,44 @@ def main():
                     out.append(d)
             return json.dumps(out[:2])
 
+        @scenario("wide_states_gathered_piece_by_piece_and_to_one_rank")
+        def _():
+            """t = 9 (rows of 36 words, the window engine of two waves per SIMD): a second group on the same slots, ragged shards, both new entry points"""
+            name9, t9 = "bn254_t9_a5_8_57", 9
+            cfg9, cr9 = product_config(name9), c_oracle(name9)
+            g9 = mgpu.DeviceGroup.single_process(cfg9, devices=[0] * world)
+            try:
+                st9 = [g9.stream(l) for l in range(world)]
+                n_total = world * 700 + 1
+                whole = synth.random_elements(cfg9.field, n_total * t9, seed=0x5EED0079).reshape(n_total, t9, 4)
+                want = cr9.permute_batch(whole, threads=0)
+                for root, chunks in ((-1, 3), (world - 1, None), (0, 5)):
+                    receivers = list(range(world)) if root < 0 else [root]
+                    shards, alls = [], []
+                    for l in range(world):
+                        start, count = g9.local_span(n_total, l)
+                        d = dalloc(count * t9 * 32)
+                        upload(d, whole[start:start + count], st9[l])
+                        shards.append(d)
+                        if l in receivers:
+                            a = dalloc(n_total * t9 * 32)
+                            upload(a, np.zeros((n_total, t9, 4), dtype=np.uint64), st9[l])
+                            alls.append(a)
+                        else:
+                            alls.append(ctypes.c_void_p(0))
+                    ptrs = [a.value or 0 for a in alls]
+                    if chunks is None:
+                        g9.permute_shards_dev([x.value for x in shards], n_total)
+                        g9.gather_dev([x.value for x in shards], ptrs, n_total, t9, root)
+                    else:
+                        g9.permute_gather_dev([x.value for x in shards], ptrs, n_total, root, chunks)
+                    for l in receivers:
+                        assert np.array_equal(download((n_total, t9, 4), alls[l], st9[l]), want), (root, chunks, l)
+                    g9.synchronize()
+                    dfree(*shards, *[a for a in alls if a.value])
+            finally:
+                g9.close()
+
         @scenario("stand_in_refuses_a_send_nobody_receives")
         def _():
             """The checker checks: a failure injected into the root's first ncclRecv voids the group (nothing hangs, the error comes back as

@@ -54,7 +54,7 @@ def test_every_multi_rank_branch_on_one_gpu(world, tmp_path):
     assert {"host_batch_fan_out", "fan_out_failure_on_a_nonzero_slot_and_serial_fallback", "gather_equal_shards_is_one_all_gather",
             "gather_ragged_shards_is_one_broadcast_per_rank", "gather_with_empty_shards", "gather_to_one_rank_is_world_minus_one_messages",
             "gather_to_one_rank_with_empty_shards_and_bad_arguments", "last_step_with_its_gather_piece_by_piece",
-            "stand_in_refuses_a_send_nobody_receives", "sharded_merkle_host_leaves",
+            "stand_in_refuses_a_send_nobody_receives", "wide_states_gathered_piece_by_piece_and_to_one_rank", "sharded_merkle_host_leaves",
             "sharded_merkle_device_resident_every_rank_holds_the_whole_top", "one_group_per_rank_create_rank",
             "collective_failures_are_status_codes", "every_communicator_was_destroyed"} <= names
     assert res["ok"] and p.returncode == 0
