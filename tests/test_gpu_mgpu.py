@@ -73,6 +73,40 @@ def test_device_resident_shards_and_rccl_gather(n_total):
     g.close()
 
 
+@pytest.mark.parametrize("root,chunks", [(0, None), (-1, 4), (0, 8), (-2, 3)])
+def test_gather_to_one_rank_and_the_last_step_piece_by_piece(root, chunks):
+    """pmx_mgpu_gather_dev (chunks None) and pmx_mgpu_permute_gather_dev on real RCCL with every GPU of the box: grouped ncclSend / ncclRecv
+    over xGMI from two GPUs up, the own-piece copies alone on a one-GPU box.  root -2 = the LAST rank; ragged shards from two GPUs up.
+    Only the receivers' buffers are written; the reads below run on the group's own streams, which must have waited for the transfers."""
+    cfg, g = _group()
+    world = g.world
+    root = world - 1 if root == -2 else root
+    n_total = (1 << 15) * world + (1 if world > 1 else 0)
+    whole = synth.random_elements(cfg.field, n_total * 3, seed=0x5EED0048).reshape(n_total, 3, 4)
+    receivers = list(range(world)) if root < 0 else [root]
+    shards, alls = [], []
+    for l, dev in enumerate(g.devices):
+        start, count = g.local_span(n_total, l)
+        shards.append(torch.from_numpy(whole[start:start + count].view(np.int64).copy()).to(f"cuda:{dev}"))
+        alls.append(torch.zeros((n_total, 3, 4), dtype=torch.int64, device=f"cuda:{dev}") if l in receivers else None)
+    for dev in g.devices:
+        torch.cuda.synchronize(dev)
+    ptrs = [a.data_ptr() if a is not None else 0 for a in alls]
+    if chunks is None:
+        g.permute_shards_dev([s.data_ptr() for s in shards], n_total)
+        g.gather_dev([s.data_ptr() for s in shards], ptrs, n_total, 3, root)
+    else:
+        g.permute_gather_dev([s.data_ptr() for s in shards], ptrs, n_total, root, chunks)
+    g.synchronize()
+    want = c_oracle(NAME).permute_batch(whole, threads=0)
+    for l in receivers:
+        assert np.array_equal(alls[l].cpu().numpy().view(np.uint64), want), f"copy on local device {l}"
+    for l in range(world):
+        start, count = g.local_span(n_total, l)
+        assert np.array_equal(shards[l].cpu().numpy().view(np.uint64), want[start:start + count]), f"shard {l}"
+    g.close()
+
+
 def test_ragged_gather_needs_two_gpus():
     """The grouped-ncclBroadcast branch of pmx_mgpu_all_gather_dev (n_total % world != 0) cannot be reached with one rank.
     An explicit skip on a one-GPU box, not a silent pass through the equal-shard branch."""
