@@ -1,7 +1,4 @@
 #!/bin/bash
-# A/B: the full rounds' S-boxes two at a time (independent chains side by side) at t >= 6
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
-{
-WORKLOADS="c3 w6 h9" STEPS=20 bash tools/ab/ab.sh
-} > gpurun_out/ab_sbox_pairs.txt 2>&1
-cat gpurun_out/ab_sbox_pairs.txt
+# the full rounds' S-boxes two per trip (-DPMX_SBOX_PAIRS) against HEAD
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+VARIANTS="head pairs" WORKLOADS="c2 c3 w6 w8 h9 k3 w4" ROUNDS=3 bash tools/ab/ab_multi.sh
