@@ -817,7 +817,9 @@ def result_line(args, ctx, peak, slot, *, world, n, n_total, units_per_step, ela
         # shader clocks one SIMD spends per permutation, and - where the instruction count is known - clocks per VALU instruction and SIMD
         # (the issue slot is 4: one wave instruction per 16 lanes x 4 passes)
         "clock_normalised": clock_normalised(kernel_s, peak.shader_clock_hz, peak.compute_units, units_per_step / max(world, 1), valu_issue),
-        "gather_ms": 1e3 * (dev_s - steps_s) if world > 1 else None,
+        # (overlap forms: the transfers run inside the K-th step - there is no epilogue to time; compare ms_per_step x steps with --gather none)
+        "gather_ms": 1e3 * (dev_s - steps_s) if (world > 1 and args.gather not in ("overlap", "overlap-root")) else None,
+        "gather_inside_last_step": (world > 1 and args.gather in ("overlap", "overlap-root") and not (merkle or hashing or duplex)) or None,
         # what the final gather should take if every peer's shard arrives over its own xGMI link at the link's rate (MI355X: 7 links x
         # ~153 GB/s per GPU, point to point): one shard's bytes / 153 GB/s, for up to 8 GPUs of one node - the first multi-GPU run judges
         # itself against this (tools/first_8gpu_run.sh prints both)

@@ -210,7 +210,9 @@ def test_bench_gpus_n_needs_no_launcher(world, form, extra, tmp_path):
     assert p.returncode == 0 and len(lines) == 1, (text[-2000:], err[-3000:])
     d = lines[0]
     assert d["verified"] is True and d["n_gpus"] == world and d["rccl"]["ranks"] == world, d
-    assert d["cpu_baseline"] is None and d["gather_ms"] is not None and "REHEARSAL" in d["config"]
+    assert d["cpu_baseline"] is None and "REHEARSAL" in d["config"]
+    overlapped = any(x in ("overlap", "overlap-root") for x in extra)
+    assert (d["gather_ms"] is None and d["gather_inside_last_step"] is True) if overlapped else d["gather_ms"] is not None
     if form == "single":
         assert "pmx_mgpu_create (ncclCommInitAll" in d["rccl"]["via"] and "launcher" in d["config"]
     else:

@@ -58,5 +58,5 @@ for f in sorted(glob.glob(os.path.join(out, "c?_n*_*.json"))):
     except Exception as e:
         print("%-32s no JSON line (%s): %s" % (os.path.basename(f), e, open(f[:-5] + ".err").read()[-300:].replace("\n", " | ")))
 print("(predicted: one shard over one xGMI link at 153 GB/s - ~1.3 ms for the C4 gather at N = 8, to every rank or to rank 0 alike; the overlap forms")
-print(" leave one piece's transfer behind the last kernel.  In the overlap forms gather_ms is ~0 by construction: compare ms/step x steps instead.)")
+print(" leave one piece's transfer behind the last kernel.  The overlap forms have no epilogue to time (gather_ms '-'): compare their ms/step x steps with the other forms'.)")
 PY
